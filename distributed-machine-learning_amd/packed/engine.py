@@ -1,0 +1,204 @@
+"""Pack engines: the device-side trainer behind the packed executor.
+
+``PackEngine`` is the small interface the executor drives (load / evict / train_epoch / evaluate /
+export / clone).  ``TorchPackEngine`` implements it with one ordinary ``MLPRegressor`` +
+``torch.optim`` optimiser per slot: it is the CPU path (the "plumbing" configuration: a few
+trials on a 20k x 8 table) and the oracle the HIP engine is tested against -- "a pack of T trials
+equals T independent single-trial trainings" is checked against *this* code.
+
+What both engines guarantee, so that a trial's outcome never depends on where it ran:
+initial weights come from ``init_mlp_state(seed, trial_index)``; the row order of epoch ``e`` is the
+keyed Feistel permutation ``(seed, trial_index, e)``; an epoch is ``N_train // batch_size`` steps
+(the ragged tail batch is dropped); validation metrics are sample-weighted means over the whole
+validation set.  The training loop has the same steps as the reference's
+(/root/reference/ray-tune-hpo-regression.py:322-370): zero_grad, forward, loss, backward,
+optional global-norm clip, optimiser step, LR schedule; but the loss is accumulated on the device
+and read once per epoch instead of ``.item()`` per batch.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .permutation import permute, round_keys
+from .trainable import PackedTrainable
+from ..models.mlp import MLPRegressor, MLPTrialSpec, init_mlp_state, lr_factor
+from ..train.losses import MAPE_EPS, get_criterion
+from ..train.optim import build_optimizer
+
+
+class PackEngine:
+    """Interface; slots are integers in ``[0, capacity)``."""
+
+    capacity: int
+    name = "base"
+
+    def load(self, slot: int, trial_index: int, config: Dict, state: Optional[Dict] = None) -> None:
+        raise NotImplementedError
+
+    def evict(self, slot: int) -> None:
+        raise NotImplementedError
+
+    def occupied(self) -> List[int]:
+        raise NotImplementedError
+
+    def train_epoch(self) -> None:
+        raise NotImplementedError
+
+    def evaluate(self) -> Dict[int, Dict[str, float]]:
+        raise NotImplementedError
+
+    def export(self, slot: int) -> Dict[str, Any]:
+        raise NotImplementedError
+
+    def clone(self, src: int, dst: int, config: Dict) -> None:
+        """PBT exploit + explore inside the pack: ``dst`` takes ``src``'s weights and optimiser state."""
+        raise NotImplementedError
+
+    def import_state(self, slot: int, state: Dict, config: Dict) -> None:
+        """Overwrite a loaded slot's weights/optimiser state (cross-GPU PBT exploit)."""
+        raise NotImplementedError
+
+    def close(self) -> None:
+        pass
+
+
+class _Slot:
+    __slots__ = ("trial_index", "spec", "model", "opt", "epoch", "step", "train_loss", "config")
+
+
+class TorchPackEngine(PackEngine):
+    name = "torch"
+
+    def __init__(self, trainable: PackedTrainable, device: str = "cpu", capacity: Optional[int] = None,
+                 seed: int = 0):
+        if trainable.model != "mlp":
+            raise ValueError("TorchPackEngine trains the 'mlp' family")
+        self.t = trainable
+        self.device = torch.device(device)
+        self.capacity = int(capacity or trainable.capacity or 64)
+        self.seed = int(seed or 0)
+        self.Xtr = trainable.train[0].to(self.device, torch.float32)
+        self.ytr = trainable.train[1].to(self.device, torch.float32)
+        self.Xva = trainable.val[0].to(self.device, torch.float32)
+        self.yva = trainable.val[1].to(self.device, torch.float32)
+        self.slots: Dict[int, _Slot] = {}
+
+    # ------------------------------------------------------------------ slot management
+    def occupied(self) -> List[int]:
+        return sorted(self.slots)
+
+    def _build(self, spec: MLPTrialSpec, config: Dict):
+        model = MLPRegressor(spec.in_features, spec.hidden_sizes).to(self.device)
+        opt = build_optimizer(spec.optimizer, model.parameters(), spec.learning_rate, spec.weight_decay,
+                              spec.momentum, spec.beta1, spec.beta2, spec.eps)
+        return model, opt
+
+    def load(self, slot, trial_index, config, state=None):
+        if slot in self.slots:
+            raise RuntimeError(f"slot {slot} is occupied")
+        spec = MLPTrialSpec.from_config(config, self.t.in_features)
+        s = _Slot()
+        s.trial_index, s.spec, s.config = int(trial_index), spec, dict(config)
+        s.model, s.opt = self._build(spec, config)
+        s.epoch, s.step, s.train_loss = 0, 0, float("nan")
+        if state is not None and "model" in state:
+            s.model.load_state_dict(state["model"])
+            if "optimizer" in state and state["optimizer"] is not None:
+                try:
+                    s.opt.load_state_dict(state["optimizer"])
+                except (ValueError, KeyError):
+                    pass      # optimiser family changed (PBT explore): keep fresh moments
+            s.epoch = int(state.get("epoch", 0))
+            s.step = int(state.get("step", 0))
+        else:
+            s.model.load_state_dict(init_mlp_state(spec, self.seed, trial_index))
+        self.slots[slot] = s
+
+    def evict(self, slot):
+        self.slots.pop(slot, None)
+
+    def export(self, slot):
+        s = self.slots[slot]
+        return {"model": {k: v.detach().cpu().clone() for k, v in s.model.state_dict().items()},
+                "optimizer": s.opt.state_dict(), "epoch": s.epoch, "step": s.step,
+                "trial_index": s.trial_index}
+
+    def clone(self, src, dst, config):
+        state = self.export(src)
+        keep = self.slots[dst].trial_index
+        self.evict(dst)
+        self.load(dst, keep, config, state=state)
+        self._apply_hparams(self.slots[dst])
+
+    def import_state(self, slot, state, config):
+        keep = self.slots[slot].trial_index
+        self.evict(slot)
+        self.load(slot, keep, config, state=state)
+        self._apply_hparams(self.slots[slot])
+
+    @staticmethod
+    def _apply_hparams(s: _Slot) -> None:
+        for g in s.opt.param_groups:
+            g["lr"] = s.spec.learning_rate
+            g["weight_decay"] = s.spec.weight_decay
+            if "betas" in g:
+                g["betas"] = (s.spec.beta1, s.spec.beta2)
+            if "momentum" in g:
+                g["momentum"] = s.spec.momentum
+
+    # ------------------------------------------------------------------ training
+    def _train_slot_epoch(self, s: _Slot) -> None:
+        n = self.Xtr.shape[0]
+        b = min(s.spec.batch_size, n)
+        steps = n // b
+        keys = round_keys(self.seed, s.trial_index, s.epoch)
+        perm = torch.from_numpy(permute(np.arange(steps * b, dtype=np.uint32), n, keys)).to(self.device)
+        crit = get_criterion(s.spec.loss_function)
+        loss_sum = torch.zeros((), device=self.device)
+        s.model.train()
+        for i in range(steps):
+            idx = perm[i * b:(i + 1) * b]
+            for g in s.opt.param_groups:
+                g["lr"] = s.spec.learning_rate * lr_factor(s.step, s.spec.warmup_steps, s.spec.total_steps)
+            s.opt.zero_grad(set_to_none=True)
+            out = s.model(self.Xtr[idx])
+            loss = crit(out, self.ytr[idx])
+            loss.backward()
+            if s.spec.gradient_clipping > 0:
+                torch.nn.utils.clip_grad_norm_(s.model.parameters(), s.spec.gradient_clipping)
+            s.opt.step()
+            s.step += 1
+            loss_sum += loss.detach()
+        s.train_loss = float(loss_sum) / max(steps, 1)
+        s.epoch += 1
+
+    def train_epoch(self):
+        for slot in self.occupied():
+            self._train_slot_epoch(self.slots[slot])
+
+    @torch.no_grad()
+    def evaluate(self):
+        out: Dict[int, Dict[str, float]] = {}
+        n = self.Xva.shape[0]
+        for slot in self.occupied():
+            s = self.slots[slot]
+            s.model.eval()
+            crit = s.spec.loss_function
+            se = torch.zeros((), device=self.device, dtype=torch.float64)
+            ape = torch.zeros((), device=self.device, dtype=torch.float64)
+            ls = torch.zeros((), device=self.device, dtype=torch.float64)
+            from ..train.losses import elementwise_loss
+            for c0 in range(0, n, self.t.val_chunk):
+                x, y = self.Xva[c0:c0 + self.t.val_chunk], self.yva[c0:c0 + self.t.val_chunk]
+                o = s.model(x)
+                se += ((o - y) ** 2).sum().double()
+                ape += ((o - y).abs() / (y.abs() + MAPE_EPS)).sum().double()
+                ls += elementwise_loss(crit, o, y).sum().double()
+            out[slot] = {"train_loss": s.train_loss,
+                         "validation_loss": float(ls) / n,
+                         "validation_mse": float(se) / n,
+                         "validation_mape": 100.0 * float(ape) / n}
+        return out

@@ -1,0 +1,219 @@
+"""PackedExecutor: trials as slots of a per-GPU pack, advanced one epoch per scheduling round.
+
+Replaces the reference's "one Ray actor + one GPU per trial" placement
+(/root/reference/ray-tune-hpo-regression.py:475).  Every rank (one process per GPU) runs this
+executor under an identical ``TrialRunner``: searcher and scheduler are replicated and seeded
+alike, so all ranks create the same trials in the same order.  A trial is *owned* by one rank
+(the one with the most free slots when it starts) and only its owner trains it.  After each epoch
+the ranks all-gather one ``[capacity, 6]`` record table (RCCL over xGMI on a GPU node); every rank
+then feeds the same trial-id-sorted batch of results to its scheduler and reaches the same
+CONTINUE / STOP / RESTART decisions without a coordinator.  Stopped trials free their slot at once
+and the next pending trials take it, so early stopping turns into throughput.
+"""
+from __future__ import annotations
+
+import os
+import socket
+import time
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+
+from .engine import PackEngine, TorchPackEngine
+from .trainable import PackedTrainable
+from ..parallel.comm import Comm, default_comm
+from ..tune import checkpoint as ckpt
+from ..tune.executor import Event, Executor
+from ..tune.logger import dump_json
+from ..tune.session import CONTINUE, PAUSE, RESTART, STOP
+from ..tune.trial import Trial
+
+_REC = 6   # trial_index, epoch, train_loss, validation_loss, validation_mse, validation_mape
+
+
+def make_engine(trainable: PackedTrainable, device: torch.device, capacity: Optional[int], seed: int) -> PackEngine:
+    kind = trainable.engine
+    if kind == "auto":
+        kind = "hip" if device.type == "cuda" else "torch"
+    if kind == "torch":
+        return TorchPackEngine(trainable, str(device), capacity, seed)
+    if kind == "hip":
+        from .engine_hip import HipPackEngine
+        return HipPackEngine(trainable, device, capacity, seed)
+    raise ValueError(f"unknown engine {kind!r}")
+
+
+class PackedExecutor(Executor):
+    lockstep = True          # results of one epoch form one scheduler batch
+    moves_weights = True     # PBT exploits are slab copies / send-recv, not checkpoint restarts
+
+    def __init__(self, trainable: PackedTrainable, scheduler=None, resources_per_trial: Optional[Dict] = None,
+                 max_concurrent: Optional[int] = None, experiment_id: str = "", seed: Optional[int] = 0,
+                 comm: Optional[Comm] = None, engine: Optional[PackEngine] = None,
+                 device: Optional[torch.device] = None, capacity: Optional[int] = None):
+        self.t = trainable
+        self.comm = comm or default_comm()
+        self.rank, self.world = self.comm.rank, self.comm.world_size
+        self.device = device or self.comm.device
+        self.seed = int(seed or 0)
+        self.engine = engine or make_engine(trainable, self.device, capacity or trainable.capacity, self.seed)
+        self.capacity = self.engine.capacity
+        self.max_concurrent = max_concurrent
+        self.experiment_id = experiment_id
+        self._free: List[List[int]] = [list(range(self.capacity)) for _ in range(self.world)]
+        self._place: Dict[str, Tuple[int, int]] = {}          # trial_id -> (rank, slot)
+        self._live: Dict[str, Trial] = {}
+        self._queued: List[Event] = []
+        self._awaiting: Dict[str, Optional[str]] = {}          # trial_id -> decision (None = not yet)
+        self._epoch_time = 0.0
+        self._t_total: Dict[str, float] = {}
+        self.runner = None
+        self.stats: Dict[str, Any] = {"epochs": 0, "slot_epochs": 0, "train_s": 0.0, "eval_s": 0.0,
+                                      "comm_s": 0.0, "engine": self.engine.name, "world_size": self.world,
+                                      "capacity_per_gpu": self.capacity, "exploits": 0}
+
+    def bind_runner(self, runner) -> None:
+        self.runner = runner
+
+    # ------------------------------------------------------------------ capacity / placement
+    def has_capacity(self) -> bool:
+        if self.max_concurrent is not None and len(self._live) >= self.max_concurrent:
+            return False
+        return any(self._free[r] for r in range(self.world))
+
+    def num_running(self) -> int:
+        return len(self._live) + len(self._queued)
+
+    def start_trial(self, trial: Trial) -> None:
+        owner = max(range(self.world), key=lambda r: (len(self._free[r]), -r))
+        slot = self._free[owner].pop(0)
+        self._place[trial.trial_id] = (owner, slot)
+        self._live[trial.trial_id] = trial
+        self._t_total.setdefault(trial.trial_id, float(trial.last_result.get("time_total_s", 0.0)))
+        trial.placement = {"rank": owner, "slot": slot}
+        if owner == self.rank:
+            self.engine.load(slot, trial.index, trial.config, state=trial.restore_from)
+        trial.restore_from = None
+
+    # ------------------------------------------------------------------ one scheduling round
+    def get_events(self, timeout: Optional[float] = None) -> List[Event]:
+        if self._queued:
+            out, self._queued = self._queued, []
+            return out
+        if not self._live:
+            return []
+        if any(d is None for d in self._awaiting.values()):
+            return []      # the runner still owes decisions for the previous round
+        t0 = time.time()
+        self.engine.train_epoch()
+        t1 = time.time()
+        local = self.engine.evaluate()
+        t2 = time.time()
+        table = torch.full((self.capacity, _REC), -1.0, dtype=torch.float64)
+        mine = {slot: tid for tid, (r, slot) in self._place.items() if r == self.rank}
+        for slot, m in local.items():
+            tr = self._live[mine[slot]]
+            table[slot] = torch.tensor([tr.index, tr.training_iteration + 1, m["train_loss"],
+                                        m["validation_loss"], m["validation_mse"], m["validation_mape"]],
+                                       dtype=torch.float64)
+        gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
+        t3 = time.time()
+        self._epoch_time = t3 - t0
+        self.stats["epochs"] += 1
+        self.stats["slot_epochs"] += len(local)
+        self.stats["train_s"] += t1 - t0
+        self.stats["eval_s"] += t2 - t1
+        self.stats["comm_s"] += t3 - t2
+
+        by_index = {tr.index: tr for tr in self._live.values()}
+        rows = gathered.reshape(-1, _REC)
+        rows = rows[rows[:, 0] >= 0]
+        rows = rows[torch.argsort(rows[:, 0])]
+        now = time.time()
+        events: List[Event] = []
+        self._awaiting = {}
+        for row in rows.tolist():
+            tr = by_index[int(row[0])]
+            self._t_total[tr.trial_id] += self._epoch_time
+            result = {
+                "training_iteration": int(row[1]), "train_loss": row[2], "validation_loss": row[3],
+                "validation_mse": row[4], "validation_mape": row[5],
+                "time_this_iter_s": self._epoch_time, "time_total_s": self._t_total[tr.trial_id],
+                "timestamp": int(now), "date": time.strftime("%Y-%m-%d_%H-%M-%S", time.localtime(now)),
+                "done": False, "trial_id": tr.trial_id, "experiment_id": self.experiment_id,
+                "pid": os.getpid(), "hostname": socket.gethostname(), "node_ip": "127.0.0.1",
+                "iterations_since_restore": int(row[1]),
+                "rank": self._place[tr.trial_id][0], "slot": self._place[tr.trial_id][1],
+            }
+            self._awaiting[tr.trial_id] = None
+            events.append(Event("result", tr, result=result))
+        return events
+
+    def resolve(self, trial: Trial, decision: str) -> None:
+        self._awaiting[trial.trial_id] = decision
+        if all(d is not None for d in self._awaiting.values()):
+            self._flush()
+
+    # ------------------------------------------------------------------ applying decisions
+    def _flush(self) -> None:
+        decisions, self._awaiting = self._awaiting, {}
+        order = sorted(decisions, key=lambda tid: self._live[tid].index)
+        # exploits first: a donor must still be resident when its weights are copied
+        for tid in order:
+            if decisions[tid] == RESTART:
+                self._exploit(self._live[tid])
+        for tid in order:
+            tr, d = self._live[tid], decisions[tid]
+            finished = d == STOP or tr.training_iteration >= self.t.max_epochs
+            if finished:
+                self._retire(tr)
+            elif self.t.checkpoint_freq and tr.training_iteration % self.t.checkpoint_freq == 0:
+                self._checkpoint(tr)
+
+    def _checkpoint(self, tr: Trial) -> None:
+        owner, slot = self._place[tr.trial_id]
+        if owner != self.rank:
+            return
+        state = self.engine.export(slot)
+        tr.checkpoint, tr.checkpoint_iter = state, tr.training_iteration
+        if tr.logdir:
+            keep = self.runner.keep_checkpoints_num if self.runner is not None else None
+            ckpt.save_checkpoint(tr.logdir, tr.training_iteration, state, keep)
+
+    def _retire(self, tr: Trial) -> None:
+        owner, slot = self._place.pop(tr.trial_id)
+        if self.t.checkpoint_at_end or (self.runner is not None and self.runner.checkpoint_at_end):
+            self._place[tr.trial_id] = (owner, slot)
+            self._checkpoint(tr)
+            self._place.pop(tr.trial_id)
+        if owner == self.rank:
+            self.engine.evict(slot)
+        self._free[owner].append(slot)
+        self._free[owner].sort()
+        self._live.pop(tr.trial_id)
+        self._queued.append(Event("done", tr, result={"decision": STOP}))
+
+    def _exploit(self, tr: Trial) -> None:
+        req = getattr(tr, "pbt_request", None)
+        tr.pbt_request = None
+        if not req or req["donor"] not in self._place:
+            return
+        (drank, dslot), (rrank, rslot) = self._place[req["donor"]], self._place[tr.trial_id]
+        tr.config = req["config"]
+        self.stats["exploits"] += 1
+        if tr.logdir and rrank == self.rank:
+            os.makedirs(tr.logdir, exist_ok=True)
+            dump_json(tr.config, os.path.join(tr.logdir, "params.json"))
+        if drank == rrank:
+            if drank == self.rank:
+                self.engine.clone(dslot, rslot, tr.config)
+            return
+        # donor and receiver live on different GPUs: ship the flattened state point-to-point
+        from ..parallel.exchange import recv_state, send_state
+        if self.rank == drank:
+            send_state(self.comm, self.engine.export(dslot), rrank)
+        elif self.rank == rrank:
+            self.engine.import_state(rslot, recv_state(self.comm, self.engine.export(rslot), drank), tr.config)
+
+    def shutdown(self) -> None:
+        self.engine.close()
