@@ -1,0 +1,66 @@
+"""Build the gfx950 kernel library in-tree: ``ops/libmitune_hip.so``.
+
+Plain ``hipcc --offload-arch=gfx950 -shared -fPIC`` over ``ops/csrc/*.hip``: the sources use only
+the HIP runtime (no torch headers), so a full rebuild takes seconds and the resulting library has a
+C ABI that ``ops/lib.py`` binds with ctypes.  hipcc cross-compiles, so this also runs on a machine
+without a GPU.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmitune_hip.so")
+STAMP = os.path.join(HERE, ".libmitune_hip.stamp")
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
+
+
+def sources() -> List[str]:
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
+def is_current() -> bool:
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+        return False
+    with open(STAMP) as f:
+        return f.read().strip() == _digest()
+
+
+def build(force: bool = False, verbose: bool = True, extra_flags: List[str] | None = None) -> str:
+    if not force and is_current():
+        return LIB
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-result", "-o", LIB] + (extra_flags or []) + sources()
+    if verbose:
+        print("[mitune] " + " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    with open(STAMP, "w") as f:
+        f.write(_digest())
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,178 @@
+// Fused regression head + loss + loss gradient (training) and head + metric reduction (evaluation).
+//
+// Training kernel, one workgroup per trial slot.  For every batch row it computes
+//   out = h . w + b,  loss(out, y),  dout = dloss/dout / B
+// and from there, in the same pass over h,
+//   dH[i][k] = dout * w[k] * (h[i][k] > 0)      (gradient entering the last hidden layer, ReLU folded in)
+//   gw[k]   += dout * h[i][k],   gb += dout,    loss_acc += mean loss.
+// The N = 1 head GEMV, the loss forward/backward, both head gradients and the per-trial loss reduction
+// are therefore one launch and one read of h; nothing is synchronised with the host.  Reductions run
+// in a fixed order (lane shuffle -> wave -> LDS), so results do not depend on which slot a trial is in.
+//
+// Evaluation kernel: same head forward, then adds {sum loss, sum squared error, sum |err|/(|y|+eps)}
+// for the chunk into the slot's f64 metric accumulators -- the table the scheduler all-gathers.
+#include "mt_common.h"
+
+#define HL_THREADS 256
+#define HL_WAVES 4
+
+__device__ __forceinline__ void loss_and_grad(int type, float out, float y, float& l, float& g) {
+  const float d = out - y;
+  const float a = fabsf(d);
+  const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+  switch (type) {
+    case 0: l = d * d; g = 2.f * d; break;
+    case 1: l = a; g = sgn; break;
+    case 2: if (a < 1.f) { l = 0.5f * d * d; g = d; } else { l = a - 0.5f; g = sgn; } break;
+    default: { const float den = fabsf(y) + 1e-8f; l = 100.f * a / den; g = 100.f * sgn / den; } break;
+  }
+}
+
+template <int NCHUNK>
+__global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSlot* __restrict__ slots, int step) {
+  const MtHeadSlot s = slots[blockIdx.x];
+  if (step >= s.active_steps) return;
+  __shared__ float red[HL_WAVES][NCHUNK * 512];
+  __shared__ float red_s[HL_WAVES][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint16_t* H = reinterpret_cast<const uint16_t*>(s.H);
+  uint16_t* dH = reinterpret_cast<uint16_t*>(s.dH);
+
+  float w[NCHUNK][8], gw[NCHUNK][8];
+#pragma unroll
+  for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = c * 512 + lane * 8 + e;
+      w[c][e] = (k < s.W) ? s.w[k] : 0.f;
+      gw[c][e] = 0.f;
+    }
+  const float bias = s.b[0];
+  const float inv_b = 1.f / (float)s.B;
+  float loss_sum = 0.f, gb = 0.f;
+
+  for (int i = wave; i < s.B; i += HL_WAVES) {
+    u32x4 hv[NCHUNK];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+      const int k0 = c * 512 + lane * 8;
+      hv[c] = u32x4{0u, 0u, 0u, 0u};
+      if (k0 < s.W) hv[c] = *reinterpret_cast<const u32x4*>(H + (size_t)i * s.ldh + k0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dot += bf16_bits_to_f32(hv[c][e] & 0xFFFFu) * w[c][2 * e];
+        dot += bf16_bits_to_f32(hv[c][e] >> 16) * w[c][2 * e + 1];
+      }
+    }
+    const float out = wave_sum(dot) + bias;
+    float l, g;
+    loss_and_grad(s.loss_type, out, s.y[i], l, g);
+    const float dout = g * inv_b;
+    loss_sum += l;
+    gb += dout;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+      const int k0 = c * 512 + lane * 8;
+      if (k0 < s.W) {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float h0 = bf16_bits_to_f32(hv[c][e] & 0xFFFFu), h1 = bf16_bits_to_f32(hv[c][e] >> 16);
+          gw[c][2 * e] += dout * h0;
+          gw[c][2 * e + 1] += dout * h1;
+          o[e] = pack_bf16x2(h0 > 0.f ? dout * w[c][2 * e] : 0.f, h1 > 0.f ? dout * w[c][2 * e + 1] : 0.f);
+        }
+        *reinterpret_cast<u32x4*>(dH + (size_t)i * s.ldh + k0) = o;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][c * 512 + lane * 8 + e] = gw[c][e];
+  if (lane == 0) { red_s[wave][0] = loss_sum; red_s[wave][1] = gb; }
+  __syncthreads();
+  for (int k = tid; k < s.W; k += HL_THREADS)
+    s.gw[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  if (tid == 0) {
+    s.gb[0] = (red_s[0][1] + red_s[1][1]) + (red_s[2][1] + red_s[3][1]);
+    const float ls = (red_s[0][0] + red_s[1][0]) + (red_s[2][0] + red_s[3][0]);
+    s.loss_acc[0] += ls * inv_b;
+  }
+}
+
+template <int NCHUNK>
+__global__ __launch_bounds__(HL_THREADS) void mt_head_eval_kernel(const MtHeadSlot* __restrict__ slots, int row0, int nrows) {
+  MtHeadSlot s = slots[blockIdx.x];
+  if (s.active_steps <= 0) return;
+  if (nrows > 0) {   // chunked evaluation: targets [row0, row0 + nrows) of the shared validation vector
+    s.B = nrows;
+    s.y += row0;
+  }
+  if (s.B <= 0) return;
+  __shared__ float red_s[HL_WAVES][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint16_t* H = reinterpret_cast<const uint16_t*>(s.H);
+  float w[NCHUNK][8];
+#pragma unroll
+  for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = c * 512 + lane * 8 + e;
+      w[c][e] = (k < s.W) ? s.w[k] : 0.f;
+    }
+  const float bias = s.b[0];
+  float sl = 0.f, sse = 0.f, sape = 0.f;
+  for (int i = wave; i < s.B; i += HL_WAVES) {
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+      const int k0 = c * 512 + lane * 8;
+      u32x4 hv = {0u, 0u, 0u, 0u};
+      if (k0 < s.W) hv = *reinterpret_cast<const u32x4*>(H + (size_t)i * s.ldh + k0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dot += bf16_bits_to_f32(hv[e] & 0xFFFFu) * w[c][2 * e];
+        dot += bf16_bits_to_f32(hv[e] >> 16) * w[c][2 * e + 1];
+      }
+    }
+    const float out = wave_sum(dot) + bias;
+    const float y = s.y[i];
+    float l, g;
+    loss_and_grad(s.loss_type, out, y, l, g);
+    const float d = out - y;
+    sl += l;
+    sse += d * d;
+    sape += fabsf(d) / (fabsf(y) + 1e-8f);
+  }
+  if (lane == 0) { red_s[wave][0] = sl; red_s[wave][1] = sse; red_s[wave][2] = sape; }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+      s.metrics[m] += (double)((red_s[0][m] + red_s[1][m]) + (red_s[2][m] + red_s[3][m]));
+  }
+}
+
+extern "C" int mt_head_loss_launch(const MtHeadSlot* slots, int n_slots, int max_width, int step, hipStream_t stream) {
+  if (n_slots <= 0) return 0;
+  dim3 grid(n_slots), block(HL_THREADS);
+  if (max_width <= 512) hipLaunchKernelGGL(mt_head_loss_kernel<1>, grid, block, 0, stream, slots, step);
+  else if (max_width <= 1024) hipLaunchKernelGGL(mt_head_loss_kernel<2>, grid, block, 0, stream, slots, step);
+  else if (max_width <= 2048) hipLaunchKernelGGL(mt_head_loss_kernel<4>, grid, block, 0, stream, slots, step);
+  else return -2;
+  return (int)hipGetLastError();
+}
+
+extern "C" int mt_head_eval_launch(const MtHeadSlot* slots, int n_slots, int max_width, int row0, int nrows,
+                                   hipStream_t stream) {
+  if (n_slots <= 0) return 0;
+  dim3 grid(n_slots), block(HL_THREADS);
+  if (max_width <= 512) hipLaunchKernelGGL(mt_head_eval_kernel<1>, grid, block, 0, stream, slots, row0, nrows);
+  else if (max_width <= 1024) hipLaunchKernelGGL(mt_head_eval_kernel<2>, grid, block, 0, stream, slots, row0, nrows);
+  else if (max_width <= 2048) hipLaunchKernelGGL(mt_head_eval_kernel<4>, grid, block, 0, stream, slots, row0, nrows);
+  else return -2;
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,120 @@
+// Shared declarations for the mitune gfx950 kernels (device helpers + host-visible descriptors).
+//
+// Everything here is written for CDNA4 only: 64-lane wavefronts, MFMA 16x16x32 bf16, LDS tiles
+// read with ds_read_b128 / ds_read_b64_tr_b16.  The descriptor structs are mirrored field by field
+// as ctypes.Structure classes in ops/lib.py; keep the two in sync.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define MT_WAVE 64
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+// Round-to-nearest-even f32 -> bf16 through the compiler's cast (v_cvt_pk_bf16_f32 on gfx950),
+// which keeps NaN a NaN; the integer-add trick can turn some NaNs into zero or infinity.
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  __bf16 h = (__bf16)f;
+  return (uint32_t)__builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grouped GEMM descriptors.  One group = one trial slot's GEMM for one layer and direction:
+//   C[I x J] = sum_kk A(i, kk) * B(kk, j)
+// mode 0 "NT" (forward):   A is [I][KK] (kk contiguous), B is [J][KK] (kk contiguous)
+// mode 1 "NN" (dgrad):     A is [I][KK] (kk contiguous), B is [KK][J] (j contiguous)
+// mode 2 "TN" (wgrad):     A is [KK][I] (i contiguous),  B is [KK][J] (j contiguous)
+// A, B are bf16; C is bf16 for modes 0/1 and f32 for mode 2.
+struct MtGemmGroup {
+  const void* A;
+  const void* B;
+  void* C;
+  const void* aux;     // mode 0: bias f32[J]; mode 1: ReLU source bf16 [I][ldaux] (output masked where <= 0)
+  void* aux_out;       // mode 2: bias gradient f32[I] (column sums of A), written by the tj == 0 tiles
+  int32_t I, J, KK;
+  int32_t lda, ldb, ldc, ldaux;
+  int32_t active_steps;  // the group takes part while step < active_steps
+};
+
+struct MtTile {
+  int32_t group;
+  int16_t ti, tj;
+};
+
+#define MT_GEMM_FLAG_RELU 1   // mode 0: ReLU after bias
+#define MT_GEMM_FLAG_MASK 1   // mode 1: multiply by (aux > 0)
+#define MT_GEMM_FLAG_DBIAS 1  // mode 2: also produce aux_out = column sums of A
+
+// ------------------------------------------------------------------------------------------------
+struct MtGatherSlot {
+  void* X0;            // out: bf16 [B][Fpad]
+  float* y;            // out: f32 [B]
+  uint32_t key[4];     // Feistel round keys of (seed, trial, epoch)
+  int32_t B;
+  int32_t active_steps;
+};
+
+struct MtHeadSlot {
+  const void* H;       // bf16 [B][ldh] last hidden activations (post-ReLU)
+  void* dH;            // bf16 [B][ldh] out: dLoss/dZ of the last hidden layer (ReLU mask applied)
+  const float* w;      // f32 [W] head weight
+  const float* b;      // f32 [1] head bias
+  float* gw;           // f32 [W] out
+  float* gb;           // f32 [1] out
+  const float* y;      // f32 [B] targets
+  float* loss_acc;     // f32 [1] += mean batch loss
+  double* metrics;     // eval: f64 [3] += {sum loss, sum squared error, sum abs pct error}
+  int32_t B, W, ldh;
+  int32_t loss_type;   // 0 mse, 1 mae, 2 huber(beta=1), 3 mape
+  int32_t active_steps;
+  int32_t pad;
+};
+
+struct MtOptSlot {
+  float lr, beta1, beta2, eps, wd, momentum, clip;
+  int32_t opt_type;      // 0 adam, 1 adamw, 2 sgd, 3 rmsprop
+  int32_t warmup, total; // LR schedule: linear warm-up then linear decay (0 = off)
+  int32_t n_params;      // live elements of this slot's slab
+  int32_t active_steps;
+  int32_t step_base;     // optimiser steps taken before this epoch
+  int32_t pad[3];
+};
+
+// Feistel permutation shared with packed/permutation.py (bit-identical).
+__device__ __forceinline__ uint32_t mt_mix32(uint32_t x) {
+  x = (x ^ (x >> 16)) * 0x85EBCA6Bu;
+  x = (x ^ (x >> 13)) * 0xC2B2AE35u;
+  return x ^ (x >> 16);
+}
+__device__ __forceinline__ uint32_t mt_feistel(uint32_t x, const uint32_t* key, int hb) {
+  const uint32_t mask = (1u << hb) - 1u;
+  uint32_t left = (x >> hb) & mask, right = x & mask;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    uint32_t f = mt_mix32(right ^ key[r]) & mask;
+    uint32_t nl = right;
+    right = left ^ f;
+    left = nl;
+  }
+  return (left << hb) | right;
+}
+__device__ __forceinline__ uint32_t mt_permute(uint32_t pos, uint32_t n, const uint32_t* key, int hb) {
+  uint32_t x = mt_feistel(pos, key, hb);
+  while (x >= n) x = mt_feistel(x, key, hb);   // cycle walking: ends because mt_feistel is a bijection
+  return x;
+}

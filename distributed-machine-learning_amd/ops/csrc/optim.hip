@@ -1,0 +1,160 @@
+// Fused per-trial optimiser step over a pack's flat parameter slab (gfx950).
+//
+// Every trial slot owns a contiguous region of the f32 master-parameter slab P (and the same region
+// of G, M, V and of the bf16 shadow Pb that the GEMMs read).  One launch updates all slots: block
+// (x, s) handles elements [x*2048, x*2048 + 2048) of slot s with that slot's own optimiser family,
+// learning rate (including the warm-up / decay factor of its own step count), weight decay, betas and
+// clip scale, read from a small descriptor table -- so heterogeneous trials still cost one launch.
+// The same pass refreshes the bf16 shadow; a separate "cast" pass never exists.
+//
+// Global-norm clipping: mt_sqnorm_kernel writes one partial sum of squares per (slot, block); each
+// optimiser block re-adds its slot's partials in index order (a fixed order, so bitwise reproducible)
+// and scales gradients by min(1, clip / (norm + 1e-6)).
+#include "mt_common.h"
+
+#define OPT_THREADS 256
+#define OPT_PER_BLOCK 2048   // 8 elements per thread
+
+__global__ __launch_bounds__(OPT_THREADS) void mt_sqnorm_kernel(const float* __restrict__ G, size_t slot_stride,
+                                                                const MtOptSlot* __restrict__ hp,
+                                                                float* __restrict__ partials, int max_blocks, int step) {
+  const int slot = blockIdx.y;
+  const MtOptSlot h = hp[slot];
+  float acc = 0.f;
+  const int base = blockIdx.x * OPT_PER_BLOCK + threadIdx.x * 8;
+  if (step < h.active_steps && h.clip > 0.f && base < h.n_params) {
+    const float* g = G + (size_t)slot * slot_stride + base;
+    if (base + 8 <= h.n_params) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(g), b = *reinterpret_cast<const f32x4*>(g + 4);
+      acc = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+    } else {
+      for (int e = 0; base + e < h.n_params; ++e) acc += g[e] * g[e];
+    }
+  }
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[(size_t)slot * max_blocks + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ __forceinline__ float lr_factor(int t, int warmup, int total) {
+  if (warmup > 0 && t < warmup) return (float)(t + 1) / (float)warmup;
+  if (total > 0) {
+    const int span = (total - warmup) > 1 ? (total - warmup) : 1;
+    const float f = (float)(total - t) / (float)span;
+    return f > 0.f ? f : 0.f;
+  }
+  return 1.f;
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict__ P, const float* __restrict__ G,
+                                                               float* __restrict__ M, float* __restrict__ V,
+                                                               uint16_t* __restrict__ Pb, size_t slot_stride,
+                                                               const MtOptSlot* __restrict__ hp,
+                                                               const float* __restrict__ partials, int max_blocks,
+                                                               int step) {
+  const int slot = blockIdx.y;
+  const MtOptSlot h = hp[slot];
+  if (step >= h.active_steps) return;
+  const int base = blockIdx.x * OPT_PER_BLOCK + threadIdx.x * 8;
+  if (blockIdx.x * OPT_PER_BLOCK >= h.n_params) return;
+
+  float gscale = 1.f;
+  if (h.clip > 0.f && partials != nullptr) {
+    const int nb = (h.n_params + OPT_PER_BLOCK - 1) / OPT_PER_BLOCK;
+    float tot = 0.f;
+    for (int i = 0; i < nb; ++i) tot += partials[(size_t)slot * max_blocks + i];   // uniform -> scalar loads
+    const float c = h.clip / (sqrtf(tot) + 1e-6f);
+    gscale = c < 1.f ? c : 1.f;
+  }
+  if (base >= h.n_params) return;
+
+  const int t = h.step_base + step;                 // optimiser steps already taken
+  const float lr = h.lr * lr_factor(t, h.warmup, h.total);
+  const float bc1 = 1.f - powf(h.beta1, (float)(t + 1));
+  const float bc2 = 1.f - powf(h.beta2, (float)(t + 1));
+  const float inv_bc2_sqrt = 1.f / sqrtf(bc2);
+  const size_t off = (size_t)slot * slot_stride + base;
+  const int n = (h.n_params - base) < 8 ? (h.n_params - base) : 8;
+
+  float p[8], g[8], m[8], v[8];
+  if (n == 8) {
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(P + off), p1 = *reinterpret_cast<const f32x4*>(P + off + 4);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(G + off), g1 = *reinterpret_cast<const f32x4*>(G + off + 4);
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(M + off), m1 = *reinterpret_cast<const f32x4*>(M + off + 4);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(V + off), v1 = *reinterpret_cast<const f32x4*>(V + off + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      p[e] = p0[e]; p[e + 4] = p1[e]; g[e] = g0[e]; g[e + 4] = g1[e];
+      m[e] = m0[e]; m[e + 4] = m1[e]; v[e] = v0[e]; v[e + 4] = v1[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = e < n;
+      p[e] = ok ? P[off + e] : 0.f; g[e] = ok ? G[off + e] : 0.f;
+      m[e] = ok ? M[off + e] : 0.f; v[e] = ok ? V[off + e] : 0.f;
+    }
+  }
+
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float gg = g[e] * gscale;
+    switch (h.opt_type) {
+      case 0:   // Adam, L2 regularisation folded into the gradient
+      case 1: { // AdamW, decoupled decay
+        if (h.opt_type == 0) gg += h.wd * p[e];
+        else p[e] *= (1.f - lr * h.wd);
+        m[e] = h.beta1 * m[e] + (1.f - h.beta1) * gg;
+        v[e] = h.beta2 * v[e] + (1.f - h.beta2) * gg * gg;
+        const float denom = sqrtf(v[e]) * inv_bc2_sqrt + h.eps;
+        p[e] -= (lr / bc1) * (m[e] / denom);
+      } break;
+      case 2: { // SGD with momentum (buffer = M)
+        gg += h.wd * p[e];
+        m[e] = h.momentum * m[e] + gg;
+        p[e] -= lr * (h.momentum > 0.f ? m[e] : gg);
+      } break;
+      default: { // RMSprop, alpha = 0.99 (V = square average, M = momentum buffer)
+        gg += h.wd * p[e];
+        v[e] = 0.99f * v[e] + 0.01f * gg * gg;
+        const float avg = sqrtf(v[e]) + h.eps;
+        if (h.momentum > 0.f) { m[e] = h.momentum * m[e] + gg / avg; p[e] -= lr * m[e]; }
+        else p[e] -= lr * gg / avg;
+      } break;
+    }
+  }
+
+  if (n == 8) {
+    *reinterpret_cast<f32x4*>(P + off) = f32x4{p[0], p[1], p[2], p[3]};
+    *reinterpret_cast<f32x4*>(P + off + 4) = f32x4{p[4], p[5], p[6], p[7]};
+    *reinterpret_cast<f32x4*>(M + off) = f32x4{m[0], m[1], m[2], m[3]};
+    *reinterpret_cast<f32x4*>(M + off + 4) = f32x4{m[4], m[5], m[6], m[7]};
+    *reinterpret_cast<f32x4*>(V + off) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(V + off + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<u32x4*>(Pb + off) = u32x4{pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]),
+                                                pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+  } else {
+    for (int e = 0; e < n; ++e) {
+      P[off + e] = p[e]; M[off + e] = m[e]; V[off + e] = v[e];
+      Pb[off + e] = (uint16_t)f32_to_bf16_bits(p[e]);
+    }
+  }
+}
+
+extern "C" int mt_optim_launch(float* P, const float* G, float* M, float* V, void* Pb, size_t slot_stride,
+                               const MtOptSlot* hp, int n_slots, int max_params, float* partials, int use_clip,
+                               int step, hipStream_t stream) {
+  if (n_slots <= 0 || max_params <= 0) return 0;
+  if (slot_stride % 8 != 0) return -2;
+  const int nb = (max_params + OPT_PER_BLOCK - 1) / OPT_PER_BLOCK;
+  dim3 grid(nb, n_slots), block(OPT_THREADS);
+  if (use_clip) {
+    if (partials == nullptr) return -3;
+    hipLaunchKernelGGL(mt_sqnorm_kernel, grid, block, 0, stream, G, slot_stride, hp, partials, nb, step);
+  }
+  hipLaunchKernelGGL(mt_optim_kernel, grid, block, 0, stream, P, G, M, V, reinterpret_cast<uint16_t*>(Pb),
+                     slot_stride, hp, use_clip ? partials : nullptr, nb, step);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,109 @@
+// Host-side step driver for a pack of MLP trials (gfx950).
+//
+// The Python layer describes a pack once per epoch as a plan: device pointers to the per-layer group
+// and tile tables, the gather / head / optimiser descriptor tables and the parameter slabs.  The two
+// entry points below then enqueue whole training steps (or a whole validation sweep) from C++ with no
+// interpreter in the loop and no host-device synchronisation: the host only ever waits at the end of
+// an epoch, when it reads the metric table.  Per step the launch sequence is
+//   gather -> L x forward GEMM(+bias+ReLU) -> head+loss+dH -> for l = L-1..0 { wgrad(+dbias); dgrad(+ReLU mask) }
+//   -> [grad sq-norm partials] -> fused per-trial optimiser (+bf16 shadow refresh)
+// i.e. 3L + 3 (+1) launches regardless of how many trials share the GPU.
+#include "mt_common.h"
+
+#define MT_MAX_LAYERS 8
+
+extern "C" {
+int mt_gemm_launch(int mode, const MtGemmGroup* groups, const MtTile* tiles, int ntiles, int step, int flags,
+                   int arow0, int i_override, hipStream_t stream);
+int mt_gather_launch(const MtGatherSlot* slots, int n_slots, int max_batch, const float* X, const float* Y,
+                     uint32_t n_rows, int F, int Fpad, int hb, int step, hipStream_t stream);
+int mt_head_loss_launch(const MtHeadSlot* slots, int n_slots, int max_width, int step, hipStream_t stream);
+int mt_head_eval_launch(const MtHeadSlot* slots, int n_slots, int max_width, int row0, int nrows, hipStream_t stream);
+int mt_optim_launch(float* P, const float* G, float* M, float* V, void* Pb, size_t slot_stride, const MtOptSlot* hp,
+                    int n_slots, int max_params, float* partials, int use_clip, int step, hipStream_t stream);
+}
+
+struct MtMlpPlan {
+  int32_t n_hidden;      // hidden (GEMM) layers; the scalar head is handled by the head kernels
+  int32_t n_slots;       // physical slots of the pack (inactive ones carry active_steps = 0)
+  int32_t max_batch, max_width, max_params;
+  int32_t F, Fpad, hb;
+  uint32_t n_rows;
+  int32_t use_clip;
+  const float* X;
+  const float* Y;
+  const MtGatherSlot* gather;
+  const MtGemmGroup* fwd_groups[MT_MAX_LAYERS];
+  const MtTile* fwd_tiles[MT_MAX_LAYERS];
+  const MtGemmGroup* dgrad_groups[MT_MAX_LAYERS];
+  const MtTile* dgrad_tiles[MT_MAX_LAYERS];
+  const MtGemmGroup* wgrad_groups[MT_MAX_LAYERS];
+  const MtTile* wgrad_tiles[MT_MAX_LAYERS];
+  int32_t fwd_ntiles[MT_MAX_LAYERS];
+  int32_t dgrad_ntiles[MT_MAX_LAYERS];
+  int32_t wgrad_ntiles[MT_MAX_LAYERS];
+  const MtHeadSlot* head;
+  float* P;
+  float* G;
+  float* M;
+  float* V;
+  void* Pb;
+  size_t slot_stride;
+  const MtOptSlot* opt;
+  float* partials;
+};
+
+#define MT_TRY(x)            \
+  do {                       \
+    int _e = (x);            \
+    if (_e != 0) return _e;  \
+  } while (0)
+
+extern "C" int mt_mlp_train_steps(const MtMlpPlan* p, int step0, int nsteps, hipStream_t stream) {
+  if (p->n_hidden < 1 || p->n_hidden > MT_MAX_LAYERS) return -10;
+  const int L = p->n_hidden;
+  for (int step = step0; step < step0 + nsteps; ++step) {
+    MT_TRY(mt_gather_launch(p->gather, p->n_slots, p->max_batch, p->X, p->Y, p->n_rows, p->F, p->Fpad, p->hb,
+                            step, stream));
+    for (int l = 0; l < L; ++l)
+      MT_TRY(mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], step, MT_GEMM_FLAG_RELU, 0, 0,
+                            stream));
+    MT_TRY(mt_head_loss_launch(p->head, p->n_slots, p->max_width, step, stream));
+    for (int l = L - 1; l >= 0; --l) {
+      MT_TRY(mt_gemm_launch(2, p->wgrad_groups[l], p->wgrad_tiles[l], p->wgrad_ntiles[l], step, MT_GEMM_FLAG_DBIAS,
+                            0, 0, stream));
+      if (l > 0)
+        MT_TRY(mt_gemm_launch(1, p->dgrad_groups[l], p->dgrad_tiles[l], p->dgrad_ntiles[l], step, MT_GEMM_FLAG_MASK,
+                              0, 0, stream));
+    }
+    MT_TRY(mt_optim_launch(p->P, p->G, p->M, p->V, p->Pb, p->slot_stride, p->opt, p->n_slots, p->max_params,
+                           p->partials, p->use_clip, step, stream));
+  }
+  return 0;
+}
+
+// Validation sweep: the forward tables of an evaluation plan all read rows of ONE shared bf16 copy of
+// the validation set (layer 0's A pointer), chunk by chunk; the head kernel adds each chunk's error
+// sums into the per-slot f64 metric table.
+extern "C" int mt_mlp_eval(const MtMlpPlan* p, int n_val_rows, int chunk_rows, hipStream_t stream) {
+  if (p->n_hidden < 1 || p->n_hidden > MT_MAX_LAYERS || chunk_rows <= 0) return -10;
+  const int L = p->n_hidden;
+  for (int r0 = 0; r0 < n_val_rows; r0 += chunk_rows) {
+    const int rows = (n_val_rows - r0) < chunk_rows ? (n_val_rows - r0) : chunk_rows;
+    for (int l = 0; l < L; ++l)
+      MT_TRY(mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], 0, MT_GEMM_FLAG_RELU,
+                            l == 0 ? r0 : 0, rows, stream));
+    MT_TRY(mt_head_eval_launch(p->head, p->n_slots, p->max_width, r0, rows, stream));
+  }
+  return 0;
+}
+
+extern "C" int mt_abi_sizes(int* out) {
+  out[0] = (int)sizeof(MtGemmGroup);
+  out[1] = (int)sizeof(MtTile);
+  out[2] = (int)sizeof(MtGatherSlot);
+  out[3] = (int)sizeof(MtHeadSlot);
+  out[4] = (int)sizeof(MtOptSlot);
+  out[5] = (int)sizeof(MtMlpPlan);
+  return 6;
+}

@@ -1,0 +1,142 @@
+"""ctypes binding of ``libmitune_hip.so`` (the hand-written gfx950 kernels + C++ step driver).
+
+The descriptor classes mirror the structs of ``csrc/mt_common.h`` / ``csrc/runtime.hip`` field for
+field; ``load()`` checks ``sizeof`` of every struct against the library so a drift fails at import
+time rather than as a wild pointer on the GPU.  There is deliberately no fallback: on a machine with a
+GPU a missing or stale library is an error, never a silent eager-PyTorch path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+
+MT_MAX_LAYERS = 8
+
+c_void_p, c_int32, c_uint32, c_float, c_size_t = C.c_void_p, C.c_int32, C.c_uint32, C.c_float, C.c_size_t
+
+
+class GemmGroup(C.Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("aux", c_void_p), ("aux_out", c_void_p),
+                ("I", c_int32), ("J", c_int32), ("KK", c_int32),
+                ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldaux", c_int32),
+                ("active_steps", c_int32)]
+
+
+class Tile(C.Structure):
+    _fields_ = [("group", c_int32), ("ti", C.c_int16), ("tj", C.c_int16)]
+
+
+class GatherSlot(C.Structure):
+    _fields_ = [("X0", c_void_p), ("y", c_void_p), ("key", c_uint32 * 4), ("B", c_int32), ("active_steps", c_int32)]
+
+
+class HeadSlot(C.Structure):
+    _fields_ = [("H", c_void_p), ("dH", c_void_p), ("w", c_void_p), ("b", c_void_p), ("gw", c_void_p),
+                ("gb", c_void_p), ("y", c_void_p), ("loss_acc", c_void_p), ("metrics", c_void_p),
+                ("B", c_int32), ("W", c_int32), ("ldh", c_int32), ("loss_type", c_int32),
+                ("active_steps", c_int32), ("pad", c_int32)]
+
+
+class OptSlot(C.Structure):
+    _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("wd", c_float),
+                ("momentum", c_float), ("clip", c_float),
+                ("opt_type", c_int32), ("warmup", c_int32), ("total", c_int32), ("n_params", c_int32),
+                ("active_steps", c_int32), ("step_base", c_int32), ("pad", c_int32 * 3)]
+
+
+class MlpPlan(C.Structure):
+    _fields_ = [("n_hidden", c_int32), ("n_slots", c_int32), ("max_batch", c_int32), ("max_width", c_int32),
+                ("max_params", c_int32), ("F", c_int32), ("Fpad", c_int32), ("hb", c_int32),
+                ("n_rows", c_uint32), ("use_clip", c_int32),
+                ("X", c_void_p), ("Y", c_void_p), ("gather", c_void_p),
+                ("fwd_groups", c_void_p * MT_MAX_LAYERS), ("fwd_tiles", c_void_p * MT_MAX_LAYERS),
+                ("dgrad_groups", c_void_p * MT_MAX_LAYERS), ("dgrad_tiles", c_void_p * MT_MAX_LAYERS),
+                ("wgrad_groups", c_void_p * MT_MAX_LAYERS), ("wgrad_tiles", c_void_p * MT_MAX_LAYERS),
+                ("fwd_ntiles", c_int32 * MT_MAX_LAYERS), ("dgrad_ntiles", c_int32 * MT_MAX_LAYERS),
+                ("wgrad_ntiles", c_int32 * MT_MAX_LAYERS),
+                ("head", c_void_p), ("P", c_void_p), ("G", c_void_p), ("M", c_void_p), ("V", c_void_p),
+                ("Pb", c_void_p), ("slot_stride", c_size_t), ("opt", c_void_p), ("partials", c_void_p)]
+
+
+# numpy views of the same layouts, for building whole descriptor tables vectorised
+GEMM_GROUP_DTYPE = np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("aux", "<u8"), ("aux_out", "<u8"),
+                             ("I", "<i4"), ("J", "<i4"), ("KK", "<i4"), ("lda", "<i4"), ("ldb", "<i4"),
+                             ("ldc", "<i4"), ("ldaux", "<i4"), ("active_steps", "<i4")], align=True)
+TILE_DTYPE = np.dtype([("group", "<i4"), ("ti", "<i2"), ("tj", "<i2")], align=True)
+GATHER_DTYPE = np.dtype([("X0", "<u8"), ("y", "<u8"), ("key", "<u4", (4,)), ("B", "<i4"), ("active_steps", "<i4")],
+                        align=True)
+HEAD_DTYPE = np.dtype([("H", "<u8"), ("dH", "<u8"), ("w", "<u8"), ("b", "<u8"), ("gw", "<u8"), ("gb", "<u8"),
+                       ("y", "<u8"), ("loss_acc", "<u8"), ("metrics", "<u8"), ("B", "<i4"), ("W", "<i4"),
+                       ("ldh", "<i4"), ("loss_type", "<i4"), ("active_steps", "<i4"), ("pad", "<i4")], align=True)
+OPT_DTYPE = np.dtype([("lr", "<f4"), ("beta1", "<f4"), ("beta2", "<f4"), ("eps", "<f4"), ("wd", "<f4"),
+                      ("momentum", "<f4"), ("clip", "<f4"), ("opt_type", "<i4"), ("warmup", "<i4"),
+                      ("total", "<i4"), ("n_params", "<i4"), ("active_steps", "<i4"), ("step_base", "<i4"),
+                      ("pad", "<i4", (3,))], align=True)
+
+_lib: Optional[C.CDLL] = None
+
+
+class KernelLibraryError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load (building first when the sources changed and a compiler is present) and type the library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if build_if_missing and not _build.is_current():
+        try:
+            _build.build(verbose=False)
+        except Exception as e:       # no hipcc on this machine: fall through to whatever was shipped in-tree
+            if not os.path.exists(path):
+                raise KernelLibraryError(f"{path} is missing and could not be built: {e}") from e
+    if not os.path.exists(path):
+        raise KernelLibraryError(f"{path} is missing: run `python -m mitune.ops.build`")
+    lib = C.CDLL(path)
+    sizes = (C.c_int * 8)()
+    n = lib.mt_abi_sizes(sizes)
+    expect = [C.sizeof(GemmGroup), C.sizeof(Tile), C.sizeof(GatherSlot), C.sizeof(HeadSlot), C.sizeof(OptSlot),
+              C.sizeof(MlpPlan)]
+    got = list(sizes[:n])
+    if got != expect:
+        raise KernelLibraryError(f"descriptor layout mismatch between lib.py {expect} and {path} {got}")
+    np_sizes = [GEMM_GROUP_DTYPE.itemsize, TILE_DTYPE.itemsize, GATHER_DTYPE.itemsize, HEAD_DTYPE.itemsize,
+                OPT_DTYPE.itemsize]
+    if np_sizes != expect[:5]:
+        raise KernelLibraryError(f"numpy descriptor dtypes {np_sizes} do not match ctypes {expect[:5]}")
+
+    lib.mt_gemm_launch.argtypes = [C.c_int, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_gather_launch.argtypes = [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p, c_uint32, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, c_void_p]
+    lib.mt_head_loss_launch.argtypes = [c_void_p, C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_head_eval_launch.argtypes = [c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_optim_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, C.c_int,
+                                    C.c_int, c_void_p, C.c_int, C.c_int, c_void_p]
+    lib.mt_mlp_train_steps.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]
+    lib.mt_mlp_eval.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]
+    for fn in (lib.mt_gemm_launch, lib.mt_gather_launch, lib.mt_head_loss_launch, lib.mt_head_eval_launch,
+               lib.mt_optim_launch, lib.mt_mlp_train_steps, lib.mt_mlp_eval):
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise KernelLibraryError(f"{what} failed with code {code}")
+
+
+def current_stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,409 @@
+"""HipPackEngine: a pack of MLP trials trained by the hand-written gfx950 kernels.
+
+Memory model (sized for one MI355X, 288 GB of HBM): every slot owns a fixed-stride region of five
+flat slabs -- f32 master parameters ``P``, gradients ``G``, optimiser moments ``M``/``V`` and the bf16
+shadow ``Pb`` the GEMMs read -- plus per-layer bf16 activation and activation-gradient buffers.
+A slot's region is laid out for its *own* architecture (row strides padded to 8 elements so every
+operand row starts 16-byte aligned; pad elements are zero and provably stay zero under the update),
+so trials of different width and depth share one pack and one launch per layer.
+
+Work submission: once per epoch the engine writes small descriptor tables (GEMM groups + XCD-balanced
+tile lists per layer and direction, gather keys, head and optimiser tables) and then makes ONE call
+into the C++ driver, which enqueues every step of the epoch back to back.  The host synchronises once
+per epoch, when it reads the loss / metric tables.  Compute is bf16 on MFMA with f32 accumulation and
+f32 master weights; the optimiser refreshes the bf16 shadow in the same pass.
+
+Behavioural contract shared with ``TorchPackEngine`` (and checked against it in tests): same initial
+weights, same keyed-permutation batches, same step count per epoch, same metrics.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .engine import PackEngine
+from .permutation import half_bits, round_keys
+from .trainable import PackedTrainable
+from ..models.mlp import MLPTrialSpec, init_mlp_state
+from ..ops import lib as L
+from ..train.losses import LOSS_CODES
+from ..train.optim import OPT_CODES
+
+TILE = 128
+N_XCD = 8
+
+
+def ceil8(x: int) -> int:
+    return (x + 7) // 8 * 8
+
+
+class SlotLayout:
+    """Element offsets of one trial's parameters inside its slab region."""
+
+    def __init__(self, spec: MLPTrialSpec, fpad: int):
+        self.hidden = list(spec.hidden_sizes)
+        self.in_dims = [spec.in_features] + self.hidden[:-1]           # real contraction length per layer
+        self.in_ld = [fpad] + [ceil8(h) for h in self.hidden[:-1]]      # row stride of W_l and of its input
+        self.out_ld = [ceil8(h) for h in self.hidden]
+        off = 0
+        self.w_off, self.b_off = [], []
+        for h, ld in zip(self.hidden, self.in_ld):
+            self.w_off.append(off)
+            off += h * ld
+            off = ceil8(off)
+            self.b_off.append(off)
+            off += ceil8(h)
+        self.head_w_off = off
+        off += self.out_ld[-1]
+        self.head_b_off = off
+        off += 8
+        self.total = off
+
+    def names(self) -> List[Tuple[str, int, Tuple[int, int], int]]:
+        """(state_dict key, offset, (rows, cols), row stride) for every parameter tensor."""
+        out = []
+        for l, h in enumerate(self.hidden):
+            out.append((f"layers.{l}.weight", self.w_off[l], (h, self.in_dims[l]), self.in_ld[l]))
+            out.append((f"layers.{l}.bias", self.b_off[l], (1, h), h))
+        out.append(("head.weight", self.head_w_off, (1, self.hidden[-1]), self.hidden[-1]))
+        out.append(("head.bias", self.head_b_off, (1, 1), 1))
+        return out
+
+
+class _HSlot:
+    __slots__ = ("trial_index", "spec", "layout", "epoch", "step", "config")
+
+
+def balanced_tiles(groups: List[Tuple[int, int, int, int]]) -> np.ndarray:
+    """XCD-aware tile list.
+
+    ``groups`` holds (group index, tiles_i, tiles_j, weight).  Workgroup ids are dealt round-robin to
+    the 8 XCDs, each with its own L2, so all tiles of one group (which share that group's operands)
+    are given ids with equal ``id % 8``: groups go to the currently lightest of 8 buckets, heaviest
+    first, and the buckets are interleaved; short buckets are padded with group = -1 entries.
+    """
+    buckets: List[List[Tuple[int, int, int]]] = [[] for _ in range(N_XCD)]
+    load = [0] * N_XCD
+    for gi, ti_n, tj_n, w in sorted(groups, key=lambda g: (-g[3] * g[1] * g[2], g[0])):
+        b = min(range(N_XCD), key=lambda k: (load[k], k))
+        for ti in range(ti_n):
+            for tj in range(tj_n):
+                buckets[b].append((gi, ti, tj))
+        load[b] += ti_n * tj_n * max(w, 1)
+    depth = max((len(b) for b in buckets), default=0)
+    out = np.zeros(depth * N_XCD, dtype=L.TILE_DTYPE)
+    out["group"] = -1
+    for b in range(N_XCD):
+        for k, (gi, ti, tj) in enumerate(buckets[b]):
+            out[k * N_XCD + b] = (gi, ti, tj)
+    return out
+
+
+class HipPackEngine(PackEngine):
+    name = "hip"
+
+    def __init__(self, trainable: PackedTrainable, device: Any = "cuda", capacity: Optional[int] = None,
+                 seed: int = 0):
+        if trainable.model != "mlp":
+            raise ValueError("HipPackEngine trains the 'mlp' family")
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipPackEngine needs a GPU")
+        self.lib = L.load()
+        self.t = trainable
+        self.device = torch.device(device)
+        self.seed = int(seed or 0)
+        kw = trainable.model_kwargs
+        self.max_width = int(kw.get("max_width", 512))
+        self.max_layers = int(kw.get("max_layers", 3))
+        self.max_batch = int(kw.get("max_batch", 1024))
+        if self.max_layers > L.MT_MAX_LAYERS or self.max_width > 2048:
+            raise ValueError("max_layers <= 8 and max_width <= 2048")
+        self.F = trainable.in_features
+        self.Fpad = ceil8(self.F)
+        self.capacity = int(capacity or trainable.capacity or 256)
+        dev = self.device
+        # ---- datasets: f32 training table (gathered + converted per step), bf16 validation table
+        self.Xtr = trainable.train[0].to(dev, torch.float32).contiguous()
+        self.ytr = trainable.train[1].to(dev, torch.float32).contiguous()
+        xv = torch.zeros(trainable.val[0].shape[0], self.Fpad, device=dev, dtype=torch.bfloat16)
+        xv[:, :self.F] = trainable.val[0].to(dev, torch.bfloat16)
+        self.Xva, self.yva = xv, trainable.val[1].to(dev, torch.float32).contiguous()
+        self.n_train, self.n_val = int(self.Xtr.shape[0]), int(self.Xva.shape[0])
+        self.val_chunk = int(min(trainable.val_chunk, max(self.n_val, 1)))
+        self.rows_max = max(self.max_batch, self.val_chunk)
+        # ---- slabs
+        wp = ceil8(self.max_width)
+        worst = SlotLayout(MLPTrialSpec(self.F, [self.max_width] * self.max_layers), self.Fpad)
+        self.stride = (worst.total + 63) // 64 * 64
+        T = self.capacity
+        self.P = torch.zeros(T * self.stride, device=dev, dtype=torch.float32)
+        self.G = torch.zeros_like(self.P)
+        self.M = torch.zeros_like(self.P)
+        self.V = torch.zeros_like(self.P)
+        self.Pb = torch.zeros(T * self.stride, device=dev, dtype=torch.bfloat16)
+        self.wp = wp
+        self.act_stride = self.rows_max * wp
+        self.X0 = torch.zeros(T * self.rows_max * self.Fpad, device=dev, dtype=torch.bfloat16)
+        self.H = [torch.zeros(T * self.act_stride, device=dev, dtype=torch.bfloat16) for _ in range(self.max_layers)]
+        self.dZ = [torch.zeros(T * self.act_stride, device=dev, dtype=torch.bfloat16) for _ in range(self.max_layers)]
+        self.ybuf = torch.zeros(T * self.rows_max, device=dev, dtype=torch.float32)
+        self.loss_acc = torch.zeros(T, device=dev, dtype=torch.float32)
+        self.metrics = torch.zeros(T, 3, device=dev, dtype=torch.float64)
+        nb = (self.stride + 2047) // 2048
+        self.partials = torch.zeros(T * nb, device=dev, dtype=torch.float32)
+        self.slots: Dict[int, _HSlot] = {}
+        self._tables: Dict[str, Any] = {}
+        self._dirty = True
+        self._train_loss: Dict[int, float] = {}
+
+    # ------------------------------------------------------------------ slot management
+    def occupied(self) -> List[int]:
+        return sorted(self.slots)
+
+    def hbm_bytes(self) -> int:
+        ts = [self.P, self.G, self.M, self.V, self.Pb, self.X0, self.ybuf, self.Xtr, self.Xva] + self.H + self.dZ
+        return int(sum(t.numel() * t.element_size() for t in ts))
+
+    def _region(self, slab: torch.Tensor, slot: int) -> torch.Tensor:
+        return slab[slot * self.stride:(slot + 1) * self.stride]
+
+    def _write_params(self, slot: int, lay: SlotLayout, state: Dict[str, torch.Tensor], slab: torch.Tensor) -> None:
+        host = torch.zeros(self.stride, dtype=torch.float32)
+        for key, off, (rows, cols), ld in lay.names():
+            src = state[key].detach().to("cpu", torch.float32).reshape(rows, cols)
+            if ld == cols:
+                host[off:off + rows * cols] = src.reshape(-1)
+            else:       # padded row stride: the pad columns stay zero
+                host[off:off + rows * ld].view(rows, ld)[:, :cols] = src
+        self._region(slab, slot).copy_(host.to(self.device))
+
+    def _read_params(self, slot: int, lay: SlotLayout, slab: torch.Tensor) -> Dict[str, torch.Tensor]:
+        host = self._region(slab, slot).detach().to("cpu", torch.float32)
+        out: Dict[str, torch.Tensor] = {}
+        for key, off, (rows, cols), ld in lay.names():
+            if ld == cols:
+                t = host[off:off + rows * cols].reshape(rows, cols).clone()
+            else:
+                t = host[off:off + rows * ld].reshape(rows, ld)[:, :cols].clone()
+            if key.endswith(".bias"):
+                t = t.reshape(-1)
+            elif key == "head.weight":
+                t = t.reshape(1, -1)
+            out[key] = t
+        return out
+
+    def load(self, slot, trial_index, config, state=None):
+        if slot in self.slots:
+            raise RuntimeError(f"slot {slot} is occupied")
+        spec = MLPTrialSpec.from_config(config, self.F)
+        if len(spec.hidden_sizes) > self.max_layers or max(spec.hidden_sizes) > self.max_width:
+            raise ValueError(f"trial shape {spec.hidden_sizes} exceeds the pack limits "
+                             f"(max_layers={self.max_layers}, max_width={self.max_width})")
+        if spec.batch_size > self.max_batch:
+            raise ValueError(f"batch_size {spec.batch_size} > max_batch {self.max_batch}")
+        s = _HSlot()
+        s.trial_index, s.spec, s.config = int(trial_index), spec, dict(config)
+        s.layout = SlotLayout(spec, self.Fpad)
+        s.epoch, s.step = 0, 0
+        for slab in (self.G, self.M, self.V):
+            self._region(slab, slot).zero_()
+        if state is not None and "model" in state:
+            self._write_params(slot, s.layout, state["model"], self.P)
+            opt = state.get("optimizer") or {}
+            if isinstance(opt, dict) and "exp_avg" in opt and opt.get("type") == spec.optimizer:
+                self._write_params(slot, s.layout, opt["exp_avg"], self.M)
+                self._write_params(slot, s.layout, opt["exp_avg_sq"], self.V)
+            s.epoch, s.step = int(state.get("epoch", 0)), int(state.get("step", 0))
+        else:
+            self._write_params(slot, s.layout, init_mlp_state(spec, self.seed, trial_index), self.P)
+        self._region(self.Pb, slot).copy_(self._region(self.P, slot).to(torch.bfloat16))
+        self.loss_acc[slot] = 0
+        self.slots[slot] = s
+        self._dirty = True
+
+    def evict(self, slot):
+        if self.slots.pop(slot, None) is not None:
+            self._dirty = True
+
+    def export(self, slot):
+        s = self.slots[slot]
+        return {"model": self._read_params(slot, s.layout, self.P),
+                "optimizer": {"type": s.spec.optimizer, "step": s.step,
+                              "exp_avg": self._read_params(slot, s.layout, self.M),
+                              "exp_avg_sq": self._read_params(slot, s.layout, self.V)},
+                "epoch": s.epoch, "step": s.step, "trial_index": s.trial_index}
+
+    def clone(self, src, dst, config):
+        a, b = self.slots[src], self.slots[dst]
+        spec = MLPTrialSpec.from_config(config, self.F)
+        if spec.hidden_sizes != a.spec.hidden_sizes:
+            raise ValueError("an exploit cannot change the architecture")
+        for slab in (self.P, self.M, self.V, self.Pb):
+            self._region(slab, dst).copy_(self._region(slab, src))      # device-to-device, stays in HBM
+        b.spec, b.layout, b.config = spec, SlotLayout(spec, self.Fpad), dict(config)
+        b.step = a.step
+        self._dirty = True
+
+    def import_state(self, slot, state, config):
+        keep = self.slots[slot].trial_index
+        epoch = self.slots[slot].epoch
+        self.evict(slot)
+        self.load(slot, keep, config, state=state)
+        self.slots[slot].epoch = epoch
+
+    # ------------------------------------------------------------------ descriptor tables
+    def _upload(self, name: str, arr: np.ndarray) -> int:
+        t = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(self.device)
+        self._tables[name] = t
+        return t.data_ptr()
+
+    def _act_ptr(self, buf: torch.Tensor, slot: int, elem_bytes: int = 2) -> int:
+        return buf.data_ptr() + slot * self.act_stride * elem_bytes
+
+    def _build_gemm_tables(self, eval_mode: bool) -> Dict[str, Any]:
+        Lmax = max(len(s.spec.hidden_sizes) for s in self.slots.values())
+        T = self.capacity
+        out: Dict[str, Any] = {"n_hidden": Lmax}
+        p_base, pb_base, g_base = self.P.data_ptr(), self.Pb.data_ptr(), self.G.data_ptr()
+        x0_stride = self.rows_max * self.Fpad * 2
+        for l in range(Lmax):
+            fwd = np.zeros(T, dtype=L.GEMM_GROUP_DTYPE)
+            dg = np.zeros(T, dtype=L.GEMM_GROUP_DTYPE)
+            wg = np.zeros(T, dtype=L.GEMM_GROUP_DTYPE)
+            fl, dl, wl = [], [], []
+            for slot, s in self.slots.items():
+                lay = s.layout
+                if l >= len(lay.hidden):
+                    continue
+                bsz = self.val_chunk if eval_mode else s.spec.batch_size
+                steps = 1 if eval_mode else self.n_train // min(s.spec.batch_size, self.n_train)
+                h, k_real, k_ld, o_ld = lay.hidden[l], lay.in_dims[l], lay.in_ld[l], lay.out_ld[l]
+                base = slot * self.stride
+                if l == 0:
+                    a_in = self.Xva.data_ptr() if eval_mode else self.X0.data_ptr() + slot * x0_stride
+                else:
+                    a_in = self._act_ptr(self.H[l - 1], slot)
+                fwd[slot] = (a_in, pb_base + (base + lay.w_off[l]) * 2, self._act_ptr(self.H[l], slot),
+                             p_base + (base + lay.b_off[l]) * 4, 0,
+                             bsz, h, k_real, k_ld, k_ld, o_ld, 0, steps)
+                ti = (bsz + TILE - 1) // TILE
+                fl.append((slot, ti, (h + TILE - 1) // TILE, (k_real + 63) // 64))
+                if eval_mode:
+                    continue
+                if l > 0:
+                    dg[slot] = (self._act_ptr(self.dZ[l], slot), pb_base + (base + lay.w_off[l]) * 2,
+                                self._act_ptr(self.dZ[l - 1], slot), self._act_ptr(self.H[l - 1], slot), 0,
+                                bsz, k_real, h, o_ld, k_ld, k_ld, k_ld, steps)
+                    dl.append((slot, ti, (k_real + TILE - 1) // TILE, (h + 63) // 64))
+                wg[slot] = (self._act_ptr(self.dZ[l], slot), a_in, g_base + (base + lay.w_off[l]) * 4, 0,
+                            g_base + (base + lay.b_off[l]) * 4,
+                            h, k_real, bsz, o_ld, k_ld, k_ld, 0, steps)
+                wl.append((slot, (h + TILE - 1) // TILE, (k_real + TILE - 1) // TILE, (bsz + 63) // 64))
+            tag = "e" if eval_mode else "t"
+            ft = balanced_tiles(fl)
+            out[f"fwd{l}"] = (self._upload(f"{tag}fwd_g{l}", fwd), self._upload(f"{tag}fwd_t{l}", ft), len(ft))
+            if not eval_mode:
+                dt, wt = balanced_tiles(dl), balanced_tiles(wl)
+                out[f"dgrad{l}"] = (self._upload(f"dg_g{l}", dg), self._upload(f"dg_t{l}", dt), len(dt))
+                out[f"wgrad{l}"] = (self._upload(f"wg_g{l}", wg), self._upload(f"wg_t{l}", wt), len(wt))
+        return out
+
+    def _build_plan(self, eval_mode: bool) -> L.MlpPlan:
+        T = self.capacity
+        gt = self._build_gemm_tables(eval_mode)
+        plan = L.MlpPlan()
+        plan.n_hidden, plan.n_slots = gt["n_hidden"], T
+        plan.max_batch = max(s.spec.batch_size for s in self.slots.values())
+        plan.max_width = max(max(s.spec.hidden_sizes) for s in self.slots.values())
+        plan.max_params = max(s.layout.total for s in self.slots.values())
+        plan.F, plan.Fpad, plan.hb, plan.n_rows = self.F, self.Fpad, half_bits(self.n_train), self.n_train
+        plan.use_clip = int(any(s.spec.gradient_clipping > 0 for s in self.slots.values()))
+        plan.X, plan.Y = self.Xtr.data_ptr(), self.ytr.data_ptr()
+        for l in range(gt["n_hidden"]):
+            plan.fwd_groups[l], plan.fwd_tiles[l], plan.fwd_ntiles[l] = gt[f"fwd{l}"]
+            if not eval_mode:
+                plan.dgrad_groups[l], plan.dgrad_tiles[l], plan.dgrad_ntiles[l] = gt[f"dgrad{l}"]
+                plan.wgrad_groups[l], plan.wgrad_tiles[l], plan.wgrad_ntiles[l] = gt[f"wgrad{l}"]
+        head = np.zeros(T, dtype=L.HEAD_DTYPE)
+        for slot, s in self.slots.items():
+            lay, last = s.layout, len(s.layout.hidden) - 1
+            base = slot * self.stride
+            steps = 1 if eval_mode else self.n_train // min(s.spec.batch_size, self.n_train)
+            head[slot] = (self._act_ptr(self.H[last], slot), self._act_ptr(self.dZ[last], slot),
+                          self.P.data_ptr() + (base + lay.head_w_off) * 4, self.P.data_ptr() + (base + lay.head_b_off) * 4,
+                          self.G.data_ptr() + (base + lay.head_w_off) * 4, self.G.data_ptr() + (base + lay.head_b_off) * 4,
+                          self.yva.data_ptr() if eval_mode else self.ybuf.data_ptr() + slot * self.rows_max * 4,
+                          self.loss_acc.data_ptr() + slot * 4, self.metrics.data_ptr() + slot * 24,
+                          self.val_chunk if eval_mode else s.spec.batch_size, lay.hidden[last], lay.out_ld[last],
+                          LOSS_CODES[s.spec.loss_function], steps, 0)
+        plan.head = self._upload("ehead" if eval_mode else "thead", head)
+        plan.P, plan.G, plan.M, plan.V, plan.Pb = (self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
+                                                   self.V.data_ptr(), self.Pb.data_ptr())
+        plan.slot_stride = self.stride
+        plan.partials = self.partials.data_ptr()
+        return plan
+
+    def _epoch_tables(self, plan: L.MlpPlan) -> int:
+        """Gather keys and optimiser step bases change every epoch; returns the pack's step count."""
+        T = self.capacity
+        gat = np.zeros(T, dtype=L.GATHER_DTYPE)
+        opt = np.zeros(T, dtype=L.OPT_DTYPE)
+        max_steps = 0
+        x0_stride = self.rows_max * self.Fpad * 2
+        for slot, s in self.slots.items():
+            sp = s.spec
+            b = min(sp.batch_size, self.n_train)
+            steps = self.n_train // b
+            max_steps = max(max_steps, steps)
+            gat[slot] = (self.X0.data_ptr() + slot * x0_stride, self.ybuf.data_ptr() + slot * self.rows_max * 4,
+                         round_keys(self.seed, s.trial_index, s.epoch), b, steps)
+            opt[slot] = (sp.learning_rate, sp.beta1, sp.beta2, sp.eps, sp.weight_decay, sp.momentum,
+                         sp.gradient_clipping, OPT_CODES[sp.optimizer], sp.warmup_steps, sp.total_steps,
+                         s.layout.total, steps, s.step, (0, 0, 0))
+        plan.gather = self._upload("gather", gat)
+        plan.opt = self._upload("opt", opt)
+        return max_steps
+
+    # ------------------------------------------------------------------ training / evaluation
+    def train_epoch(self):
+        if not self.slots:
+            return
+        if self._dirty or "train_plan" not in self._tables:
+            self._tables["train_plan"] = self._build_plan(eval_mode=False)
+            self._tables["eval_plan"] = self._build_plan(eval_mode=True)
+            self._dirty = False
+        plan = self._tables["train_plan"]
+        steps = self._epoch_tables(plan)
+        self.loss_acc.zero_()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.mt_mlp_train_steps(C.byref(plan), 0, steps, stream), "mt_mlp_train_steps")
+        losses = self.loss_acc.to("cpu")           # the epoch's only host synchronisation
+        for slot, s in self.slots.items():
+            n = self.n_train // min(s.spec.batch_size, self.n_train)
+            self._train_loss[slot] = float(losses[slot]) / max(n, 1)
+            s.step += n
+            s.epoch += 1
+
+    def evaluate(self):
+        if not self.slots:
+            return {}
+        if self._dirty or "eval_plan" not in self._tables:
+            self._tables["train_plan"] = self._build_plan(eval_mode=False)
+            self._tables["eval_plan"] = self._build_plan(eval_mode=True)
+            self._dirty = False
+        plan = self._tables["eval_plan"]
+        self.metrics.zero_()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.mt_mlp_eval(C.byref(plan), self.n_val, self.val_chunk, stream), "mt_mlp_eval")
+        m = self.metrics.to("cpu")
+        out: Dict[int, Dict[str, float]] = {}
+        for slot in self.occupied():
+            out[slot] = {"train_loss": self._train_loss.get(slot, float("nan")),
+                         "validation_loss": float(m[slot, 0]) / self.n_val,
+                         "validation_mse": float(m[slot, 1]) / self.n_val,
+                         "validation_mape": 100.0 * float(m[slot, 2]) / self.n_val}
+        return out

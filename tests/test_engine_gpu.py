@@ -1,0 +1,95 @@
+"""The HIP pack engine against the per-trial PyTorch oracle, and packing invariance."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(n=6000, f=20, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(n, f, generator=g)
+    w = torch.randn(f, generator=g)
+    y = torch.tanh(X @ w * 0.3) * 2 + 0.3 * X[:, 0] * X[:, 1] + 0.05 * torch.randn(n, generator=g)
+    k = int(0.8 * n)
+    return (X[:k], y[:k]), (X[k:], y[k:])
+
+
+CONFIGS = [
+    {"hidden_sizes": [64, 64], "batch_size": 128, "learning_rate": 3e-3, "optimizer": "adamw", "weight_decay": 1e-3},
+    {"hidden_sizes": [128, 64, 32], "batch_size": 256, "learning_rate": 1e-3, "optimizer": "adam", "loss_function": "huber"},
+    {"hidden_sizes": [40], "batch_size": 64, "learning_rate": 1e-2, "optimizer": "sgd", "momentum": 0.9,
+     "gradient_clipping": 1.0},
+    {"hidden_sizes": [256, 200], "batch_size": 512, "learning_rate": 2e-3, "optimizer": "rmsprop", "loss_function": "mae",
+     "warmup_steps": 5, "total_steps": 200},
+]
+
+
+def _run(engine_cls, trainable, configs, slots, epochs, **kw):
+    eng = engine_cls(trainable, **kw)
+    for slot, (idx, cfg) in zip(slots, configs):
+        eng.load(slot, idx, cfg)
+    hist = []
+    for _ in range(epochs):
+        eng.train_epoch()
+        hist.append(eng.evaluate())
+    states = {slot: eng.export(slot) for slot in slots}
+    return hist, states
+
+
+def test_hip_engine_tracks_torch_oracle():
+    from mitune.packed import PackedTrainable, TorchPackEngine
+    from mitune.packed.engine_hip import HipPackEngine
+    train, val = _data()
+    tr = PackedTrainable(train=train, val=val, max_epochs=3, val_chunk=512,
+                         model_kwargs={"max_width": 256, "max_layers": 3, "max_batch": 512})
+    cfgs = list(enumerate(CONFIGS))
+    slots = [0, 1, 2, 3]
+    h_hip, s_hip = _run(HipPackEngine, tr, cfgs, slots, 3, device="cuda", capacity=6, seed=3)
+    h_ref, s_ref = _run(TorchPackEngine, tr, cfgs, slots, 3, device="cuda", capacity=6, seed=3)
+    var_y = float(val[1].var())
+    for e in range(3):
+        for slot in slots:
+            a, b = h_hip[e][slot], h_ref[e][slot]
+            for k in ("train_loss", "validation_loss", "validation_mse"):
+                assert a[k] == pytest.approx(b[k], rel=0.08, abs=0.02 * var_y), (e, slot, k, a, b)
+    # the model actually learns (bf16 compute does not stall training)
+    assert h_hip[-1][0]["validation_mse"] < 0.5 * var_y
+    # exported checkpoint loads into the plain single-trial module
+    from mitune.models.mlp import MLPRegressor
+    m = MLPRegressor(train[0].shape[1], CONFIGS[1]["hidden_sizes"])
+    m.load_state_dict(s_hip[1]["model"])
+    with torch.no_grad():
+        mse = float(((m(val[0]) - val[1]) ** 2).mean())
+    assert mse == pytest.approx(h_hip[-1][1]["validation_mse"], rel=0.05)
+
+
+def test_packing_invariance_is_bitwise():
+    """A trial's weights do not depend on its slot or on which other trials share the pack."""
+    from mitune.packed import PackedTrainable
+    from mitune.packed.engine_hip import HipPackEngine
+    train, val = _data(seed=1)
+    tr = PackedTrainable(train=train, val=val, max_epochs=2, val_chunk=512,
+                         model_kwargs={"max_width": 256, "max_layers": 3, "max_batch": 512})
+    _, alone = _run(HipPackEngine, tr, [(7, CONFIGS[1])], [0], 2, device="cuda", capacity=8, seed=5)
+    _, packed = _run(HipPackEngine, tr, [(3, CONFIGS[0]), (7, CONFIGS[1]), (9, CONFIGS[3])], [5, 2, 6], 2,
+                     device="cuda", capacity=8, seed=5)
+    for k, v in alone[0]["model"].items():
+        assert torch.equal(v, packed[2]["model"][k]), k
+
+
+def test_end_to_end_packed_search_on_gpu(tmp_path):
+    import mitune
+    from mitune import tune
+    from mitune.packed import PackedTrainable
+    from mitune.schedulers import ASHAScheduler
+    train, val = _data(n=20000, f=16, seed=2)
+    tr = PackedTrainable(train=train, val=val, max_epochs=4, checkpoint_at_end=True, val_chunk=2048,
+                         model_kwargs={"max_width": 128, "max_layers": 2, "max_batch": 256}, capacity=16)
+    an = mitune.run(tr, config={"width": tune.choice([32, 64, 128]), "num_layers": tune.choice([1, 2]),
+                                "learning_rate": tune.loguniform(1e-3, 1e-2), "batch_size": tune.choice([128, 256])},
+                    num_samples=24, scheduler=ASHAScheduler(metric="validation_loss", mode="min", max_t=4,
+                                                            reduction_factor=2),
+                    local_dir=str(tmp_path), verbose=0)
+    assert len(an.trials) == 24 and an.stats["engine"] == "hip"
+    assert an.best_result["validation_loss"] < 0.3 * float(val[1].var())
+    assert an.best_checkpoint is not None

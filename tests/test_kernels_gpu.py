@@ -1,0 +1,246 @@
+"""Numerics of every hand-written HIP kernel against a plain PyTorch fp32 reference of the same op.
+
+bf16 operands are generated as bf16-representable values, so the only difference between kernel and
+reference is the f32 accumulation order (and the final bf16 rounding of bf16 outputs).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mitune.ops import lib as L
+    return L, L.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _up(arr: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).cuda()
+
+
+def _tiles(L, dims):
+    """dims: list of (group, I, J) -> plain (unbalanced) tile list incl. one padding entry."""
+    rows = [(-1, 0, 0)]
+    for g, i, j in dims:
+        for ti in range((i + 127) // 128):
+            for tj in range((j + 127) // 128):
+                rows.append((g, ti, tj))
+    return np.array(rows, dtype=L.TILE_DTYPE)
+
+
+def _rand_bf16(*shape, scale=1.0, gen=None):
+    return (torch.randn(*shape, generator=gen, device="cuda") * scale).to(torch.bfloat16)
+
+
+SHAPES = [(256, 128, 64), (512, 512, 512), (200, 72, 40), (128, 64, 8), (384, 256, 192), (130, 136, 520)]
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_gemm_forward_nt(lib, relu):
+    L, so = lib
+    g = torch.Generator(device="cuda").manual_seed(1)
+    groups = np.zeros(len(SHAPES) + 1, dtype=L.GEMM_GROUP_DTYPE)
+    keep, dims = [], []
+    for gi, (m, n, k) in enumerate(SHAPES):
+        ldk, ldn = (k + 7) // 8 * 8, (n + 7) // 8 * 8
+        x = torch.zeros(m, ldk, device="cuda", dtype=torch.bfloat16); x[:, :k] = _rand_bf16(m, k, gen=g)
+        w = torch.zeros(n, ldk, device="cuda", dtype=torch.bfloat16); w[:, :k] = _rand_bf16(n, k, scale=0.2, gen=g)
+        b = torch.randn(n, device="cuda", generator=g)
+        y = torch.full((m, ldn), 7.0, device="cuda", dtype=torch.bfloat16)
+        groups[gi] = (x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, m, n, k, ldk, ldk, ldn, 0, 1)
+        keep.append((x, w, b, y)); dims.append((gi, m, n))
+    groups[len(SHAPES)]["active_steps"] = 0
+    tiles = _tiles(L, dims)
+    gt, tt = _up(groups), _up(tiles)
+    L.check(so.mt_gemm_launch(0, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, int(relu), 0, 0, _stream()), "gemm")
+    torch.cuda.synchronize()
+    for (m, n, k), (x, w, b, y) in zip(SHAPES, keep):
+        ref = x[:, :k].float() @ w[:, :k].float().t() + b
+        if relu:
+            ref = ref.relu()
+        got = y[:, :n].float()
+        torch.testing.assert_close(got, ref, rtol=1e-2, atol=1e-2)
+        ldn = y.shape[1]
+        if ldn > n:     # pad columns inside the last 8-chunk are written as zeros
+            assert torch.all(y[:, n:] == 0)
+
+
+def test_gemm_forward_identity_asymmetric(lib):
+    """A = I with an asymmetric B: catches a transposed or permuted accumulator write."""
+    L, so = lib
+    n = 128
+    x = torch.eye(n, device="cuda", dtype=torch.bfloat16)
+    w = (torch.arange(n * n, device="cuda").reshape(n, n) % 251).float().to(torch.bfloat16)   # W[j][k]
+    b = torch.zeros(n, device="cuda")
+    y = torch.zeros(n, n, device="cuda", dtype=torch.bfloat16)
+    groups = np.zeros(1, dtype=L.GEMM_GROUP_DTYPE)
+    groups[0] = (x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, n, n, n, n, n, n, 0, 1)
+    tiles = _tiles(L, [(0, n, n)])
+    gt, tt = _up(groups), _up(tiles)
+    L.check(so.mt_gemm_launch(0, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, 0, 0, 0, _stream()), "gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(y.float(), w.float().t())
+
+
+@pytest.mark.parametrize("mask", [False, True])
+def test_gemm_dgrad_nn(lib, mask):
+    L, so = lib
+    g = torch.Generator(device="cuda").manual_seed(2)
+    groups = np.zeros(len(SHAPES), dtype=L.GEMM_GROUP_DTYPE)
+    keep, dims = [], []
+    for gi, (m, n, k) in enumerate(SHAPES):      # dX[m,k] = dY[m,n] @ W[n,k]
+        ldk, ldn = (k + 7) // 8 * 8, (n + 7) // 8 * 8
+        dy = torch.zeros(m, ldn, device="cuda", dtype=torch.bfloat16); dy[:, :n] = _rand_bf16(m, n, gen=g)
+        w = torch.zeros(n, ldk, device="cuda", dtype=torch.bfloat16); w[:, :k] = _rand_bf16(n, k, scale=0.2, gen=g)
+        h = torch.zeros(m, ldk, device="cuda", dtype=torch.bfloat16); h[:, :k] = _rand_bf16(m, k, gen=g).relu()
+        dx = torch.full((m, ldk), 7.0, device="cuda", dtype=torch.bfloat16)
+        groups[gi] = (dy.data_ptr(), w.data_ptr(), dx.data_ptr(), h.data_ptr(), 0, m, k, n, ldn, ldk, ldk, ldk, 1)
+        keep.append((dy, w, h, dx)); dims.append((gi, m, k))
+    tiles = _tiles(L, dims)
+    gt, tt = _up(groups), _up(tiles)
+    L.check(so.mt_gemm_launch(1, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, int(mask), 0, 0, _stream()), "gemm")
+    torch.cuda.synchronize()
+    for (m, n, k), (dy, w, h, dx) in zip(SHAPES, keep):
+        ref = dy[:, :n].float() @ w[:, :k].float()
+        if mask:
+            ref = ref * (h[:, :k].float() > 0)
+        torch.testing.assert_close(dx[:, :k].float(), ref, rtol=1e-2, atol=1e-2)
+
+
+def test_gemm_wgrad_tn(lib):
+    L, so = lib
+    g = torch.Generator(device="cuda").manual_seed(3)
+    groups = np.zeros(len(SHAPES), dtype=L.GEMM_GROUP_DTYPE)
+    keep, dims = [], []
+    for gi, (m, n, k) in enumerate(SHAPES):      # dW[n,k] = dY[m,n]^T @ X[m,k];  db[n] = sum_m dY[m,n]
+        ldk, ldn = (k + 7) // 8 * 8, (n + 7) // 8 * 8
+        dy = torch.zeros(m, ldn, device="cuda", dtype=torch.bfloat16); dy[:, :n] = _rand_bf16(m, n, scale=0.1, gen=g)
+        x = torch.zeros(m, ldk, device="cuda", dtype=torch.bfloat16); x[:, :k] = _rand_bf16(m, k, gen=g)
+        dw = torch.zeros(n, ldk, device="cuda")
+        db = torch.full((n,), 5.0, device="cuda")
+        groups[gi] = (dy.data_ptr(), x.data_ptr(), dw.data_ptr(), 0, db.data_ptr(), n, k, m, ldn, ldk, ldk, 0, 1)
+        keep.append((dy, x, dw, db)); dims.append((gi, n, k))
+    tiles = _tiles(L, dims)
+    gt, tt = _up(groups), _up(tiles)
+    L.check(so.mt_gemm_launch(2, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, 1, 0, 0, _stream()), "gemm")
+    torch.cuda.synchronize()
+    for (m, n, k), (dy, x, dw, db) in zip(SHAPES, keep):
+        ref = dy[:, :n].float().t() @ x[:, :k].float()
+        torch.testing.assert_close(dw[:, :k], ref, rtol=2e-3, atol=2e-3)
+        torch.testing.assert_close(db, dy[:, :n].float().sum(0), rtol=2e-3, atol=2e-3)
+        if dw.shape[1] > k:
+            assert torch.all(dw[:, k:] == 0)
+
+
+def test_gather_matches_numpy_permutation(lib):
+    L, so = lib
+    from mitune.packed.permutation import half_bits, permute, round_keys
+    n, F, Fpad, B = 5000, 10, 16, 96
+    X = torch.randn(n, F, device="cuda"); Y = torch.randn(n, device="cuda")
+    slots = np.zeros(3, dtype=L.GATHER_DTYPE)
+    outs = []
+    for s in range(3):
+        x0 = torch.full((B, Fpad), 9.0, device="cuda", dtype=torch.bfloat16); y = torch.zeros(B, device="cuda")
+        keys = round_keys(11, 100 + s, 2)
+        slots[s] = (x0.data_ptr(), y.data_ptr(), keys, B - 8 * s, 50)
+        outs.append((x0, y, keys))
+    st = _up(slots)
+    step = 7
+    L.check(so.mt_gather_launch(st.data_ptr(), 3, B, X.data_ptr(), Y.data_ptr(), n, F, Fpad, half_bits(n), step,
+                                _stream()), "gather")
+    torch.cuda.synchronize()
+    for s, (x0, y, keys) in enumerate(outs):
+        b = B - 8 * s
+        idx = torch.from_numpy(permute(np.arange(step * b, step * b + b, dtype=np.uint32), n, keys)).cuda()
+        assert torch.equal(x0[:b, :F], X[idx].to(torch.bfloat16))
+        assert torch.all(x0[:b, F:] == 0)
+        assert torch.equal(y[:b], Y[idx])
+
+
+@pytest.mark.parametrize("loss,code", [("mse", 0), ("mae", 1), ("huber", 2), ("mape", 3)])
+def test_head_loss(lib, loss, code):
+    L, so = lib
+    from mitune.train.losses import elementwise_loss
+    g = torch.Generator(device="cuda").manual_seed(4)
+    cfgs = [(256, 512), (100, 64), (96, 200)]
+    slots = np.zeros(len(cfgs), dtype=L.HEAD_DTYPE)
+    keep = []
+    for s, (B, W) in enumerate(cfgs):
+        ld = (W + 7) // 8 * 8
+        H = torch.zeros(B, ld, device="cuda", dtype=torch.bfloat16); H[:, :W] = _rand_bf16(B, W, gen=g).relu()
+        dH = torch.zeros(B, ld, device="cuda", dtype=torch.bfloat16)
+        w = torch.randn(W, device="cuda", generator=g) * 0.1; b = torch.randn(1, device="cuda", generator=g)
+        gw = torch.zeros(W, device="cuda"); gb = torch.zeros(1, device="cuda")
+        y = torch.randn(B, device="cuda", generator=g) + 2.0
+        acc = torch.full((1,), 1.0, device="cuda"); met = torch.zeros(3, device="cuda", dtype=torch.float64)
+        slots[s] = (H.data_ptr(), dH.data_ptr(), w.data_ptr(), b.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                    y.data_ptr(), acc.data_ptr(), met.data_ptr(), B, W, ld, code, 1, 0)
+        keep.append((H, dH, w, b, gw, gb, y, acc, met))
+    st = _up(slots)
+    L.check(so.mt_head_loss_launch(st.data_ptr(), len(cfgs), 512, 0, _stream()), "head_loss")
+    L.check(so.mt_head_eval_launch(st.data_ptr(), len(cfgs), 512, 0, 0, _stream()), "head_eval")
+    torch.cuda.synchronize()
+    for (B, W), (H, dH, w, b, gw, gb, y, acc, met) in zip(cfgs, keep):
+        h = H[:, :W].float().requires_grad_(True)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        out = h @ wr + br
+        l = elementwise_loss(loss, out, y).mean()
+        l.backward()
+        torch.testing.assert_close(acc, torch.tensor([1.0 + l.item()], device="cuda"), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(gw, wr.grad, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(gb, br.grad, rtol=1e-3, atol=1e-4)
+        ref_dh = (h.grad * (h > 0)).detach()
+        torch.testing.assert_close(dH[:, :W].float(), ref_dh, rtol=1e-2, atol=1e-5)
+        d = (out - y).detach()
+        ref_m = torch.stack([elementwise_loss(loss, out, y).sum(), (d * d).sum(), (d.abs() / (y.abs() + 1e-8)).sum()])
+        torch.testing.assert_close(met.float(), ref_m.detach().float(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("name,code", [("adam", 0), ("adamw", 1), ("sgd", 2), ("rmsprop", 3)])
+@pytest.mark.parametrize("clip", [0.0, 0.5])
+def test_fused_optimizer_matches_torch(lib, name, code, clip):
+    L, so = lib
+    from mitune.train.optim import build_optimizer
+    g = torch.Generator(device="cuda").manual_seed(5)
+    sizes, stride = [5000, 333, 2048], 6144
+    T = len(sizes)
+    P = torch.zeros(T * stride, device="cuda"); G = torch.zeros_like(P); M = torch.zeros_like(P); V = torch.zeros_like(P)
+    Pb = torch.zeros(T * stride, device="cuda", dtype=torch.bfloat16)
+    hp = np.zeros(T, dtype=L.OPT_DTYPE)
+    refs = []
+    for s, n in enumerate(sizes):
+        p0 = torch.randn(n, device="cuda", generator=g)
+        P[s * stride:s * stride + n] = p0
+        lr, wd, mom = 1e-2 * (s + 1), 1e-2, 0.9
+        hp[s] = (lr, 0.9, 0.999, 1e-8, wd, mom, clip, code, 0, 0, n, 100, 0, (0, 0, 0))
+        pr = p0.clone().requires_grad_(True)
+        refs.append((pr, build_optimizer(name, [pr], lr, wd, mom)))
+    nb = (max(sizes) + 2047) // 2048
+    partials = torch.zeros(T * nb, device="cuda")
+    ht = _up(hp)
+    for step in range(5):
+        for s, n in enumerate(sizes):
+            gr = torch.randn(n, device="cuda", generator=g)
+            G[s * stride:s * stride + n] = gr
+            pr, opt = refs[s]
+            pr.grad = gr.clone()
+            if clip > 0:
+                torch.nn.utils.clip_grad_norm_([pr], clip)
+            opt.step()
+        L.check(so.mt_optim_launch(P.data_ptr(), G.data_ptr(), M.data_ptr(), V.data_ptr(), Pb.data_ptr(), stride,
+                                   ht.data_ptr(), T, max(sizes), partials.data_ptr(), int(clip > 0), step, _stream()),
+                "optim")
+    torch.cuda.synchronize()
+    for s, n in enumerate(sizes):
+        got = P[s * stride:s * stride + n]
+        torch.testing.assert_close(got, refs[s][0].detach(), rtol=2e-5, atol=2e-6)
+        assert torch.equal(Pb[s * stride:s * stride + n], got.to(torch.bfloat16))
+        assert torch.all(P[s * stride + n:(s + 1) * stride] == 0)
