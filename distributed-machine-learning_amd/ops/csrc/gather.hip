@@ -7,9 +7,10 @@
 #include "mt_common.h"
 
 __global__ __launch_bounds__(256) void mt_gather_kernel(const MtGatherSlot* __restrict__ slots,
+                                                        const int32_t* __restrict__ ids,
                                                         const float* __restrict__ X, const float* __restrict__ Y,
                                                         uint32_t n_rows, int F, int Fpad, int hb, int step) {
-  const MtGatherSlot s = slots[blockIdx.y];
+  const MtGatherSlot s = slots[ids[blockIdx.y]];
   if (step >= s.active_steps) return;
   const int cpr = Fpad >> 3;                 // 16-byte output chunks per row
   const int rows_per_block = 256 / cpr;
@@ -37,13 +38,13 @@ __global__ __launch_bounds__(256) void mt_gather_kernel(const MtGatherSlot* __re
   if (c == 0) s.y[i] = Y[src];
 }
 
-extern "C" int mt_gather_launch(const MtGatherSlot* slots, int n_slots, int max_batch, const float* X,
+extern "C" int mt_gather_launch(const MtGatherSlot* slots, const int32_t* ids, int n_slots, int max_batch, const float* X,
                                 const float* Y, uint32_t n_rows, int F, int Fpad, int hb, int step,
                                 hipStream_t stream) {
   if (n_slots <= 0) return 0;
   if (Fpad % 8 != 0 || Fpad / 8 > 256 || Fpad < F) return -2;
   const int rows_per_block = 256 / (Fpad / 8);
   dim3 grid((max_batch + rows_per_block - 1) / rows_per_block, n_slots), block(256);
-  hipLaunchKernelGGL(mt_gather_kernel, grid, block, 0, stream, slots, X, Y, n_rows, F, Fpad, hb, step);
+  hipLaunchKernelGGL(mt_gather_kernel, grid, block, 0, stream, slots, ids, X, Y, n_rows, F, Fpad, hb, step);
   return (int)hipGetLastError();
 }

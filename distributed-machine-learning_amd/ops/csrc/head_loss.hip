@@ -28,10 +28,22 @@ __device__ __forceinline__ void loss_and_grad(int type, float out, float y, floa
   }
 }
 
+// Training: grid (row_chunks, active slots).  Workgroup (c, a) handles rows [c*HL_ROWS, (c+1)*HL_ROWS) of
+// slot ids[a] and writes one partial record {gw[0..W), gb, loss} to scratch; mt_head_reduce_kernel then adds
+// the records of a slot in chunk order (fixed order => bitwise reproducible, no float atomics).
+#define HL_ROWS 64
+
 template <int NCHUNK>
-__global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSlot* __restrict__ slots, int step) {
-  const MtHeadSlot s = slots[blockIdx.x];
+__global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSlot* __restrict__ slots,
+                                                                  const int32_t* __restrict__ ids, int step,
+                                                                  float* __restrict__ scratch, int max_chunks,
+                                                                  int rec) {
+  const int slot = ids[blockIdx.y];
+  const MtHeadSlot s = slots[slot];
   if (step >= s.active_steps) return;
+  const int row_lo = blockIdx.x * HL_ROWS;
+  if (row_lo >= s.B) return;
+  const int row_hi = (row_lo + HL_ROWS < s.B) ? row_lo + HL_ROWS : s.B;
   __shared__ float red[HL_WAVES][NCHUNK * 512];
   __shared__ float red_s[HL_WAVES][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -51,7 +63,7 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSl
   const float inv_b = 1.f / (float)s.B;
   float loss_sum = 0.f, gb = 0.f;
 
-  for (int i = wave; i < s.B; i += HL_WAVES) {
+  for (int i = row_lo + wave; i < row_hi; i += HL_WAVES) {
     u32x4 hv[NCHUNK];
     float dot = 0.f;
 #pragma unroll
@@ -94,24 +106,52 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSl
     for (int e = 0; e < 8; ++e) red[wave][c * 512 + lane * 8 + e] = gw[c][e];
   if (lane == 0) { red_s[wave][0] = loss_sum; red_s[wave][1] = gb; }
   __syncthreads();
+  float* out = scratch + ((size_t)slot * max_chunks + blockIdx.x) * rec;
   for (int k = tid; k < s.W; k += HL_THREADS)
-    s.gw[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    out[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
   if (tid == 0) {
-    s.gb[0] = (red_s[0][1] + red_s[1][1]) + (red_s[2][1] + red_s[3][1]);
-    const float ls = (red_s[0][0] + red_s[1][0]) + (red_s[2][0] + red_s[3][0]);
-    s.loss_acc[0] += ls * inv_b;
+    out[rec - 2] = (red_s[0][1] + red_s[1][1]) + (red_s[2][1] + red_s[3][1]);
+    out[rec - 1] = ((red_s[0][0] + red_s[1][0]) + (red_s[2][0] + red_s[3][0])) * inv_b;
   }
 }
 
+__global__ __launch_bounds__(HL_THREADS) void mt_head_reduce_kernel(const MtHeadSlot* __restrict__ slots,
+                                                                    const int32_t* __restrict__ ids, int step,
+                                                                    const float* __restrict__ scratch,
+                                                                    int max_chunks, int rec) {
+  const int slot = ids[blockIdx.x];
+  const MtHeadSlot s = slots[slot];
+  if (step >= s.active_steps) return;
+  const int nchunk = (s.B + HL_ROWS - 1) / HL_ROWS;
+  const float* base = scratch + (size_t)slot * max_chunks * rec;
+  for (int k = threadIdx.x; k < s.W + 2; k += HL_THREADS) {
+    const int col = (k < s.W) ? k : rec - 2 + (k - s.W);
+    float acc = 0.f;
+    for (int c = 0; c < nchunk; ++c) acc += base[(size_t)c * rec + col];
+    if (k < s.W) s.gw[k] = acc;
+    else if (k == s.W) s.gb[0] = acc;
+    else s.loss_acc[0] += acc;
+  }
+}
+
+// Evaluation: grid (row_chunks, active slots); each workgroup writes {sum loss, sum sq err, sum abs pct err}
+// of its HL_EVAL_ROWS rows to scratch, mt_head_eval_reduce_kernel adds them (chunk order) into the f64 table.
+#define HL_EVAL_ROWS 256
+
 template <int NCHUNK>
-__global__ __launch_bounds__(HL_THREADS) void mt_head_eval_kernel(const MtHeadSlot* __restrict__ slots, int row0, int nrows) {
-  MtHeadSlot s = slots[blockIdx.x];
+__global__ __launch_bounds__(HL_THREADS) void mt_head_eval_kernel(const MtHeadSlot* __restrict__ slots,
+                                                                  const int32_t* __restrict__ ids, int row0, int nrows,
+                                                                  float* __restrict__ scratch, int max_chunks) {
+  const int slot = ids[blockIdx.y];
+  MtHeadSlot s = slots[slot];
   if (s.active_steps <= 0) return;
   if (nrows > 0) {   // chunked evaluation: targets [row0, row0 + nrows) of the shared validation vector
     s.B = nrows;
     s.y += row0;
   }
-  if (s.B <= 0) return;
+  const int row_lo = blockIdx.x * HL_EVAL_ROWS;
+  if (row_lo >= s.B) return;
+  const int row_hi = (row_lo + HL_EVAL_ROWS < s.B) ? row_lo + HL_EVAL_ROWS : s.B;
   __shared__ float red_s[HL_WAVES][3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint16_t* H = reinterpret_cast<const uint16_t*>(s.H);
@@ -125,7 +165,7 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_eval_kernel(const MtHeadSl
     }
   const float bias = s.b[0];
   float sl = 0.f, sse = 0.f, sape = 0.f;
-  for (int i = wave; i < s.B; i += HL_WAVES) {
+  for (int i = row_lo + wave; i < row_hi; i += HL_WAVES) {
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
@@ -149,30 +189,66 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_eval_kernel(const MtHeadSl
   }
   if (lane == 0) { red_s[wave][0] = sl; red_s[wave][1] = sse; red_s[wave][2] = sape; }
   __syncthreads();
-  if (tid == 0) {
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-      s.metrics[m] += (double)((red_s[0][m] + red_s[1][m]) + (red_s[2][m] + red_s[3][m]));
+  if (tid < 3)
+    scratch[((size_t)slot * max_chunks + blockIdx.x) * 4 + tid] =
+        (red_s[0][tid] + red_s[1][tid]) + (red_s[2][tid] + red_s[3][tid]);
+}
+
+__global__ __launch_bounds__(64) void mt_head_eval_reduce_kernel(const MtHeadSlot* __restrict__ slots,
+                                                                 const int32_t* __restrict__ ids, int nrows,
+                                                                 const float* __restrict__ scratch, int max_chunks) {
+  const int slot = ids[blockIdx.x];
+  const MtHeadSlot s = slots[slot];
+  if (s.active_steps <= 0) return;
+  const int rows = nrows > 0 ? nrows : s.B;
+  const int nchunk = (rows + HL_EVAL_ROWS - 1) / HL_EVAL_ROWS;
+  if (threadIdx.x < 3) {
+    double acc = 0.0;
+    for (int c = 0; c < nchunk; ++c) acc += (double)scratch[((size_t)slot * max_chunks + c) * 4 + threadIdx.x];
+    s.metrics[threadIdx.x] += acc;
   }
 }
 
-extern "C" int mt_head_loss_launch(const MtHeadSlot* slots, int n_slots, int max_width, int step, hipStream_t stream) {
-  if (n_slots <= 0) return 0;
-  dim3 grid(n_slots), block(HL_THREADS);
-  if (max_width <= 512) hipLaunchKernelGGL(mt_head_loss_kernel<1>, grid, block, 0, stream, slots, step);
-  else if (max_width <= 1024) hipLaunchKernelGGL(mt_head_loss_kernel<2>, grid, block, 0, stream, slots, step);
-  else if (max_width <= 2048) hipLaunchKernelGGL(mt_head_loss_kernel<4>, grid, block, 0, stream, slots, step);
+// Scratch floats needed for n_slots physical slots: training records and evaluation records share it.
+extern "C" long mt_head_scratch_floats(int n_slots, int max_rows, int max_width) {
+  const long rec = ((max_width + 7) / 8) * 8 + 8;
+  const long train = (long)((max_rows + HL_ROWS - 1) / HL_ROWS) * rec;
+  const long eval = (long)((max_rows + HL_EVAL_ROWS - 1) / HL_EVAL_ROWS) * 4;
+  return (long)n_slots * (train > eval ? train : eval);
+}
+
+// ids: the n_active physical slot numbers to process; scratch: mt_head_scratch_floats(n_slots_total, ...) floats.
+extern "C" int mt_head_loss_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch,
+                                   int max_width, int step, float* scratch, hipStream_t stream) {
+  if (n_active <= 0) return 0;
+  const int rec = ((max_width + 7) / 8) * 8 + 8;
+  const int max_chunks = (max_batch + HL_ROWS - 1) / HL_ROWS;
+  dim3 grid(max_chunks, n_active), block(HL_THREADS);
+  if (max_width <= 512)
+    hipLaunchKernelGGL(mt_head_loss_kernel<1>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec);
+  else if (max_width <= 1024)
+    hipLaunchKernelGGL(mt_head_loss_kernel<2>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec);
+  else if (max_width <= 2048)
+    hipLaunchKernelGGL(mt_head_loss_kernel<4>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec);
   else return -2;
+  hipLaunchKernelGGL(mt_head_reduce_kernel, dim3(n_active), block, 0, stream, slots, ids, step, scratch, max_chunks, rec);
   return (int)hipGetLastError();
 }
 
-extern "C" int mt_head_eval_launch(const MtHeadSlot* slots, int n_slots, int max_width, int row0, int nrows,
-                                   hipStream_t stream) {
-  if (n_slots <= 0) return 0;
-  dim3 grid(n_slots), block(HL_THREADS);
-  if (max_width <= 512) hipLaunchKernelGGL(mt_head_eval_kernel<1>, grid, block, 0, stream, slots, row0, nrows);
-  else if (max_width <= 1024) hipLaunchKernelGGL(mt_head_eval_kernel<2>, grid, block, 0, stream, slots, row0, nrows);
-  else if (max_width <= 2048) hipLaunchKernelGGL(mt_head_eval_kernel<4>, grid, block, 0, stream, slots, row0, nrows);
+extern "C" int mt_head_eval_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_width,
+                                   int row0, int nrows, int max_rows, float* scratch, hipStream_t stream) {
+  if (n_active <= 0) return 0;
+  const int rows = nrows > 0 ? nrows : max_rows;
+  const int max_chunks = (max_rows + HL_EVAL_ROWS - 1) / HL_EVAL_ROWS;
+  dim3 grid((rows + HL_EVAL_ROWS - 1) / HL_EVAL_ROWS, n_active), block(HL_THREADS);
+  if (max_width <= 512)
+    hipLaunchKernelGGL(mt_head_eval_kernel<1>, grid, block, 0, stream, slots, ids, row0, nrows, scratch, max_chunks);
+  else if (max_width <= 1024)
+    hipLaunchKernelGGL(mt_head_eval_kernel<2>, grid, block, 0, stream, slots, ids, row0, nrows, scratch, max_chunks);
+  else if (max_width <= 2048)
+    hipLaunchKernelGGL(mt_head_eval_kernel<4>, grid, block, 0, stream, slots, ids, row0, nrows, scratch, max_chunks);
   else return -2;
+  hipLaunchKernelGGL(mt_head_eval_reduce_kernel, dim3(n_active), dim3(64), 0, stream, slots, ids, nrows, scratch,
+                     max_chunks);
   return (int)hipGetLastError();
 }

@@ -17,8 +17,9 @@
 
 __global__ __launch_bounds__(OPT_THREADS) void mt_sqnorm_kernel(const float* __restrict__ G, size_t slot_stride,
                                                                 const MtOptSlot* __restrict__ hp,
+                                                                const int32_t* __restrict__ ids,
                                                                 float* __restrict__ partials, int max_blocks, int step) {
-  const int slot = blockIdx.y;
+  const int slot = ids[blockIdx.y];
   const MtOptSlot h = hp[slot];
   float acc = 0.f;
   const int base = blockIdx.x * OPT_PER_BLOCK + threadIdx.x * 8;
@@ -52,9 +53,10 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict
                                                                float* __restrict__ M, float* __restrict__ V,
                                                                uint16_t* __restrict__ Pb, size_t slot_stride,
                                                                const MtOptSlot* __restrict__ hp,
+                                                               const int32_t* __restrict__ ids,
                                                                const float* __restrict__ partials, int max_blocks,
                                                                int step) {
-  const int slot = blockIdx.y;
+  const int slot = ids[blockIdx.y];
   const MtOptSlot h = hp[slot];
   if (step >= h.active_steps) return;
   const int base = blockIdx.x * OPT_PER_BLOCK + threadIdx.x * 8;
@@ -144,17 +146,19 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict
 }
 
 extern "C" int mt_optim_launch(float* P, const float* G, float* M, float* V, void* Pb, size_t slot_stride,
-                               const MtOptSlot* hp, int n_slots, int max_params, float* partials, int use_clip,
-                               int step, hipStream_t stream) {
+                               const MtOptSlot* hp, const int32_t* ids, int n_active, int max_params,
+                               float* partials, int max_blocks, int use_clip, int step, hipStream_t stream) {
+  const int n_slots = n_active;
   if (n_slots <= 0 || max_params <= 0) return 0;
   if (slot_stride % 8 != 0) return -2;
   const int nb = (max_params + OPT_PER_BLOCK - 1) / OPT_PER_BLOCK;
+  if (nb > max_blocks) return -4;     // partials holds max_blocks floats per physical slot
   dim3 grid(nb, n_slots), block(OPT_THREADS);
   if (use_clip) {
     if (partials == nullptr) return -3;
-    hipLaunchKernelGGL(mt_sqnorm_kernel, grid, block, 0, stream, G, slot_stride, hp, partials, nb, step);
+    hipLaunchKernelGGL(mt_sqnorm_kernel, grid, block, 0, stream, G, slot_stride, hp, ids, partials, max_blocks, step);
   }
   hipLaunchKernelGGL(mt_optim_kernel, grid, block, 0, stream, P, G, M, V, reinterpret_cast<uint16_t*>(Pb),
-                     slot_stride, hp, use_clip ? partials : nullptr, nb, step);
+                     slot_stride, hp, ids, use_clip ? partials : nullptr, max_blocks, step);
   return (int)hipGetLastError();
 }

@@ -15,17 +15,20 @@
 extern "C" {
 int mt_gemm_launch(int mode, const MtGemmGroup* groups, const MtTile* tiles, int ntiles, int step, int flags,
                    int arow0, int i_override, hipStream_t stream);
-int mt_gather_launch(const MtGatherSlot* slots, int n_slots, int max_batch, const float* X, const float* Y,
-                     uint32_t n_rows, int F, int Fpad, int hb, int step, hipStream_t stream);
-int mt_head_loss_launch(const MtHeadSlot* slots, int n_slots, int max_width, int step, hipStream_t stream);
-int mt_head_eval_launch(const MtHeadSlot* slots, int n_slots, int max_width, int row0, int nrows, hipStream_t stream);
+int mt_gather_launch(const MtGatherSlot* slots, const int32_t* ids, int n_active, int max_batch, const float* X,
+                     const float* Y, uint32_t n_rows, int F, int Fpad, int hb, int step, hipStream_t stream);
+int mt_head_loss_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch, int max_width,
+                        int step, float* scratch, hipStream_t stream);
+int mt_head_eval_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_width, int row0, int nrows,
+                        int max_rows, float* scratch, hipStream_t stream);
 int mt_optim_launch(float* P, const float* G, float* M, float* V, void* Pb, size_t slot_stride, const MtOptSlot* hp,
-                    int n_slots, int max_params, float* partials, int use_clip, int step, hipStream_t stream);
+                    const int32_t* ids, int n_active, int max_params, float* partials, int max_blocks, int use_clip,
+                    int step, hipStream_t stream);
 }
 
 struct MtMlpPlan {
   int32_t n_hidden;      // hidden (GEMM) layers; the scalar head is handled by the head kernels
-  int32_t n_slots;       // physical slots of the pack (inactive ones carry active_steps = 0)
+  int32_t n_active;      // occupied slots; active_ids lists their physical slot numbers
   int32_t max_batch, max_width, max_params;
   int32_t F, Fpad, hb;
   uint32_t n_rows;
@@ -50,7 +53,11 @@ struct MtMlpPlan {
   void* Pb;
   size_t slot_stride;
   const MtOptSlot* opt;
-  float* partials;
+  float* partials;        // max_blocks floats per physical slot (gradient sq-norm partial sums)
+  const int32_t* active_ids;
+  float* head_scratch;    // mt_head_scratch_floats(physical slots, max batch, max width) floats
+  int32_t max_blocks;
+  int32_t pad;
 };
 
 #define MT_TRY(x)            \
@@ -63,12 +70,13 @@ extern "C" int mt_mlp_train_steps(const MtMlpPlan* p, int step0, int nsteps, hip
   if (p->n_hidden < 1 || p->n_hidden > MT_MAX_LAYERS) return -10;
   const int L = p->n_hidden;
   for (int step = step0; step < step0 + nsteps; ++step) {
-    MT_TRY(mt_gather_launch(p->gather, p->n_slots, p->max_batch, p->X, p->Y, p->n_rows, p->F, p->Fpad, p->hb,
-                            step, stream));
+    MT_TRY(mt_gather_launch(p->gather, p->active_ids, p->n_active, p->max_batch, p->X, p->Y, p->n_rows, p->F,
+                            p->Fpad, p->hb, step, stream));
     for (int l = 0; l < L; ++l)
       MT_TRY(mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], step, MT_GEMM_FLAG_RELU, 0, 0,
                             stream));
-    MT_TRY(mt_head_loss_launch(p->head, p->n_slots, p->max_width, step, stream));
+    MT_TRY(mt_head_loss_launch(p->head, p->active_ids, p->n_active, p->max_batch, p->max_width, step,
+                               p->head_scratch, stream));
     for (int l = L - 1; l >= 0; --l) {
       MT_TRY(mt_gemm_launch(2, p->wgrad_groups[l], p->wgrad_tiles[l], p->wgrad_ntiles[l], step, MT_GEMM_FLAG_DBIAS,
                             0, 0, stream));
@@ -76,8 +84,8 @@ extern "C" int mt_mlp_train_steps(const MtMlpPlan* p, int step0, int nsteps, hip
         MT_TRY(mt_gemm_launch(1, p->dgrad_groups[l], p->dgrad_tiles[l], p->dgrad_ntiles[l], step, MT_GEMM_FLAG_MASK,
                               0, 0, stream));
     }
-    MT_TRY(mt_optim_launch(p->P, p->G, p->M, p->V, p->Pb, p->slot_stride, p->opt, p->n_slots, p->max_params,
-                           p->partials, p->use_clip, step, stream));
+    MT_TRY(mt_optim_launch(p->P, p->G, p->M, p->V, p->Pb, p->slot_stride, p->opt, p->active_ids, p->n_active,
+                           p->max_params, p->partials, p->max_blocks, p->use_clip, step, stream));
   }
   return 0;
 }
@@ -93,7 +101,8 @@ extern "C" int mt_mlp_eval(const MtMlpPlan* p, int n_val_rows, int chunk_rows, h
     for (int l = 0; l < L; ++l)
       MT_TRY(mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], 0, MT_GEMM_FLAG_RELU,
                             l == 0 ? r0 : 0, rows, stream));
-    MT_TRY(mt_head_eval_launch(p->head, p->n_slots, p->max_width, r0, rows, stream));
+    MT_TRY(mt_head_eval_launch(p->head, p->active_ids, p->n_active, p->max_width, r0, rows, chunk_rows,
+                               p->head_scratch, stream));
   }
   return 0;
 }

@@ -50,7 +50,7 @@ class OptSlot(C.Structure):
 
 
 class MlpPlan(C.Structure):
-    _fields_ = [("n_hidden", c_int32), ("n_slots", c_int32), ("max_batch", c_int32), ("max_width", c_int32),
+    _fields_ = [("n_hidden", c_int32), ("n_active", c_int32), ("max_batch", c_int32), ("max_width", c_int32),
                 ("max_params", c_int32), ("F", c_int32), ("Fpad", c_int32), ("hb", c_int32),
                 ("n_rows", c_uint32), ("use_clip", c_int32),
                 ("X", c_void_p), ("Y", c_void_p), ("gather", c_void_p),
@@ -60,7 +60,8 @@ class MlpPlan(C.Structure):
                 ("fwd_ntiles", c_int32 * MT_MAX_LAYERS), ("dgrad_ntiles", c_int32 * MT_MAX_LAYERS),
                 ("wgrad_ntiles", c_int32 * MT_MAX_LAYERS),
                 ("head", c_void_p), ("P", c_void_p), ("G", c_void_p), ("M", c_void_p), ("V", c_void_p),
-                ("Pb", c_void_p), ("slot_stride", c_size_t), ("opt", c_void_p), ("partials", c_void_p)]
+                ("Pb", c_void_p), ("slot_stride", c_size_t), ("opt", c_void_p), ("partials", c_void_p),
+                ("active_ids", c_void_p), ("head_scratch", c_void_p), ("max_blocks", c_int32), ("pad", c_int32)]
 
 
 # numpy views of the same layouts, for building whole descriptor tables vectorised
@@ -117,12 +118,15 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         raise KernelLibraryError(f"numpy descriptor dtypes {np_sizes} do not match ctypes {expect[:5]}")
 
     lib.mt_gemm_launch.argtypes = [C.c_int, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]
-    lib.mt_gather_launch.argtypes = [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p, c_uint32, C.c_int, C.c_int,
-                                     C.c_int, C.c_int, c_void_p]
-    lib.mt_head_loss_launch.argtypes = [c_void_p, C.c_int, C.c_int, C.c_int, c_void_p]
-    lib.mt_head_eval_launch.argtypes = [c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]
-    lib.mt_optim_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, C.c_int,
-                                    C.c_int, c_void_p, C.c_int, C.c_int, c_void_p]
+    lib.mt_gather_launch.argtypes = [c_void_p, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p, c_uint32, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_head_loss_launch.argtypes = [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p, c_void_p]
+    lib.mt_head_eval_launch.argtypes = [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p,
+                                        c_void_p]
+    lib.mt_optim_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p,
+                                    C.c_int, C.c_int, c_void_p, C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_head_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.mt_head_scratch_floats.restype = C.c_long
     lib.mt_mlp_train_steps.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]
     lib.mt_mlp_eval.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]
     for fn in (lib.mt_gemm_launch, lib.mt_gather_launch, lib.mt_head_loss_launch, lib.mt_head_eval_launch,

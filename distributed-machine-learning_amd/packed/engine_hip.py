@@ -153,8 +153,10 @@ class HipPackEngine(PackEngine):
         self.ybuf = torch.zeros(T * self.rows_max, device=dev, dtype=torch.float32)
         self.loss_acc = torch.zeros(T, device=dev, dtype=torch.float32)
         self.metrics = torch.zeros(T, 3, device=dev, dtype=torch.float64)
-        nb = (self.stride + 2047) // 2048
-        self.partials = torch.zeros(T * nb, device=dev, dtype=torch.float32)
+        self.max_blocks = (self.stride + 2047) // 2048
+        self.partials = torch.zeros(T * self.max_blocks, device=dev, dtype=torch.float32)
+        self.head_scratch = torch.zeros(int(self.lib.mt_head_scratch_floats(T, self.rows_max, self.max_width)),
+                                        device=dev, dtype=torch.float32)
         self.slots: Dict[int, _HSlot] = {}
         self._tables: Dict[str, Any] = {}
         self._dirty = True
@@ -316,7 +318,10 @@ class HipPackEngine(PackEngine):
         T = self.capacity
         gt = self._build_gemm_tables(eval_mode)
         plan = L.MlpPlan()
-        plan.n_hidden, plan.n_slots = gt["n_hidden"], T
+        ids = np.array(sorted(self.slots), dtype=np.int32)
+        plan.n_hidden, plan.n_active = gt["n_hidden"], len(ids)
+        plan.active_ids = self._upload("eids" if eval_mode else "tids", ids)
+        plan.head_scratch, plan.max_blocks = self.head_scratch.data_ptr(), self.max_blocks
         plan.max_batch = max(s.spec.batch_size for s in self.slots.values())
         plan.max_width = max(max(s.spec.hidden_sizes) for s in self.slots.values())
         plan.max_params = max(s.layout.total for s in self.slots.values())

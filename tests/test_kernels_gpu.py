@@ -153,9 +153,10 @@ def test_gather_matches_numpy_permutation(lib):
         slots[s] = (x0.data_ptr(), y.data_ptr(), keys, B - 8 * s, 50)
         outs.append((x0, y, keys))
     st = _up(slots)
+    ids = torch.arange(3, dtype=torch.int32, device="cuda")
     step = 7
-    L.check(so.mt_gather_launch(st.data_ptr(), 3, B, X.data_ptr(), Y.data_ptr(), n, F, Fpad, half_bits(n), step,
-                                _stream()), "gather")
+    L.check(so.mt_gather_launch(st.data_ptr(), ids.data_ptr(), 3, B, X.data_ptr(), Y.data_ptr(), n, F, Fpad,
+                                half_bits(n), step, _stream()), "gather")
     torch.cuda.synchronize()
     for s, (x0, y, keys) in enumerate(outs):
         b = B - 8 * s
@@ -185,8 +186,12 @@ def test_head_loss(lib, loss, code):
                     y.data_ptr(), acc.data_ptr(), met.data_ptr(), B, W, ld, code, 1, 0)
         keep.append((H, dH, w, b, gw, gb, y, acc, met))
     st = _up(slots)
-    L.check(so.mt_head_loss_launch(st.data_ptr(), len(cfgs), 512, 0, _stream()), "head_loss")
-    L.check(so.mt_head_eval_launch(st.data_ptr(), len(cfgs), 512, 0, 0, _stream()), "head_eval")
+    ids = torch.arange(len(cfgs), dtype=torch.int32, device="cuda")
+    scratch = torch.zeros(int(so.mt_head_scratch_floats(len(cfgs), 256, 512)), device="cuda")
+    L.check(so.mt_head_loss_launch(st.data_ptr(), ids.data_ptr(), len(cfgs), 256, 512, 0, scratch.data_ptr(), _stream()),
+            "head_loss")
+    L.check(so.mt_head_eval_launch(st.data_ptr(), ids.data_ptr(), len(cfgs), 512, 0, 0, 256, scratch.data_ptr(),
+                                   _stream()), "head_eval")
     torch.cuda.synchronize()
     for (B, W), (H, dH, w, b, gw, gb, y, acc, met) in zip(cfgs, keep):
         h = H[:, :W].float().requires_grad_(True)
@@ -226,6 +231,7 @@ def test_fused_optimizer_matches_torch(lib, name, code, clip):
     nb = (max(sizes) + 2047) // 2048
     partials = torch.zeros(T * nb, device="cuda")
     ht = _up(hp)
+    ids = torch.arange(T, dtype=torch.int32, device="cuda")
     for step in range(5):
         for s, n in enumerate(sizes):
             gr = torch.randn(n, device="cuda", generator=g)
@@ -236,7 +242,8 @@ def test_fused_optimizer_matches_torch(lib, name, code, clip):
                 torch.nn.utils.clip_grad_norm_([pr], clip)
             opt.step()
         L.check(so.mt_optim_launch(P.data_ptr(), G.data_ptr(), M.data_ptr(), V.data_ptr(), Pb.data_ptr(), stride,
-                                   ht.data_ptr(), T, max(sizes), partials.data_ptr(), int(clip > 0), step, _stream()),
+                                   ht.data_ptr(), ids.data_ptr(), T, max(sizes), partials.data_ptr(), nb, int(clip > 0),
+                                   step, _stream()),
                 "optim")
     torch.cuda.synchronize()
     for s, n in enumerate(sizes):
