@@ -1,0 +1,64 @@
+"""Short-sequence attention: one fused HIP kernel per direction on a GPU, plain PyTorch elsewhere.
+
+The reference's sequences are 50 or 96 tokens long
+(/root/reference/ray-tune-hpo-regression-sample.py:28, /root/reference/ray-tune-hpo-regression.py:446), so a
+whole (batch, head) problem -- Q, K, V and the S x S score tile -- fits in one workgroup's LDS and
+registers: no flash-style streaming or online softmax is needed.  Two score functions share the
+kernels:
+
+* ``"softmax"``: ``P = softmax(Q K^T / sqrt(dk))``                      (``nn.MultiheadAttention`` semantics)
+* ``"relu"``   : ``A = relu(Q K^T / sqrt(dk)); P = A / (rowsum(A) + eps)``  (the reference's softmax-free
+  "LinearAttention", :113-117, with a row normalisation so the output scale does not grow with S).
+
+``short_attention`` is differentiable.  On a GPU, shapes inside the kernel envelope (S <= 128, head
+dims <= 64 and multiples of 8) run ``ops/csrc/attention.hip`` (bf16 MFMA, f32 softmax and
+accumulation); anything else -- and every CPU call -- runs ``attention_reference``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+RELU_EPS = 1e-6
+MAX_SEQ = 128
+MAX_HEAD_DIM = 64
+
+
+def attention_reference(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kind: str = "softmax",
+                        keep_mask: Optional[torch.Tensor] = None, dropout_p: float = 0.0) -> torch.Tensor:
+    """q, k: [..., S, dk]; v: [..., S, dv]; ``keep_mask`` ([..., S, S], 0/1) applies attention dropout."""
+    s = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(q.shape[-1]))
+    if kind == "softmax":
+        p = torch.softmax(s, dim=-1)
+    elif kind == "relu":
+        a = torch.relu(s)
+        p = a / (a.sum(-1, keepdim=True) + RELU_EPS)
+    else:
+        raise ValueError(f"kind must be 'softmax' or 'relu', got {kind!r}")
+    if keep_mask is not None:
+        p = p * keep_mask.to(p.dtype) * (1.0 / (1.0 - dropout_p))
+    return p @ v
+
+
+def _hip_ok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bool:
+    if not q.is_cuda or q.dim() != 4:
+        return False
+    s, dk, dv = q.shape[-2], q.shape[-1], v.shape[-1]
+    return (s <= MAX_SEQ and dk <= MAX_HEAD_DIM and dv <= MAX_HEAD_DIM and dk % 8 == 0 and dv % 8 == 0
+            and k.shape[-2] == s and v.shape[-2] == s)
+
+
+def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kind: str = "softmax",
+                    dropout_p: float = 0.0) -> torch.Tensor:
+    """Self-attention over short sequences, [B, h, S, d] in and out."""
+    keep = None
+    if dropout_p > 0.0:
+        shape = q.shape[:-1] + (k.shape[-2],)
+        keep = torch.bernoulli(torch.full(shape, 1.0 - dropout_p, device=q.device, dtype=torch.float32))
+    if _hip_ok(q, k, v):
+        from .attention_hip import FusedShortAttention, available
+        if available():
+            return FusedShortAttention.apply(q, k, v, kind, keep, dropout_p)
+    return attention_reference(q, k, v, kind, keep, dropout_p)

@@ -12,7 +12,7 @@ def __getattr__(name):
     # run()/with_parameters() import the scheduler and search packages, which import this
     # package for Trial/space: resolve them lazily to keep the import graph acyclic.
     if name in ("run", "with_parameters", "TuneError", "ProgressReporter"):
-        from . import run as _run
+        from . import api as _run
         return getattr(_run, name)
     if name in ("schedulers", "search", "suggest"):
         import importlib

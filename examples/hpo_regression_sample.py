@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""The sample HPO workflow: 10 random-search trials of a small Transformer regressor under ASHA.
+
+Counterpart of /root/reference/ray-tune-hpo-regression-sample.py:152-172 with the imports switched from
+``ray.tune`` to ``mitune.tune``; no cluster runtime, no hard-coded home directory.
+
+    python examples/hpo_regression_sample.py [--num-samples 10] [--local-dir ./mitune_results] [--epochs 5]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from mitune import tune                                     # noqa: E402
+from mitune.data import create_dummy_data                   # noqa: E402
+from mitune.schedulers import ASHAScheduler                 # noqa: E402
+from mitune.train.functions import train_dummy_model        # noqa: E402
+from mitune.utils.logging import setup_logging              # noqa: E402
+from search_spaces import SAMPLE_SPACE                      # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num-samples", type=int, default=10)
+    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--local-dir", default="./mitune_results")
+    ap.add_argument("--noise-target", action="store_true", help="target independent of the inputs, like the reference")
+    args = ap.parse_args()
+    logger = setup_logging(args.local_dir, prefix="mitune_workflow_sample_run")
+    logger.info("Starting the mitune workflow...")
+    train_loader, val_loader = create_dummy_data(learnable=not args.noise_target)
+    analysis = tune.run(
+        tune.with_parameters(train_dummy_model, data_loader=train_loader, val_loader=val_loader, epochs=args.epochs),
+        config=SAMPLE_SPACE,
+        num_samples=args.num_samples,
+        scheduler=ASHAScheduler(metric="validation_loss", mode="min"),
+        resources_per_trial={"cpu": 2, "gpu": 1},
+        local_dir=args.local_dir,
+        verbose=1,
+    )
+    best_config = analysis.best_config
+    logger.info("Best hyperparameters found: \n %s", best_config)
+    print("Best hyperparameters found: \n", best_config)
+    print("Best validation_loss:", analysis.best_result["validation_loss"])
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,6 @@ __version__ = "0.1.0"
 from .tune.space import (choice, uniform, loguniform, quniform, qloguniform, randn, randint,     # noqa: E402,F401
                          lograndint, sample_from, grid_search)
 from .tune.session import report, get_checkpoint, get_trial_id, get_trial_dir          # noqa: E402,F401
-from .tune.run import run, with_parameters, TuneError                                   # noqa: E402,F401
+from .tune.api import run, with_parameters, TuneError                                   # noqa: E402,F401
 from .tune.analysis import ExperimentAnalysis                                            # noqa: E402,F401
 from . import tune, schedulers, search                                                   # noqa: E402,F401
