@@ -119,10 +119,10 @@ class TorchDistComm(Comm):
         return t if t.device == self.device else t.to(self.device)
 
     def all_gather(self, t):
-        src = self._dev(t.contiguous())
-        out = torch.empty((self.world_size,) + tuple(src.shape), dtype=src.dtype, device=src.device)
-        self.dist.all_gather_into_tensor(out, src)
-        return out.to(t.device)
+        src = self._dev(t.contiguous()).reshape(-1)
+        out = torch.empty(self.world_size * src.numel(), dtype=src.dtype, device=src.device)
+        self.dist.all_gather_into_tensor(out, src)       # one collective, ranks concatenated along dim 0
+        return out.reshape((self.world_size,) + tuple(t.shape)).to(t.device)
 
     def all_reduce(self, t, op="sum", async_op=False):
         assert t.device == self.device or self.backend != "nccl", "all_reduce tensor must live on the comm device"

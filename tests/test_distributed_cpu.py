@@ -1,0 +1,112 @@
+"""Replicated-scheduler logic over real collectives: in-process ranks (threads) and gloo processes."""
+import json
+import os
+import socket
+import threading
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import mitune
+from mitune import tune
+from mitune.packed import PackedExecutor, PackedTrainable
+from mitune.parallel.comm import LocalComm, ThreadComm
+from mitune.schedulers import ASHAScheduler, PopulationBasedTraining
+
+
+def _data(n=1500, f=6, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(n, f, generator=g)
+    y = torch.tanh(X[:, 0] - X[:, 1]) + 0.3 * X[:, 2] + 0.05 * torch.randn(n, generator=g)
+    k = int(0.8 * n)
+    return (X[:k], y[:k]), (X[k:], y[k:])
+
+
+SPACE = {"width": tune.choice([8, 16, 32]), "num_layers": tune.choice([1, 2]),
+         "learning_rate": tune.loguniform(1e-3, 3e-2), "batch_size": tune.choice([64, 128])}
+
+
+def _search(comm, num_samples=12, capacity=6, scheduler=None, epochs=4, seed=0):
+    train, val = _data()
+    tr = PackedTrainable(train=train, val=val, max_epochs=epochs, engine="torch", capacity=capacity)
+    ex = PackedExecutor(tr, comm=comm, device=torch.device("cpu"), capacity=capacity, seed=seed)
+    sched = scheduler or ASHAScheduler(metric="validation_loss", mode="min", max_t=epochs, reduction_factor=2)
+    an = mitune.run(tr, config=SPACE, num_samples=num_samples, scheduler=sched, executor=ex, seed=seed, verbose=0)
+    return {t.trial_id: (t.training_iteration, round(t.last_result["validation_loss"], 6), t.placement["rank"])
+            for t in an.trials}, an
+
+
+def _run_ranks(world, fn):
+    comms = ThreadComm.make(world)
+    out, errs = [None] * world, []
+
+    def body(r):
+        try:
+            out[r] = fn(comms[r])
+        except BaseException as e:       # noqa: BLE001
+            errs.append(e)
+            try:
+                comms[r].hub.barrier.abort()
+            except Exception:
+                pass
+
+    ths = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]
+    [t.join(timeout=300) for t in ths]
+    if errs:
+        raise errs[0]
+    return out
+
+
+def test_all_ranks_reach_identical_asha_decisions_and_match_single_rank():
+    single, _ = _search(LocalComm(), capacity=12)
+    ranks = _run_ranks(3, lambda c: _search(c, capacity=4)[0])
+    assert ranks[0] == ranks[1] == ranks[2]
+    # which rank trained a trial must not change its trajectory or its fate
+    assert {k: v[:2] for k, v in ranks[0].items()} == {k: v[:2] for k, v in single.items()}
+    assert {v[2] for v in ranks[0].values()} == {0, 1, 2}
+    assert any(v[0] < 4 for v in single.values()) and any(v[0] == 4 for v in single.values())
+
+
+def test_slots_freed_by_early_stopping_are_refilled():
+    res, an = _search(LocalComm(), num_samples=20, capacity=4, epochs=4)
+    assert len(res) == 20 and an.stats["epochs"] > 4          # more rounds than one cohort needs
+    assert an.stats["slot_epochs"] < 20 * 4                   # ASHA saved work
+
+
+def test_pbt_exploit_moves_weights_between_ranks():
+    def fn(comm):
+        pbt = PopulationBasedTraining(metric="validation_loss", mode="min", perturbation_interval=2,
+                                      hyperparam_mutations={"learning_rate": tune.loguniform(1e-3, 3e-2)},
+                                      quantile_fraction=0.25, seed=1)
+        res, an = _search(comm, num_samples=8, capacity=4, scheduler=pbt, epochs=6)
+        return res, an.stats["exploits"], {t.trial_id: t.config["learning_rate"] for t in an.trials}
+
+    (r0, e0, c0), (r1, e1, c1) = _run_ranks(2, fn)
+    assert r0 == r1 and c0 == c1 and e0 == e1 and e0 >= 1
+    assert all(v[0] == 6 for v in r0.values())                # PBT never stops a trial early
+
+
+def _gloo_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from mitune.parallel.comm import TorchDistComm
+    comm = TorchDistComm(backend="gloo", rank=rank, world_size=world)
+    res, an = _search(comm, num_samples=8, capacity=4)
+    t = torch.tensor([float(rank + 1)])
+    comm.all_reduce(t)
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump({"res": res, "sum": t.item(), "comm_s": an.stats["comm_s"]}, f)
+    comm.close()
+
+
+def test_gloo_two_process_search_agrees(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = json.load(open(tmp_path / "rank0.json"))
+    b = json.load(open(tmp_path / "rank1.json"))
+    assert a["res"] == b["res"] and a["sum"] == 3.0
+    single, _ = _search(LocalComm(), num_samples=8, capacity=8)
+    assert {k: v[:2] for k, v in a["res"].items()} == {k: list(v[:2]) for k, v in single.items()}
