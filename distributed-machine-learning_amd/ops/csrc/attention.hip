@@ -1,0 +1,369 @@
+// Fused short-sequence self-attention, forward and backward (gfx950, bf16 MFMA, f32 softmax/accumulate).
+//
+// One workgroup (4 waves) owns one (batch, head): Q, K, V (and dO in backward) are staged once into LDS
+// as [row][64] bf16 images; the whole S x S score tile lives in registers.  S <= 128, head dims <= 64.
+//
+// Register-level dataflow (no LDS round trip for the probabilities in forward):
+//   * scores are computed TRANSPOSED, S^T[key][query] = K . Q^T, with v_mfma_f32_16x16x32_bf16.  In the
+//     accumulator layout a lane then holds, for ONE query (lane & 15), four consecutive keys per 16-key
+//     block -- so the row-wise softmax is a register reduction plus two lane shuffles (xor 16, 32);
+//   * those same registers, packed to bf16, are directly the A operand of O = P . V: the contraction
+//     index (key) may be enumerated in any order as long as both operands agree, so V's B fragment is
+//     fetched with ds_read_b64_tr_b16 from exactly the key rows the P registers hold
+//     (32*step + 4*g + {0..3} and 32*step + 16 + 4*g + {0..3} for lane group g).
+// Backward recomputes P from Q, K and the saved row statistic (log-sum-exp, or the ReLU row sum),
+// forms dP^T = V . dO^T in the same layout, reduces delta = rowsum(dP * P) in registers, turns both into
+// dS^T, gets dQ^T = K^T . dS with the same register trick, and only then writes P^T and dS^T (bf16) to LDS
+// for the two products that contract over queries: dV = P^T . dO and dK = dS^T . Q.
+//
+// kind 0: softmax(QK^T * scale); kind 1: relu(QK^T * scale) / (rowsum + eps).
+// keep: optional uint8 [BH][S][S] attention-dropout mask (1 = keep), applied with scale 1/(1-p).
+#include "mt_common.h"
+
+#define AT_THREADS 256
+#define AT_PITCH_CH 8          // 16-byte chunks per row of a [row][64] image
+#define AT_IMG_BYTES (128 * 128)
+#define AT_RELU_EPS 1e-6f
+
+typedef __attribute__((address_space(3))) uint8_t at_lds_u8;
+typedef __attribute__((ext_vector_type(8))) short at_s16x8;
+
+__device__ __forceinline__ int img_off(int row, int chunk, int cpr) {
+  return row * cpr * 16 + ((chunk ^ (row & (cpr - 1))) << 4);
+}
+
+// global [rows][cols] bf16 (row stride ld elements) -> zero-padded LDS image [rows_pad][64]
+__device__ __forceinline__ void stage_image(uint8_t* lds, const uint16_t* __restrict__ src, int rows, int cols, int ld,
+                                            int rows_pad, int tid) {
+  for (int q = tid; q < rows_pad * AT_PITCH_CH; q += AT_THREADS) {
+    const int r = q >> 3, c = q & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r < rows && c * 8 < cols) v = *reinterpret_cast<const u32x4*>(src + (size_t)r * ld + c * 8);
+    *reinterpret_cast<u32x4*>(lds + img_off(r, c, AT_PITCH_CH)) = v;
+  }
+}
+
+// rows = M or N index (16 of them from row0), contraction contiguous: one ds_read_b128
+__device__ __forceinline__ bf16x8 frag_rows(const uint8_t* lds, int row0, int ks, int lane, int cpr) {
+  const int row = row0 + (lane & 15);
+  const int chunk = ks * 4 + (lane >> 4);
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + img_off(row, chunk, cpr)));
+}
+
+// contraction index = image ROW, M/N index = image column (16 of them from col0): two transposed reads.
+// The lane group g = lane >> 4 takes contraction rows rbase_lo + {0..3} and rbase_hi + {0..3}.
+__device__ __forceinline__ bf16x8 frag_cols(const uint8_t* lds, int col0, int rbase_lo, int rbase_hi, int lane, int cpr) {
+  const int i = lane & 15, q = i >> 2, p = i & 3;
+  const int c0 = (col0 >> 3) + (p >> 1);
+  const at_lds_u8* a0 = (const at_lds_u8*)(lds + img_off(rbase_lo + q, c0, cpr) + 8 * (p & 1));
+  const at_lds_u8* a1 = (const at_lds_u8*)(lds + img_off(rbase_hi + q, c0, cpr) + 8 * (p & 1));
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+  at_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
+  u32x4 v = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ float group_sum(float v) {   // across the 4 lane groups holding one query
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float group_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+// Scores for 16 queries (block qb) against all keys, transposed: acc[kb][j] = S[query][key = 16kb + 4g + j].
+template <int NKB>
+__device__ __forceinline__ void scores_T(f32x4 (&acc)[NKB], const uint8_t* ldsK, const uint8_t* ldsQ, int qb, int dsteps,
+                                         int lane) {
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) acc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < dsteps; ++ks) {
+    const bf16x8 qf = frag_rows(ldsQ, qb * 16, ks, lane, AT_PITCH_CH);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const bf16x8 kf = frag_rows(ldsK, kb * 16, ks, lane, AT_PITCH_CH);
+      acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, acc[kb], 0, 0, 0);
+    }
+  }
+}
+
+template <int NKB>   // NKB = padded sequence length / 16 (2, 4, 6 or 8)
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const uint16_t* __restrict__ Q,
+                                                                 const uint16_t* __restrict__ K,
+                                                                 const uint16_t* __restrict__ V,
+                                                                 const uint8_t* __restrict__ keep,
+                                                                 uint16_t* __restrict__ O, float* __restrict__ stat,
+                                                                 int S, int dk, int dv, float scale, float keep_scale,
+                                                                 int kind) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * AT_IMG_BYTES];
+  uint8_t *ldsQ = lds, *ldsK = lds + AT_IMG_BYTES, *ldsV = lds + 2 * AT_IMG_BYTES;
+  const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, fr = lane & 15;
+  constexpr int SP = NKB * 16;
+  stage_image(ldsQ, Q + (size_t)bh * S * dk, S, dk, dk, SP, tid);
+  stage_image(ldsK, K + (size_t)bh * S * dk, S, dk, dk, SP, tid);
+  stage_image(ldsV, V + (size_t)bh * S * dv, S, dv, dv, SP, tid);
+  __syncthreads();
+  const int dsteps = (dk + 31) / 32, nvb = (dv + 15) / 16;
+
+  for (int qb = wave; qb < NKB; qb += 4) {
+    f32x4 acc[NKB];
+    scores_T<NKB>(acc, ldsK, ldsQ, qb, dsteps, lane);
+    const int query = qb * 16 + fr;
+    float norm;
+    if (kind == 0) {
+      float m = -3.0e38f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = kb * 16 + g * 4 + j;
+          acc[kb][j] = (key < S) ? acc[kb][j] * scale : -3.0e38f;
+          m = fmaxf(m, acc[kb][j]);
+        }
+      m = group_max(m);
+      float l = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p = (kb * 16 + g * 4 + j < S) ? __expf(acc[kb][j] - m) : 0.f;
+          acc[kb][j] = p;
+          l += p;
+        }
+      l = group_sum(l);
+      norm = 1.f / l;
+      if (g == 0 && query < S) stat[(size_t)bh * S + query] = m + __logf(l);
+    } else {
+      float z = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = fmaxf(acc[kb][j] * scale, 0.f);     // padded keys have zero K rows -> a = 0
+          acc[kb][j] = a;
+          z += a;
+        }
+      z = group_sum(z) + AT_RELU_EPS;
+      norm = 1.f / z;
+      if (g == 0 && query < S) stat[(size_t)bh * S + query] = z;
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      uint32_t kw = 0x01010101u;
+      if (keep != nullptr && query < S) {
+        const int key0 = kb * 16 + g * 4;
+        const uint8_t* kp = keep + ((size_t)bh * S + query) * S + key0;
+        kw = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (key0 + j < S) kw |= (uint32_t)kp[j] << (8 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float mk = ((kw >> (8 * j)) & 0xFFu) ? keep_scale : 0.f;
+        acc[kb][j] *= norm * (keep != nullptr ? mk : 1.f);
+      }
+    }
+    // O = P . V with P straight from the accumulators
+    for (int nb = 0; nb < nvb; ++nb) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < NKB / 2; ++s2) {
+        const bf16x8 pf = pack_frag(acc[2 * s2], acc[2 * s2 + 1]);
+        const bf16x8 vf = frag_cols(ldsV, nb * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, lane, AT_PITCH_CH);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o, 0, 0, 0);
+      }
+      const int n = nb * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int qrow = qb * 16 + g * 4 + j;
+        if (qrow < S && n < dv) O[((size_t)bh * S + qrow) * dv + n] = (uint16_t)f32_to_bf16_bits(o[j]);
+      }
+    }
+  }
+}
+
+template <int NKB>
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const uint16_t* __restrict__ Q,
+                                                                 const uint16_t* __restrict__ K,
+                                                                 const uint16_t* __restrict__ V,
+                                                                 const uint16_t* __restrict__ dO,
+                                                                 const uint8_t* __restrict__ keep,
+                                                                 const float* __restrict__ stat, float* __restrict__ dQ,
+                                                                 float* __restrict__ dK, float* __restrict__ dV, int S,
+                                                                 int dk, int dv, float scale, float keep_scale,
+                                                                 int kind) {
+  constexpr int SP = NKB * 16;
+  constexpr int PCH = (SP <= 64) ? 8 : 16;        // chunks per row of the [key][query] images
+  constexpr int PT_BYTES = SP * PCH * 16;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * AT_IMG_BYTES + 2 * PT_BYTES];
+  uint8_t *ldsQ = lds, *ldsK = lds + AT_IMG_BYTES, *ldsV = lds + 2 * AT_IMG_BYTES, *ldsdO = lds + 3 * AT_IMG_BYTES;
+  uint8_t *ldsPT = lds + 4 * AT_IMG_BYTES, *ldsST = ldsPT + PT_BYTES;
+  const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, fr = lane & 15;
+  stage_image(ldsQ, Q + (size_t)bh * S * dk, S, dk, dk, SP, tid);
+  stage_image(ldsK, K + (size_t)bh * S * dk, S, dk, dk, SP, tid);
+  stage_image(ldsV, V + (size_t)bh * S * dv, S, dv, dv, SP, tid);
+  stage_image(ldsdO, dO + (size_t)bh * S * dv, S, dv, dv, SP, tid);
+  __syncthreads();
+  const int dsteps = (dk + 31) / 32, vsteps = (dv + 31) / 32, nkd = (dk + 15) / 16, nvb = (dv + 15) / 16;
+
+  // ---------------------------------------------------------------- query-parallel phase
+  for (int qb = wave; qb < NKB; qb += 4) {
+    f32x4 p[NKB], dp[NKB];
+    scores_T<NKB>(p, ldsK, ldsQ, qb, dsteps, lane);
+    scores_T<NKB>(dp, ldsV, ldsdO, qb, vsteps, lane);     // dP^T[key][query] = V . dO^T, same layout
+    const int query = qb * 16 + fr;
+    const float st = (query < S) ? stat[(size_t)bh * S + query] : 1.f;
+    const float inv_z = (kind == 1) ? 1.f / st : 0.f;
+    float delta = 0.f;
+    uint32_t relu_pos = 0u;       // bit (kb*4 + j): pre-activation > 0 (kind 1)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      uint32_t kw = 0x01010101u;
+      if (keep != nullptr && query < S) {
+        const int key0 = kb * 16 + g * 4;
+        const uint8_t* kp = keep + ((size_t)bh * S + query) * S + key0;
+        kw = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (key0 + j < S) kw |= (uint32_t)kp[j] << (8 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kb * 16 + g * 4 + j;
+        const float s = p[kb][j] * scale;
+        float pv;
+        if (kind == 0) pv = (key < S && query < S) ? __expf(s - st) : 0.f;
+        else { pv = fmaxf(s, 0.f) * inv_z; if (s > 0.f) relu_pos |= 1u << (kb * 4 + j); }
+        const float mk = (keep != nullptr) ? (((kw >> (8 * j)) & 0xFFu) ? keep_scale : 0.f) : 1.f;
+        const float dpe = dp[kb][j] * mk;      // gradient w.r.t. the un-dropped probability
+        delta += dpe * pv;
+        p[kb][j] = pv;
+        dp[kb][j] = dpe;
+        // P^T with dropout applied feeds dV
+        *reinterpret_cast<uint16_t*>(ldsPT + img_off(key, query >> 3, PCH) + (query & 7) * 2) =
+            (uint16_t)f32_to_bf16_bits(pv * mk);
+      }
+    }
+    delta = group_sum(delta);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kb * 16 + g * 4 + j;
+        float ds;
+        if (kind == 0) ds = p[kb][j] * (dp[kb][j] - delta) * scale;
+        else ds = ((relu_pos >> (kb * 4 + j)) & 1u) ? (dp[kb][j] - delta) * inv_z * scale : 0.f;
+        if (query >= S) ds = 0.f;
+        dp[kb][j] = ds;
+        *reinterpret_cast<uint16_t*>(ldsST + img_off(key, query >> 3, PCH) + (query & 7) * 2) =
+            (uint16_t)f32_to_bf16_bits(ds);
+      }
+    // dQ^T[d][query] = sum_key K[key][d] * dS[query][key]   (dS registers are the B operand)
+    for (int db = 0; db < nkd; ++db) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < NKB / 2; ++s2) {
+        const bf16x8 kf = frag_cols(ldsK, db * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, lane, AT_PITCH_CH);
+        const bf16x8 sf = pack_frag(dp[2 * s2], dp[2 * s2 + 1]);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, a, 0, 0, 0);
+      }
+      // a[j] = dQ[query = qb*16 + fr][d = db*16 + 4g + j]
+      if (query < S) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int d = db * 16 + g * 4 + j;
+          if (d < dk) dQ[((size_t)bh * S + query) * dk + d] = a[j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- key-parallel phase
+  for (int kb = wave; kb < NKB; kb += 4) {
+    for (int nb = 0; nb < nvb; ++nb) {       // dV[key][n] = sum_query P^T[key][query] dO[query][n]
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < NKB / 2; ++s2) {
+        const bf16x8 pf = frag_rows(ldsPT, kb * 16, s2, lane, PCH);
+        const bf16x8 of = frag_cols(ldsdO, nb * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, lane, AT_PITCH_CH);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, of, a, 0, 0, 0);
+      }
+      const int n = nb * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kb * 16 + g * 4 + j;
+        if (key < S && n < dv) dV[((size_t)bh * S + key) * dv + n] = a[j];
+      }
+    }
+    for (int db = 0; db < nkd; ++db) {       // dK[key][d] = sum_query dS^T[key][query] Q[query][d]
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < NKB / 2; ++s2) {
+        const bf16x8 sf = frag_rows(ldsST, kb * 16, s2, lane, PCH);
+        const bf16x8 qf = frag_cols(ldsQ, db * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, lane, AT_PITCH_CH);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, qf, a, 0, 0, 0);
+      }
+      const int d = db * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kb * 16 + g * 4 + j;
+        if (key < S && d < dk) dK[((size_t)bh * S + key) * dk + d] = a[j];
+      }
+    }
+  }
+}
+
+static int nkb_for(int S) { return ((S + 31) / 32) * 2; }   // pad the sequence to a multiple of 32
+
+extern "C" int mt_attn_fwd_launch(const void* Q, const void* K, const void* V, const void* keep, void* O, float* stat,
+                                  int BH, int S, int dk, int dv, float scale, float keep_scale, int kind,
+                                  hipStream_t stream) {
+  if (BH <= 0) return 0;
+  if (S < 1 || S > 128 || dk > 64 || dv > 64 || (dk & 7) || (dv & 7)) return -2;
+  dim3 grid(BH), block(AT_THREADS);
+#define AT_FWD(N)                                                                                              \
+  hipLaunchKernelGGL(mt_attn_fwd_kernel<N>, grid, block, 0, stream, (const uint16_t*)Q, (const uint16_t*)K,    \
+                     (const uint16_t*)V, (const uint8_t*)keep, (uint16_t*)O, stat, S, dk, dv, scale, keep_scale, kind)
+  switch (nkb_for(S)) {
+    case 2: AT_FWD(2); break;
+    case 4: AT_FWD(4); break;
+    case 6: AT_FWD(6); break;
+    case 8: AT_FWD(8); break;
+    default: return -3;
+  }
+#undef AT_FWD
+  return (int)hipGetLastError();
+}
+
+extern "C" int mt_attn_bwd_launch(const void* Q, const void* K, const void* V, const void* dO, const void* keep,
+                                  const float* stat, float* dQ, float* dK, float* dV, int BH, int S, int dk, int dv,
+                                  float scale, float keep_scale, int kind, hipStream_t stream) {
+  if (BH <= 0) return 0;
+  if (S < 1 || S > 128 || dk > 64 || dv > 64 || (dk & 7) || (dv & 7)) return -2;
+  dim3 grid(BH), block(AT_THREADS);
+#define AT_BWD(N)                                                                                              \
+  hipLaunchKernelGGL(mt_attn_bwd_kernel<N>, grid, block, 0, stream, (const uint16_t*)Q, (const uint16_t*)K,    \
+                     (const uint16_t*)V, (const uint16_t*)dO, (const uint8_t*)keep, stat, dQ, dK, dV, S, dk, dv, \
+                     scale, keep_scale, kind)
+  switch (nkb_for(S)) {
+    case 2: AT_BWD(2); break;
+    case 4: AT_BWD(4); break;
+    case 6: AT_BWD(6); break;
+    case 8: AT_BWD(8); break;
+    default: return -3;
+  }
+#undef AT_BWD
+  return (int)hipGetLastError();
+}

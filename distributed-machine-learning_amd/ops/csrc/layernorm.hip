@@ -1,0 +1,174 @@
+// Fused dropout + residual add + LayerNorm, forward and backward (gfx950, f32 rows, one wave per row).
+//
+//   forward : z = residual + x * keep * keep_scale;  y = (z - mean(z)) * rstd(z) * w + b
+//             writes y, z and the per-row {mean, rstd}
+//   backward: dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w,  xhat = (z - mean) * rstd
+//             writes dres = dz, dx = dz * keep * keep_scale and per-block partial sums of
+//             dw = sum_rows dy * xhat, db = sum_rows dy (summed over blocks by the caller, fixed order).
+// A row (d <= 2048, d % 4 == 0) is held in registers as up to 8 float4 per lane: one global read of
+// each input, one write of each output, wave-shuffle reductions, no LDS in forward.
+#include "mt_common.h"
+
+#define LN_THREADS 256
+#define LN_MAXV 8           // float4 per lane: 64 lanes * 4 * 8 = 2048 columns
+#define LN_ROWS_PER_WAVE 8  // backward: rows per wave, so a block covers 32 rows
+
+__global__ __launch_bounds__(LN_THREADS) void mt_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                               const uint8_t* __restrict__ keep,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               float* __restrict__ y, float* __restrict__ z,
+                                                               float* __restrict__ stats, int M, int d, float eps,
+                                                               float keep_scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const int nv = d >> 2;
+  const size_t base = (size_t)row * d;
+  f32x4 v[LN_MAXV];
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < LN_MAXV; ++t) {
+    const int c = lane + 64 * t;
+    v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < nv) {
+      f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + 4 * c);
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(res + base + 4 * c);
+      if (keep != nullptr) {
+        const uint32_t kw = *reinterpret_cast<const uint32_t*>(keep + base + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] *= ((kw >> (8 * e)) & 0xFFu) ? keep_scale : 0.f;
+      }
+      v[t] = xv + rv;
+      *reinterpret_cast<f32x4*>(z + base + 4 * c) = v[t];
+      sum += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+    }
+  }
+  const float mean = wave_sum(sum) / (float)d;
+  float var = 0.f;
+#pragma unroll
+  for (int t = 0; t < LN_MAXV; ++t)
+    if (lane + 64 * t < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float c0 = v[t][e] - mean; var += c0 * c0; }
+    }
+  const float rstd = rsqrtf(wave_sum(var) / (float)d + eps);
+#pragma unroll
+  for (int t = 0; t < LN_MAXV; ++t) {
+    const int c = lane + 64 * t;
+    if (c < nv) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 4 * c), bv = *reinterpret_cast<const f32x4*>(b + 4 * c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[t][e] - mean) * rstd * wv[e] + bv[e];
+      *reinterpret_cast<f32x4*>(y + base + 4 * c) = o;
+    }
+  }
+  if (lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
+}
+
+__global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                               const float* __restrict__ stats,
+                                                               const uint8_t* __restrict__ keep,
+                                                               const float* __restrict__ w, float* __restrict__ dx,
+                                                               float* __restrict__ dres, float* __restrict__ dwb_part,
+                                                               int M, int d, float keep_scale) {
+  __shared__ float red[4][2 * 2048 / 4];     // per wave: dw then db for one float4 column group at a time
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = d >> 2;
+  f32x4 dw[LN_MAXV], db[LN_MAXV];
+#pragma unroll
+  for (int t = 0; t < LN_MAXV; ++t) { dw[t] = f32x4{0.f, 0.f, 0.f, 0.f}; db[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int row0 = (blockIdx.x * 4 + wave) * LN_ROWS_PER_WAVE;
+  for (int r = 0; r < LN_ROWS_PER_WAVE; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    const size_t base = (size_t)row * d;
+    const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+    f32x4 g[LN_MAXV], xh[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+      const int c = lane + 64 * t;
+      g[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xh[t] = g[t];
+      if (c < nv) {
+        const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + base + 4 * c);
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + base + 4 * c);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[t][e] = (zv[e] - mean) * rstd;
+          g[t][e] = dyv[e] * wv[e];
+          s1 += g[t][e];
+          s2 += g[t][e] * xh[t][e];
+          dw[t][e] += dyv[e] * xh[t][e];
+          db[t][e] += dyv[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+      const int c = lane + 64 * t;
+      if (c < nv) {
+        f32x4 dz, dxv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dz[e] = rstd * (g[t][e] - s1 - xh[t][e] * s2);
+        dxv = dz;
+        if (keep != nullptr) {
+          const uint32_t kw = *reinterpret_cast<const uint32_t*>(keep + base + 4 * c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dxv[e] *= ((kw >> (8 * e)) & 0xFFu) ? keep_scale : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dres + base + 4 * c) = dz;
+        *reinterpret_cast<f32x4*>(dx + base + 4 * c) = dxv;
+      }
+    }
+  }
+  // block-level partial of dw / db: waves take turns through LDS, one float4 column group at a time
+  float* out = dwb_part + (size_t)blockIdx.x * 2 * d;
+#pragma unroll
+  for (int t = 0; t < LN_MAXV; ++t) {
+    const int c = lane + 64 * t;
+    __syncthreads();
+    if (c < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[wave][(lane * 4 + e)] = dw[t][e];
+        red[wave][256 + (lane * 4 + e)] = db[t][e];
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && c < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = lane * 4 + e;
+        out[4 * c + e] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        out[d + 4 * c + e] = (red[0][256 + k] + red[1][256 + k]) + (red[2][256 + k] + red[3][256 + k]);
+      }
+    }
+  }
+}
+
+extern "C" int mt_ln_bwd_blocks(int M) { return (M + 4 * LN_ROWS_PER_WAVE - 1) / (4 * LN_ROWS_PER_WAVE); }
+
+extern "C" int mt_ln_fwd_launch(const float* x, const float* res, const void* keep, const float* w, const float* b,
+                                float* y, float* z, float* stats, int M, int d, float eps, float keep_scale,
+                                hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (d > 2048 || (d & 3)) return -2;
+  hipLaunchKernelGGL(mt_ln_fwd_kernel, dim3((M + 3) / 4), dim3(LN_THREADS), 0, stream, x, res, (const uint8_t*)keep, w,
+                     b, y, z, stats, M, d, eps, keep_scale);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mt_ln_bwd_launch(const float* dy, const float* z, const float* stats, const void* keep, const float* w,
+                                float* dx, float* dres, float* dwb_part, int M, int d, float keep_scale,
+                                hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (d > 2048 || (d & 3)) return -2;
+  hipLaunchKernelGGL(mt_ln_bwd_kernel, dim3(mt_ln_bwd_blocks(M)), dim3(LN_THREADS), 0, stream, dy, z, stats,
+                     (const uint8_t*)keep, w, dx, dres, dwb_part, M, d, keep_scale);
+  return (int)hipGetLastError();
+}

@@ -1,8 +1,53 @@
 """Autograd binding of the fused dropout + residual + LayerNorm kernels (``csrc/layernorm.hip``)."""
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
+
+from . import lib as L
 
 
 def available() -> bool:
-    return False
+    if not torch.cuda.is_available():
+        return False
+    L.load()
+    return True
+
+
+class FusedResidualLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps: float, keep: Optional[torch.Tensor], dropout_p: float):
+        so = L.load()
+        d = x.shape[-1]
+        xf, rf = x.contiguous().view(-1, d), residual.contiguous().view(-1, d)
+        M = xf.shape[0]
+        keep_u8 = keep.to(torch.uint8).contiguous() if keep is not None else None
+        y, z = torch.empty_like(xf), torch.empty_like(xf)
+        stats = torch.empty(M, 2, device=x.device, dtype=torch.float32)
+        keep_scale = 1.0 / (1.0 - dropout_p) if keep is not None else 1.0
+        w, b = weight.contiguous(), bias.contiguous()
+        L.check(so.mt_ln_fwd_launch(xf.data_ptr(), rf.data_ptr(), keep_u8.data_ptr() if keep_u8 is not None else None,
+                                    w.data_ptr(), b.data_ptr(), y.data_ptr(), z.data_ptr(), stats.data_ptr(), M, d,
+                                    float(eps), keep_scale, torch.cuda.current_stream(x.device).cuda_stream),
+                "mt_ln_fwd_launch")
+        ctx.save_for_backward(z, stats, w, keep_u8 if keep_u8 is not None else torch.empty(0, device=x.device))
+        ctx.meta = (keep is not None, keep_scale, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        so = L.load()
+        z, stats, w, keep_u8 = ctx.saved_tensors
+        has_keep, keep_scale, shape = ctx.meta
+        M, d = z.shape
+        dy = grad_y.contiguous().view(M, d)
+        dx, dres = torch.empty_like(z), torch.empty_like(z)
+        nblk = int(so.mt_ln_bwd_blocks(M))
+        part = torch.empty(nblk, 2, d, device=z.device, dtype=torch.float32)
+        L.check(so.mt_ln_bwd_launch(dy.data_ptr(), z.data_ptr(), stats.data_ptr(),
+                                    keep_u8.data_ptr() if has_keep else None, w.data_ptr(), dx.data_ptr(),
+                                    dres.data_ptr(), part.data_ptr(), M, d, keep_scale,
+                                    torch.cuda.current_stream(z.device).cuda_stream), "mt_ln_bwd_launch")
+        dwb = part.sum(0)
+        return dx.view(shape), dres.view(shape), dwb[0], dwb[1], None, None, None

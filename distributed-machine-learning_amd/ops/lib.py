@@ -127,6 +127,16 @@ def load(build_if_missing: bool = True) -> C.CDLL:
                                     C.c_int, C.c_int, c_void_p, C.c_int, C.c_int, C.c_int, c_void_p]
     lib.mt_head_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.mt_head_scratch_floats.restype = C.c_long
+    lib.mt_attn_fwd_launch.argtypes = [c_void_p] * 5 + [c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float, c_float,
+                                                        C.c_int, c_void_p]
+    lib.mt_attn_bwd_launch.argtypes = [c_void_p] * 9 + [C.c_int, C.c_int, C.c_int, C.c_int, c_float, c_float, C.c_int,
+                                                        c_void_p]
+    lib.mt_ln_fwd_launch.argtypes = [c_void_p] * 8 + [C.c_int, C.c_int, c_float, c_float, c_void_p]
+    lib.mt_ln_bwd_launch.argtypes = [c_void_p] * 8 + [C.c_int, C.c_int, c_float, c_void_p]
+    lib.mt_ln_bwd_blocks.argtypes = [C.c_int]
+    for fn in (lib.mt_attn_fwd_launch, lib.mt_attn_bwd_launch, lib.mt_ln_fwd_launch, lib.mt_ln_bwd_launch,
+               lib.mt_ln_bwd_blocks):
+        fn.restype = C.c_int
     lib.mt_mlp_train_steps.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]
     lib.mt_mlp_eval.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]
     for fn in (lib.mt_gemm_launch, lib.mt_gather_launch, lib.mt_head_loss_launch, lib.mt_head_eval_launch,

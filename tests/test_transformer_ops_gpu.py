@@ -1,0 +1,95 @@
+"""Fused attention / LayerNorm HIP kernels against the PyTorch fp32 reference of the same op."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("kind", ["softmax", "relu"])
+@pytest.mark.parametrize("S,dk,dv", [(50, 16, 16), (96, 32, 32), (128, 64, 64), (17, 8, 24), (65, 24, 8)])
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_fused_attention_forward_backward(kind, S, dk, dv, drop):
+    from mitune.ops.attention import attention_reference
+    from mitune.ops.attention_hip import FusedShortAttention
+    g = torch.Generator(device="cuda").manual_seed(S * 7 + dk)
+    B, h = 3, 2
+    q = _bf16r(torch.randn(B, h, S, dk, device="cuda", generator=g)).requires_grad_(True)
+    k = _bf16r(torch.randn(B, h, S, dk, device="cuda", generator=g)).requires_grad_(True)
+    v = _bf16r(torch.randn(B, h, S, dv, device="cuda", generator=g)).requires_grad_(True)
+    keep = None
+    if drop > 0:
+        keep = torch.bernoulli(torch.full((B, h, S, S), 1 - drop, device="cuda"), generator=g)
+    do = _bf16r(torch.randn(B, h, S, dv, device="cuda", generator=g))
+    out = FusedShortAttention.apply(q, k, v, kind, keep, drop)
+    out.backward(do)
+    got = (out.detach(), q.grad.clone(), k.grad.clone(), v.grad.clone())
+    q.grad = k.grad = v.grad = None
+    ref = attention_reference(q, k, v, kind, keep, drop)
+    ref.backward(do)
+    exp = (ref.detach(), q.grad, k.grad, v.grad)
+    for name, a, b in zip(("out", "dq", "dk", "dv"), got, exp):
+        scale = b.abs().max().item() + 1e-6
+        err = (a - b).abs().max().item() / scale
+        assert err < 3e-2, (name, err)
+        assert torch.isfinite(a).all(), name
+
+
+def test_attention_asymmetric_values_catch_transposes():
+    """Identity-like attention (one hot scores) must route V rows exactly."""
+    from mitune.ops.attention_hip import FusedShortAttention
+    S, d = 64, 32
+    q = torch.zeros(1, 1, S, d, device="cuda"); k = torch.zeros(1, 1, S, d, device="cuda")
+    perm = torch.randperm(S, device="cuda")
+    for i in range(S):                     # query i matches key perm[i] through a unique pair of +-16 entries
+        q[0, 0, i, i % d] = 16.0 * (1 if i < d else -1)
+        k[0, 0, perm[i], i % d] = 16.0 * (1 if i < d else -1)
+    v = (torch.arange(S * d, device="cuda").reshape(1, 1, S, d) % 61).float()
+    out = FusedShortAttention.apply(q, k, v, "softmax", None, 0.0)
+    assert torch.allclose(out[0, 0], v[0, 0, perm], atol=0.26)      # bf16 output rounding of values <= 60
+
+
+@pytest.mark.parametrize("d", [32, 128, 320, 512, 2048])
+@pytest.mark.parametrize("drop", [0.0, 0.3])
+def test_fused_residual_layernorm(d, drop):
+    from mitune.ops.layernorm import residual_layer_norm_reference
+    from mitune.ops.layernorm_hip import FusedResidualLayerNorm
+    g = torch.Generator(device="cuda").manual_seed(d)
+    M = 77
+    x = torch.randn(M, d, device="cuda", generator=g, requires_grad=True)
+    r = torch.randn(M, d, device="cuda", generator=g, requires_grad=True)
+    w = torch.randn(d, device="cuda", generator=g, requires_grad=True)
+    b = torch.randn(d, device="cuda", generator=g, requires_grad=True)
+    keep = torch.bernoulli(torch.full((M, d), 1 - drop, device="cuda"), generator=g) if drop > 0 else None
+    dy = torch.randn(M, d, device="cuda", generator=g)
+    y = FusedResidualLayerNorm.apply(x, r, w, b, 1e-5, keep, drop)
+    y.backward(dy)
+    got = [y.detach()] + [t.grad.clone() for t in (x, r, w, b)]
+    for t in (x, r, w, b):
+        t.grad = None
+    yr = residual_layer_norm_reference(x, r, w, b, 1e-5, keep, drop)
+    yr.backward(dy)
+    exp = [yr.detach()] + [t.grad for t in (x, r, w, b)]
+    for name, a, e in zip(("y", "dx", "dres", "dw", "db"), got, exp):
+        torch.testing.assert_close(a, e, rtol=2e-4, atol=2e-4, msg=lambda m, n=name: f"{n}: {m}")
+
+
+def test_transformer_models_run_on_the_fused_kernels():
+    from mitune.models.transformer import SimpleTransformerModel, TransformerModel
+    torch.manual_seed(0)
+    x = torch.randn(8, 96, 10)
+    for attn in ("scaled_dot_product", "linear_attention"):
+        m = TransformerModel(10, 4, 2, 64, 128, 0.1, 96, attn, 3, False, 1.0, False, 0.05)
+        ref = m.eval()(x)
+        mg = m.cuda()
+        out = mg.eval()(x.cuda())
+        assert torch.allclose(out.cpu(), ref, atol=3e-2, rtol=3e-2)
+        mg.train()
+        loss = mg(x.cuda()).pow(2).mean()
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mg.parameters())
+    s = SimpleTransformerModel(10, 32, 4, 2, 0.1).cuda()
+    s(torch.randn(4, 50, 10, device="cuda")).sum().backward()
