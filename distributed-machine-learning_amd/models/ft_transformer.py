@@ -1,0 +1,93 @@
+"""FT-Transformer-style tabular regressor (feature tokenizer + Transformer encoder + [CLS] head).
+
+Not part of the reference (its models are sequence encoders, /root/reference/ray-tune-hpo-regression.py:183-240);
+it is the model family of the "tabular regression in bf16 with population-based training" target
+configuration.  Every numeric feature becomes one token (``x_j * w_j + b_j``), a learned [CLS] token
+is appended, ``n_blocks`` post-norm encoder blocks with a ReGLU feed-forward mix the tokens, and the
+[CLS] representation is regressed to a scalar.  With F <= 127 features the token sequence fits the fused
+short-sequence attention kernel (S <= 128); the projections are plain GEMMs left to the BLAS library,
+under bf16 autocast on a GPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .transformer import SelfAttention
+from ..ops.layernorm import residual_layer_norm
+
+
+class FeatureTokenizer(nn.Module):
+    def __init__(self, n_features: int, d_token: int):
+        super().__init__()
+        bound = 1.0 / math.sqrt(d_token)
+        self.weight = nn.Parameter(torch.empty(n_features, d_token).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(n_features, d_token).uniform_(-bound, bound))
+        self.cls = nn.Parameter(torch.empty(1, 1, d_token).uniform_(-bound, bound))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:            # [B, F] -> [B, F + 1, d]
+        tok = x.unsqueeze(-1) * self.weight + self.bias
+        return torch.cat([tok, self.cls.expand(x.size(0), -1, -1).to(tok.dtype)], dim=1)
+
+
+class ReGLU(nn.Module):
+    def __init__(self, d_token: int, d_hidden: int, dropout: float):
+        super().__init__()
+        self.up = nn.Linear(d_token, 2 * d_hidden)
+        self.down = nn.Linear(d_hidden, d_token)
+        self.p = dropout
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        a, g = self.up(x).chunk(2, dim=-1)
+        return self.down(F.dropout(a * F.relu(g), self.p, self.training))
+
+
+class FTBlock(nn.Module):
+    def __init__(self, d_token: int, n_heads: int, d_hidden: int, attn_dropout: float, ffn_dropout: float,
+                 residual_dropout: float):
+        super().__init__()
+        self.attn = SelfAttention(d_token, n_heads, attn_dropout)
+        self.ffn = ReGLU(d_token, d_hidden, ffn_dropout)
+        self.norm1, self.norm2 = nn.LayerNorm(d_token), nn.LayerNorm(d_token)
+        self.p = residual_dropout
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        p = self.p if self.training else 0.0
+        a, _ = self.attn(x)
+        x = residual_layer_norm(a.float(), x.float(), self.norm1.weight, self.norm1.bias, self.norm1.eps, dropout_p=p)
+        f = self.ffn(x)
+        return residual_layer_norm(f.float(), x, self.norm2.weight, self.norm2.bias, self.norm2.eps, dropout_p=p)
+
+
+class FTTransformer(nn.Module):
+    def __init__(self, n_features: int, d_token: int = 192, n_blocks: int = 3, n_heads: int = 8,
+                 ffn_factor: float = 4.0 / 3.0, attn_dropout: float = 0.2, ffn_dropout: float = 0.1,
+                 residual_dropout: float = 0.0):
+        super().__init__()
+        if d_token % n_heads:
+            raise ValueError("d_token must be divisible by n_heads")
+        self.tokenizer = FeatureTokenizer(n_features, d_token)
+        d_hidden = max(8, int(round(d_token * ffn_factor / 8)) * 8)
+        self.blocks = nn.ModuleList(FTBlock(d_token, n_heads, d_hidden, attn_dropout, ffn_dropout, residual_dropout)
+                                    for _ in range(n_blocks))
+        self.head_norm = nn.LayerNorm(d_token)
+        self.head = nn.Linear(d_token, 1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:            # [B, F] -> [B]
+        t = self.tokenizer(x)
+        for blk in self.blocks:
+            t = blk(t)
+        cls = t[:, -1, :]
+        return self.head(F.relu(self.head_norm(cls.float()))).squeeze(-1)
+
+    @classmethod
+    def from_config(cls, config: Dict, n_features: int) -> "FTTransformer":
+        return cls(n_features, d_token=int(config.get("d_token", 192)), n_blocks=int(config.get("n_blocks", 3)),
+                   n_heads=int(config.get("n_heads", 8)), ffn_factor=float(config.get("ffn_factor", 4.0 / 3.0)),
+                   attn_dropout=float(config.get("attention_dropout", 0.2)),
+                   ffn_dropout=float(config.get("ffn_dropout", 0.1)),
+                   residual_dropout=float(config.get("residual_dropout", 0.0)))

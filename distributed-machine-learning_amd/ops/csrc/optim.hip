@@ -49,6 +49,7 @@ __device__ __forceinline__ float lr_factor(int t, int warmup, int total) {
   return 1.f;
 }
 
+template <bool G_BF16>   // G_BF16: gradients are bf16 (data-parallel trials all-reduce bf16 gradient buckets)
 __global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict__ P, const float* __restrict__ G,
                                                                float* __restrict__ M, float* __restrict__ V,
                                                                uint16_t* __restrict__ Pb, size_t slot_stride,
@@ -83,7 +84,17 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict
   float p[8], g[8], m[8], v[8];
   if (n == 8) {
     const f32x4 p0 = *reinterpret_cast<const f32x4*>(P + off), p1 = *reinterpret_cast<const f32x4*>(P + off + 4);
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(G + off), g1 = *reinterpret_cast<const f32x4*>(G + off + 4);
+    f32x4 g0, g1;
+    if (G_BF16) {
+      const u32x4 gb = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(G) + off);
+      g0 = f32x4{bf16_bits_to_f32(gb[0] & 0xFFFFu), bf16_bits_to_f32(gb[0] >> 16), bf16_bits_to_f32(gb[1] & 0xFFFFu),
+                 bf16_bits_to_f32(gb[1] >> 16)};
+      g1 = f32x4{bf16_bits_to_f32(gb[2] & 0xFFFFu), bf16_bits_to_f32(gb[2] >> 16), bf16_bits_to_f32(gb[3] & 0xFFFFu),
+                 bf16_bits_to_f32(gb[3] >> 16)};
+    } else {
+      g0 = *reinterpret_cast<const f32x4*>(G + off);
+      g1 = *reinterpret_cast<const f32x4*>(G + off + 4);
+    }
     const f32x4 m0 = *reinterpret_cast<const f32x4*>(M + off), m1 = *reinterpret_cast<const f32x4*>(M + off + 4);
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(V + off), v1 = *reinterpret_cast<const f32x4*>(V + off + 4);
 #pragma unroll
@@ -95,7 +106,8 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const bool ok = e < n;
-      p[e] = ok ? P[off + e] : 0.f; g[e] = ok ? G[off + e] : 0.f;
+      p[e] = ok ? P[off + e] : 0.f;
+      g[e] = !ok ? 0.f : (G_BF16 ? bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(G)[off + e]) : G[off + e]);
       m[e] = ok ? M[off + e] : 0.f; v[e] = ok ? V[off + e] : 0.f;
     }
   }
@@ -158,7 +170,20 @@ extern "C" int mt_optim_launch(float* P, const float* G, float* M, float* V, voi
     if (partials == nullptr) return -3;
     hipLaunchKernelGGL(mt_sqnorm_kernel, grid, block, 0, stream, G, slot_stride, hp, ids, partials, max_blocks, step);
   }
-  hipLaunchKernelGGL(mt_optim_kernel, grid, block, 0, stream, P, G, M, V, reinterpret_cast<uint16_t*>(Pb),
+  hipLaunchKernelGGL(mt_optim_kernel<false>, grid, block, 0, stream, P, G, M, V, reinterpret_cast<uint16_t*>(Pb),
                      slot_stride, hp, ids, use_clip ? partials : nullptr, max_blocks, step);
+  return (int)hipGetLastError();
+}
+
+// Same update with bf16 gradients and no clipping pass (the caller clips, if at all, before the all-reduce).
+extern "C" int mt_optim_launch_bf16g(float* P, const void* Gb, float* M, float* V, void* Pb, size_t slot_stride,
+                                     const MtOptSlot* hp, const int32_t* ids, int n_active, int max_params, int step,
+                                     hipStream_t stream) {
+  if (n_active <= 0 || max_params <= 0) return 0;
+  if (slot_stride % 8 != 0) return -2;
+  const int nb = (max_params + OPT_PER_BLOCK - 1) / OPT_PER_BLOCK;
+  dim3 grid(nb, n_active), block(OPT_THREADS);
+  hipLaunchKernelGGL(mt_optim_kernel<true>, grid, block, 0, stream, P, reinterpret_cast<const float*>(Gb), M, V,
+                     reinterpret_cast<uint16_t*>(Pb), slot_stride, hp, ids, nullptr, 0, step);
   return (int)hipGetLastError();
 }

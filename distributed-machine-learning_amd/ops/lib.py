@@ -125,6 +125,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
                                         c_void_p]
     lib.mt_optim_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p,
                                     C.c_int, C.c_int, c_void_p, C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_optim_launch_bf16g.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                          c_void_p, C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_optim_launch_bf16g.restype = C.c_int
     lib.mt_head_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.mt_head_scratch_floats.restype = C.c_long
     lib.mt_attn_fwd_launch.argtypes = [c_void_p] * 5 + [c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float, c_float,

@@ -74,8 +74,8 @@ class TorchPackEngine(PackEngine):
 
     def __init__(self, trainable: PackedTrainable, device: str = "cpu", capacity: Optional[int] = None,
                  seed: int = 0):
-        if trainable.model != "mlp":
-            raise ValueError("TorchPackEngine trains the 'mlp' family")
+        if not (trainable.model in ("mlp", "ft_transformer") or callable(trainable.model)):
+            raise ValueError("model must be 'mlp', 'ft_transformer' or a factory fn(config, in_features) -> nn.Module")
         self.t = trainable
         self.device = torch.device(device)
         self.capacity = int(capacity or trainable.capacity or 64)
@@ -85,13 +85,30 @@ class TorchPackEngine(PackEngine):
         self.Xva = trainable.val[0].to(self.device, torch.float32)
         self.yva = trainable.val[1].to(self.device, torch.float32)
         self.slots: Dict[int, _Slot] = {}
+        # bf16 autocast for the non-MLP families on a GPU: projections run as bf16 library GEMMs, attention
+        # and LayerNorm as the fused HIP kernels
+        self.amp = self.device.type == "cuda" and trainable.dtype == "bf16" and trainable.model != "mlp"
+
+    def _autocast(self):
+        return torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp)
 
     # ------------------------------------------------------------------ slot management
     def occupied(self) -> List[int]:
         return sorted(self.slots)
 
-    def _build(self, spec: MLPTrialSpec, config: Dict):
-        model = MLPRegressor(spec.in_features, spec.hidden_sizes).to(self.device)
+    def _build(self, spec: MLPTrialSpec, config: Dict, trial_index: int = 0):
+        if self.t.model == "mlp":
+            model = MLPRegressor(spec.in_features, spec.hidden_sizes)
+        else:
+            # weights drawn from the trial's own stream, so a trial's start does not depend on its slot
+            with torch.random.fork_rng(devices=[]):
+                torch.manual_seed((self.seed * 1_000_003 + int(trial_index)) * 16 + 7)
+                if self.t.model == "ft_transformer":
+                    from ..models.ft_transformer import FTTransformer
+                    model = FTTransformer.from_config({**self.t.model_kwargs, **config}, spec.in_features)
+                else:
+                    model = self.t.model(config, spec.in_features)
+        model = model.to(self.device)
         opt = build_optimizer(spec.optimizer, model.parameters(), spec.learning_rate, spec.weight_decay,
                               spec.momentum, spec.beta1, spec.beta2, spec.eps)
         return model, opt
@@ -102,7 +119,7 @@ class TorchPackEngine(PackEngine):
         spec = MLPTrialSpec.from_config(config, self.t.in_features)
         s = _Slot()
         s.trial_index, s.spec, s.config = int(trial_index), spec, dict(config)
-        s.model, s.opt = self._build(spec, config)
+        s.model, s.opt = self._build(spec, config, trial_index)
         s.epoch, s.step, s.train_loss = 0, 0, float("nan")
         if state is not None and "model" in state:
             s.model.load_state_dict(state["model"])
@@ -113,7 +130,7 @@ class TorchPackEngine(PackEngine):
                     pass      # optimiser family changed (PBT explore): keep fresh moments
             s.epoch = int(state.get("epoch", 0))
             s.step = int(state.get("step", 0))
-        else:
+        elif self.t.model == "mlp":
             s.model.load_state_dict(init_mlp_state(spec, self.seed, trial_index))
         self.slots[slot] = s
 
@@ -164,8 +181,9 @@ class TorchPackEngine(PackEngine):
             for g in s.opt.param_groups:
                 g["lr"] = s.spec.learning_rate * lr_factor(s.step, s.spec.warmup_steps, s.spec.total_steps)
             s.opt.zero_grad(set_to_none=True)
-            out = s.model(self.Xtr[idx])
-            loss = crit(out, self.ytr[idx])
+            with self._autocast():
+                out = s.model(self.Xtr[idx])
+            loss = crit(out.float(), self.ytr[idx])
             loss.backward()
             if s.spec.gradient_clipping > 0:
                 torch.nn.utils.clip_grad_norm_(s.model.parameters(), s.spec.gradient_clipping)
@@ -193,7 +211,9 @@ class TorchPackEngine(PackEngine):
             from ..train.losses import elementwise_loss
             for c0 in range(0, n, self.t.val_chunk):
                 x, y = self.Xva[c0:c0 + self.t.val_chunk], self.yva[c0:c0 + self.t.val_chunk]
-                o = s.model(x)
+                with self._autocast():
+                    o = s.model(x)
+                o = o.float()
                 se += ((o - y) ** 2).sum().double()
                 ape += ((o - y).abs() / (y.abs() + MAPE_EPS)).sum().double()
                 ls += elementwise_loss(crit, o, y).sum().double()

@@ -110,3 +110,53 @@ def test_gloo_two_process_search_agrees(tmp_path):
     assert a["res"] == b["res"] and a["sum"] == 3.0
     single, _ = _search(LocalComm(), num_samples=8, capacity=8)
     assert {k: v[:2] for k, v in a["res"].items()} == {k: list(v[:2]) for k, v in single.items()}
+
+
+# ----------------------------------------------------------------------------------------- data-parallel trials
+def _dp_data(n=512, f=12, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(n, f, generator=g)
+    y = torch.tanh(X[:, 0]) + 0.5 * X[:, 1] + 0.05 * torch.randn(n, generator=g)
+    return X, y
+
+
+def test_dp_gradient_average_equals_full_batch_training():
+    """2 ranks x half the rows (batch = whole shard) == 1 rank x all rows (batch = everything)."""
+    from mitune.parallel.dp import DPTrainer, shard_rows
+    X, y = _dp_data()
+    cfg = {"hidden_sizes": [32, 16], "batch_size": 512, "learning_rate": 0.05, "optimizer": "sgd", "momentum": 0.9}
+    ref = DPTrainer(cfg, X, y, X[:64], y[:64], seed=4, trial_index=2)
+    for _ in range(5):
+        ref.train_epoch()
+
+    def fn(comm):
+        lo, hi = shard_rows(512, comm.rank, 2)
+        t = DPTrainer(cfg, X[lo:hi], y[lo:hi], X[:64], y[:64], comm=comm, seed=4, trial_index=2)
+        losses = [t.train_epoch() for _ in range(5)]
+        return t.model.P.clone(), losses, t.evaluate(), t.reducer.bytes_reduced
+
+    (p0, l0, e0, b0), (p1, l1, e1, b1) = _run_ranks(2, fn)
+    assert torch.equal(p0, p1) and l0 == l1 and e0 == e1          # replicas never diverge
+    assert torch.allclose(p0, ref.model.P, atol=1e-5)
+    assert b0 == 5 * ref.model.numel * 4                            # every gradient element reduced once per step
+    assert l0[-1] < l0[0]
+
+
+def test_dp_trainable_under_replicated_driver():
+    from mitune.parallel.dp import dp_mlp_trainable, shard_rows
+    X, y = _dp_data(n=1024)
+
+    def fn(comm):
+        lo, hi = shard_rows(768, comm.rank, comm.world_size)
+        vlo, vhi = shard_rows(256, comm.rank, comm.world_size)
+        tr = tune.with_parameters(dp_mlp_trainable, train=(X[lo:hi], y[lo:hi]),
+                                  val=(X[768 + vlo:768 + vhi], y[768 + vlo:768 + vhi]), comm=comm, epochs=3, seed=1)
+        an = mitune.run(tr, config={"hidden_sizes": [32], "batch_size": tune.choice([64, 128]),
+                                    "learning_rate": tune.loguniform(1e-3, 3e-2)},
+                        num_samples=4, scheduler=ASHAScheduler(metric="validation_loss", mode="min", max_t=3,
+                                                               reduction_factor=2),
+                        max_concurrent_trials=1, seed=0, verbose=0)
+        return [(t.trial_id, t.training_iteration, t.last_result["validation_loss"]) for t in an.trials]
+
+    r0, r1 = _run_ranks(2, fn)
+    assert r0 == r1 and len(r0) == 4

@@ -35,3 +35,21 @@ def test_packed_mlp_cpu(tmp_path):
     assert len(an.trials) == 6
     assert an.best_result["validation_loss"] < float(y.var())
     assert an.best_checkpoint is not None
+
+
+def test_ft_transformer_population_based_training_cpu():
+    from mitune.schedulers import PopulationBasedTraining
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(1200, 6, generator=g)
+    y = X[:, 0] * X[:, 1] + torch.sin(X[:, 2]) + 0.05 * torch.randn(1200, generator=g)
+    tr = PackedTrainable(model="ft_transformer", train=(X[:1000], y[:1000]), val=(X[1000:], y[1000:]), max_epochs=4,
+                         engine="torch", capacity=4, model_kwargs={"d_token": 16, "n_blocks": 1, "n_heads": 2})
+    pbt = PopulationBasedTraining(metric="validation_loss", mode="min", perturbation_interval=2,
+                                  hyperparam_mutations={"learning_rate": tune.loguniform(1e-4, 1e-2)},
+                                  quantile_fraction=0.25, seed=0)
+    an = mitune.run(tr, config={"learning_rate": tune.loguniform(1e-4, 1e-2), "batch_size": 100,
+                                "attention_dropout": 0.0}, num_samples=4, scheduler=pbt, verbose=0)
+    assert all(t.training_iteration == 4 for t in an.trials)
+    assert an.stats["exploits"] >= 1
+    first = min(t.results[0]["validation_loss"] for t in an.trials)
+    assert an.best_result["validation_loss"] < first
