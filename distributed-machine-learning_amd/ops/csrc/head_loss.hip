@@ -31,7 +31,7 @@ __device__ __forceinline__ void loss_and_grad(int type, float out, float y, floa
 // Training: grid (row_chunks, active slots).  Workgroup (c, a) handles rows [c*HL_ROWS, (c+1)*HL_ROWS) of
 // slot ids[a] and writes one partial record {gw[0..W), gb, loss} to scratch; mt_head_reduce_kernel then adds
 // the records of a slot in chunk order (fixed order => bitwise reproducible, no float atomics).
-#define HL_ROWS 64
+#define HL_ROWS 16
 
 template <int NCHUNK>
 __global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSlot* __restrict__ slots,

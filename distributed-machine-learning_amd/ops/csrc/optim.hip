@@ -18,18 +18,19 @@
 __global__ __launch_bounds__(OPT_THREADS) void mt_sqnorm_kernel(const float* __restrict__ G, size_t slot_stride,
                                                                 const MtOptSlot* __restrict__ hp,
                                                                 const int32_t* __restrict__ ids,
-                                                                float* __restrict__ partials, int max_blocks, int step) {
+                                                                float* __restrict__ partials, int max_blocks, int step,
+                                                                int gsplits, size_t gsplit_stride) {
   const int slot = ids[blockIdx.y];
   const MtOptSlot h = hp[slot];
   float acc = 0.f;
   const int base = blockIdx.x * OPT_PER_BLOCK + threadIdx.x * 8;
   if (step < h.active_steps && h.clip > 0.f && base < h.n_params) {
     const float* g = G + (size_t)slot * slot_stride + base;
-    if (base + 8 <= h.n_params) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(g), b = *reinterpret_cast<const f32x4*>(g + 4);
-      acc = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
-    } else {
-      for (int e = 0; base + e < h.n_params; ++e) acc += g[e] * g[e];
+    const int n = (h.n_params - base) < 8 ? (h.n_params - base) : 8;
+    for (int e = 0; e < n; ++e) {
+      float v = g[e];
+      for (int sp = 1; sp < gsplits; ++sp) v += g[(size_t)sp * gsplit_stride + e];   // same order as the update
+      acc += v * v;
     }
   }
   __shared__ float red[4];
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict
                                                                const MtOptSlot* __restrict__ hp,
                                                                const int32_t* __restrict__ ids,
                                                                const float* __restrict__ partials, int max_blocks,
-                                                               int step) {
+                                                               int step, int gsplits, size_t gsplit_stride) {
   const int slot = ids[blockIdx.y];
   const MtOptSlot h = hp[slot];
   if (step >= h.active_steps) return;
@@ -94,6 +95,10 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict
     } else {
       g0 = *reinterpret_cast<const f32x4*>(G + off);
       g1 = *reinterpret_cast<const f32x4*>(G + off + 4);
+      for (int sp = 1; sp < gsplits; ++sp) {      // split-K weight gradients: add the partial slabs in order
+        g0 += *reinterpret_cast<const f32x4*>(G + (size_t)sp * gsplit_stride + off);
+        g1 += *reinterpret_cast<const f32x4*>(G + (size_t)sp * gsplit_stride + off + 4);
+      }
     }
     const f32x4 m0 = *reinterpret_cast<const f32x4*>(M + off), m1 = *reinterpret_cast<const f32x4*>(M + off + 4);
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(V + off), v1 = *reinterpret_cast<const f32x4*>(V + off + 4);
@@ -108,6 +113,8 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict
       const bool ok = e < n;
       p[e] = ok ? P[off + e] : 0.f;
       g[e] = !ok ? 0.f : (G_BF16 ? bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(G)[off + e]) : G[off + e]);
+      if (ok && !G_BF16)
+        for (int sp = 1; sp < gsplits; ++sp) g[e] += G[(size_t)sp * gsplit_stride + off + e];
       m[e] = ok ? M[off + e] : 0.f; v[e] = ok ? V[off + e] : 0.f;
     }
   }
@@ -159,8 +166,10 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict
 
 extern "C" int mt_optim_launch(float* P, const float* G, float* M, float* V, void* Pb, size_t slot_stride,
                                const MtOptSlot* hp, const int32_t* ids, int n_active, int max_params,
-                               float* partials, int max_blocks, int use_clip, int step, hipStream_t stream) {
+                               float* partials, int max_blocks, int use_clip, int step, int gsplits,
+                               size_t gsplit_stride, hipStream_t stream) {
   const int n_slots = n_active;
+  if (gsplits < 1) return -6;
   if (n_slots <= 0 || max_params <= 0) return 0;
   if (slot_stride % 8 != 0) return -2;
   const int nb = (max_params + OPT_PER_BLOCK - 1) / OPT_PER_BLOCK;
@@ -168,10 +177,11 @@ extern "C" int mt_optim_launch(float* P, const float* G, float* M, float* V, voi
   dim3 grid(nb, n_slots), block(OPT_THREADS);
   if (use_clip) {
     if (partials == nullptr) return -3;
-    hipLaunchKernelGGL(mt_sqnorm_kernel, grid, block, 0, stream, G, slot_stride, hp, ids, partials, max_blocks, step);
+    hipLaunchKernelGGL(mt_sqnorm_kernel, grid, block, 0, stream, G, slot_stride, hp, ids, partials, max_blocks, step, gsplits,
+                       gsplit_stride);
   }
   hipLaunchKernelGGL(mt_optim_kernel<false>, grid, block, 0, stream, P, G, M, V, reinterpret_cast<uint16_t*>(Pb),
-                     slot_stride, hp, ids, use_clip ? partials : nullptr, max_blocks, step);
+                     slot_stride, hp, ids, use_clip ? partials : nullptr, max_blocks, step, gsplits, gsplit_stride);
   return (int)hipGetLastError();
 }
 
@@ -184,6 +194,6 @@ extern "C" int mt_optim_launch_bf16g(float* P, const void* Gb, float* M, float* 
   const int nb = (max_params + OPT_PER_BLOCK - 1) / OPT_PER_BLOCK;
   dim3 grid(nb, n_active), block(OPT_THREADS);
   hipLaunchKernelGGL(mt_optim_kernel<true>, grid, block, 0, stream, P, reinterpret_cast<const float*>(Gb), M, V,
-                     reinterpret_cast<uint16_t*>(Pb), slot_stride, hp, ids, nullptr, 0, step);
+                     reinterpret_cast<uint16_t*>(Pb), slot_stride, hp, ids, nullptr, 0, step, 1, (size_t)0);
   return (int)hipGetLastError();
 }

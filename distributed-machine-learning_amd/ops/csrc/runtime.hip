@@ -5,16 +5,19 @@
 // entry points below then enqueue whole training steps (or a whole validation sweep) from C++ with no
 // interpreter in the loop and no host-device synchronisation: the host only ever waits at the end of
 // an epoch, when it reads the metric table.  Per step the launch sequence is
-//   gather -> L x forward GEMM(+bias+ReLU) -> head+loss+dH -> for l = L-1..0 { wgrad(+dbias); dgrad(+ReLU mask) }
-//   -> [grad sq-norm partials] -> fused per-trial optimiser (+bf16 shadow refresh)
-// i.e. 3L + 3 (+1) launches regardless of how many trials share the GPU.
+//   gather -> L x forward GEMM(+bias+ReLU) -> head+loss+dH (+ its reduce) -> for l = L-1..0 { wgrad(+dbias) and
+//   dgrad(+ReLU mask) of layer l in ONE launch } -> [grad sq-norm partials] -> fused per-trial optimiser
+//   (+bf16 shadow refresh), i.e. 2L + 4 (+1) launches regardless of how many trials share the GPU.
 #include "mt_common.h"
 
 #define MT_MAX_LAYERS 8
 
 extern "C" {
 int mt_gemm_launch(int mode, const MtGemmGroup* groups, const MtTile* tiles, int ntiles, int step, int flags,
-                   int arow0, int i_override, hipStream_t stream);
+                   int arow0, int i_override, int ksplits, size_t split_stride, int nstage, hipStream_t stream);
+int mt_gemm_bwd_launch(const MtGemmGroup* wgroups, const MtTile* wtiles, int n_wtiles, const MtGemmGroup* dgroups,
+                       const MtTile* dtiles, int n_dtiles, int step, int ksplits, size_t split_stride, int nstage,
+                       hipStream_t stream);
 int mt_gather_launch(const MtGatherSlot* slots, const int32_t* ids, int n_active, int max_batch, const float* X,
                      const float* Y, uint32_t n_rows, int F, int Fpad, int hb, int step, hipStream_t stream);
 int mt_head_loss_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch, int max_width,
@@ -23,7 +26,7 @@ int mt_head_eval_launch(const MtHeadSlot* slots, const int32_t* ids, int n_activ
                         int max_rows, float* scratch, hipStream_t stream);
 int mt_optim_launch(float* P, const float* G, float* M, float* V, void* Pb, size_t slot_stride, const MtOptSlot* hp,
                     const int32_t* ids, int n_active, int max_params, float* partials, int max_blocks, int use_clip,
-                    int step, hipStream_t stream);
+                    int step, int gsplits, size_t gsplit_stride, hipStream_t stream);
 }
 
 struct MtMlpPlan {
@@ -57,7 +60,8 @@ struct MtMlpPlan {
   const int32_t* active_ids;
   float* head_scratch;    // mt_head_scratch_floats(physical slots, max batch, max width) floats
   int32_t max_blocks;
-  int32_t pad;
+  int32_t ksplits;        // wgrad contraction splits; G holds that many slabs of gsplit_stride floats
+  size_t gsplit_stride;
 };
 
 #define MT_TRY(x)            \
@@ -74,18 +78,16 @@ extern "C" int mt_mlp_train_steps(const MtMlpPlan* p, int step0, int nsteps, hip
                             p->Fpad, p->hb, step, stream));
     for (int l = 0; l < L; ++l)
       MT_TRY(mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], step, MT_GEMM_FLAG_RELU, 0, 0,
-                            stream));
+                            1, 0, 0, stream));
     MT_TRY(mt_head_loss_launch(p->head, p->active_ids, p->n_active, p->max_batch, p->max_width, step,
                                p->head_scratch, stream));
-    for (int l = L - 1; l >= 0; --l) {
-      MT_TRY(mt_gemm_launch(2, p->wgrad_groups[l], p->wgrad_tiles[l], p->wgrad_ntiles[l], step, MT_GEMM_FLAG_DBIAS,
-                            0, 0, stream));
-      if (l > 0)
-        MT_TRY(mt_gemm_launch(1, p->dgrad_groups[l], p->dgrad_tiles[l], p->dgrad_ntiles[l], step, MT_GEMM_FLAG_MASK,
-                              0, 0, stream));
-    }
+    for (int l = L - 1; l >= 0; --l)     // layer 0 has no input gradient: its dgrad tile list is empty
+      MT_TRY(mt_gemm_bwd_launch(p->wgrad_groups[l], p->wgrad_tiles[l], p->wgrad_ntiles[l], p->dgrad_groups[l],
+                                p->dgrad_tiles[l], l > 0 ? p->dgrad_ntiles[l] : 0, step, p->ksplits,
+                                p->gsplit_stride, 0, stream));
     MT_TRY(mt_optim_launch(p->P, p->G, p->M, p->V, p->Pb, p->slot_stride, p->opt, p->active_ids, p->n_active,
-                           p->max_params, p->partials, p->max_blocks, p->use_clip, step, stream));
+                           p->max_params, p->partials, p->max_blocks, p->use_clip, step, p->ksplits,
+                           p->gsplit_stride, stream));
   }
   return 0;
 }
@@ -100,7 +102,7 @@ extern "C" int mt_mlp_eval(const MtMlpPlan* p, int n_val_rows, int chunk_rows, h
     const int rows = (n_val_rows - r0) < chunk_rows ? (n_val_rows - r0) : chunk_rows;
     for (int l = 0; l < L; ++l)
       MT_TRY(mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], 0, MT_GEMM_FLAG_RELU,
-                            l == 0 ? r0 : 0, rows, stream));
+                            l == 0 ? r0 : 0, rows, 1, 0, 0, stream));
     MT_TRY(mt_head_eval_launch(p->head, p->active_ids, p->n_active, p->max_width, r0, rows, chunk_rows,
                                p->head_scratch, stream));
   }

@@ -61,7 +61,8 @@ class MlpPlan(C.Structure):
                 ("wgrad_ntiles", c_int32 * MT_MAX_LAYERS),
                 ("head", c_void_p), ("P", c_void_p), ("G", c_void_p), ("M", c_void_p), ("V", c_void_p),
                 ("Pb", c_void_p), ("slot_stride", c_size_t), ("opt", c_void_p), ("partials", c_void_p),
-                ("active_ids", c_void_p), ("head_scratch", c_void_p), ("max_blocks", c_int32), ("pad", c_int32)]
+                ("active_ids", c_void_p), ("head_scratch", c_void_p), ("max_blocks", c_int32), ("ksplits", c_int32),
+                ("gsplit_stride", c_size_t)]
 
 
 # numpy views of the same layouts, for building whole descriptor tables vectorised
@@ -117,14 +118,18 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if np_sizes != expect[:5]:
         raise KernelLibraryError(f"numpy descriptor dtypes {np_sizes} do not match ctypes {expect[:5]}")
 
-    lib.mt_gemm_launch.argtypes = [C.c_int, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_gemm_launch.argtypes = [C.c_int, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   c_size_t, C.c_int, c_void_p]
+    lib.mt_gemm_bwd_launch.argtypes = [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int,
+                                       c_size_t, C.c_int, c_void_p]
+    lib.mt_gemm_bwd_launch.restype = C.c_int
     lib.mt_gather_launch.argtypes = [c_void_p, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p, c_uint32, C.c_int,
                                      C.c_int, C.c_int, C.c_int, c_void_p]
     lib.mt_head_loss_launch.argtypes = [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p, c_void_p]
     lib.mt_head_eval_launch.argtypes = [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p,
                                         c_void_p]
     lib.mt_optim_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p,
-                                    C.c_int, C.c_int, c_void_p, C.c_int, C.c_int, C.c_int, c_void_p]
+                                    C.c_int, C.c_int, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_size_t, c_void_p]
     lib.mt_optim_launch_bf16g.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
                                           c_void_p, C.c_int, C.c_int, C.c_int, c_void_p]
     lib.mt_optim_launch_bf16g.restype = C.c_int

@@ -35,6 +35,7 @@ from ..train.optim import OPT_CODES
 
 TILE = 128
 N_XCD = 8
+MAX_KSPLITS = 4        # weight-gradient slabs kept per slot (split-K over the batch for small packs)
 
 
 def ceil8(x: int) -> int:
@@ -78,8 +79,8 @@ class _HSlot:
     __slots__ = ("trial_index", "spec", "layout", "epoch", "step", "config")
 
 
-def balanced_tiles(groups: List[Tuple[int, int, int, int]]) -> np.ndarray:
-    """XCD-aware tile list.
+def balanced_tiles(groups: List[Tuple[int, int, int, int]], ksplits: int = 1) -> np.ndarray:
+    """XCD-aware tile list (``ksplits`` > 1: one entry per contraction split, index in the high byte of ``ti``).
 
     ``groups`` holds (group index, tiles_i, tiles_j, weight).  Workgroup ids are dealt round-robin to
     the 8 XCDs, each with its own L2, so all tiles of one group (which share that group's operands)
@@ -92,7 +93,8 @@ def balanced_tiles(groups: List[Tuple[int, int, int, int]]) -> np.ndarray:
         b = min(range(N_XCD), key=lambda k: (load[k], k))
         for ti in range(ti_n):
             for tj in range(tj_n):
-                buckets[b].append((gi, ti, tj))
+                for sp in range(ksplits):
+                    buckets[b].append((gi, ti | (sp << 8), tj))
         load[b] += ti_n * tj_n * max(w, 1)
     depth = max((len(b) for b in buckets), default=0)
     out = np.zeros(depth * N_XCD, dtype=L.TILE_DTYPE)
@@ -141,7 +143,7 @@ class HipPackEngine(PackEngine):
         self.stride = (worst.total + 63) // 64 * 64
         T = self.capacity
         self.P = torch.zeros(T * self.stride, device=dev, dtype=torch.float32)
-        self.G = torch.zeros_like(self.P)
+        self.G = torch.zeros(MAX_KSPLITS * T * self.stride, device=dev, dtype=torch.float32)
         self.M = torch.zeros_like(self.P)
         self.V = torch.zeros_like(self.P)
         self.Pb = torch.zeros(T * self.stride, device=dev, dtype=torch.bfloat16)
@@ -211,8 +213,11 @@ class HipPackEngine(PackEngine):
         s.trial_index, s.spec, s.config = int(trial_index), spec, dict(config)
         s.layout = SlotLayout(spec, self.Fpad)
         s.epoch, s.step = 0, 0
-        for slab in (self.G, self.M, self.V):
+        for slab in (self.M, self.V):
             self._region(slab, slot).zero_()
+        for sp in range(MAX_KSPLITS):      # every partial-gradient slab: a previous tenant laid its tensors out differently
+            off = (sp * self.capacity + slot) * self.stride
+            self.G[off:off + self.stride].zero_()
         if state is not None and "model" in state:
             self._write_params(slot, s.layout, state["model"], self.P)
             opt = state.get("optimizer") or {}
@@ -266,8 +271,24 @@ class HipPackEngine(PackEngine):
     def _act_ptr(self, buf: torch.Tensor, slot: int, elem_bytes: int = 2) -> int:
         return buf.data_ptr() + slot * self.act_stride * elem_bytes
 
+    def _choose_ksplits(self) -> int:
+        """Split the wgrad contraction when the pack is too small to give every CU a weight-gradient tile."""
+        per_layer: Dict[int, int] = {}
+        for s in self.slots.values():
+            lay = s.layout
+            for l, h in enumerate(lay.hidden):
+                per_layer[l] = per_layer.get(l, 0) + ((h + TILE - 1) // TILE) * ((lay.in_dims[l] + TILE - 1) // TILE)
+        busiest = max(per_layer.values())
+        # measured on 512-wide layers: 4 splits win 1.4x at 128 tiles, nothing at 256, and every split
+        # costs the optimiser one more slab to read
+        if busiest <= 128:
+            return MAX_KSPLITS
+        return 2 if busiest <= 192 else 1
+
     def _build_gemm_tables(self, eval_mode: bool) -> Dict[str, Any]:
         Lmax = max(len(s.spec.hidden_sizes) for s in self.slots.values())
+        ksplits = 1 if eval_mode else self._choose_ksplits()
+        self._ksplits = ksplits
         T = self.capacity
         out: Dict[str, Any] = {"n_hidden": Lmax}
         p_base, pb_base, g_base = self.P.data_ptr(), self.Pb.data_ptr(), self.G.data_ptr()
@@ -309,7 +330,7 @@ class HipPackEngine(PackEngine):
             ft = balanced_tiles(fl)
             out[f"fwd{l}"] = (self._upload(f"{tag}fwd_g{l}", fwd), self._upload(f"{tag}fwd_t{l}", ft), len(ft))
             if not eval_mode:
-                dt, wt = balanced_tiles(dl), balanced_tiles(wl)
+                dt, wt = balanced_tiles(dl), balanced_tiles(wl, ksplits)
                 out[f"dgrad{l}"] = (self._upload(f"dg_g{l}", dg), self._upload(f"dg_t{l}", dt), len(dt))
                 out[f"wgrad{l}"] = (self._upload(f"wg_g{l}", wg), self._upload(f"wg_t{l}", wt), len(wt))
         return out
@@ -322,6 +343,7 @@ class HipPackEngine(PackEngine):
         plan.n_hidden, plan.n_active = gt["n_hidden"], len(ids)
         plan.active_ids = self._upload("eids" if eval_mode else "tids", ids)
         plan.head_scratch, plan.max_blocks = self.head_scratch.data_ptr(), self.max_blocks
+        plan.ksplits, plan.gsplit_stride = self._ksplits, self.capacity * self.stride
         plan.max_batch = max(s.spec.batch_size for s in self.slots.values())
         plan.max_width = max(max(s.spec.hidden_sizes) for s in self.slots.values())
         plan.max_params = max(s.layout.total for s in self.slots.values())

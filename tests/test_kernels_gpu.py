@@ -4,6 +4,7 @@ bf16 operands are generated as bf16-representable values, so the only difference
 reference is the f32 accumulation order (and the final bf16 rounding of bf16 outputs).
 """
 import ctypes as C
+import sys
 
 import numpy as np
 import pytest
@@ -40,6 +41,14 @@ def _rand_bf16(*shape, scale=1.0, gen=None):
     return (torch.randn(*shape, generator=gen, device="cuda") * scale).to(torch.bfloat16)
 
 
+NSTAGE = 0          # 0: launcher picks the pipeline depth; the parametrised test below forces both forms
+
+
+@pytest.fixture(params=[2, 4], autouse=True)
+def _both_pipeline_depths(request, monkeypatch):
+    monkeypatch.setattr(sys.modules[__name__], "NSTAGE", request.param)
+
+
 SHAPES = [(256, 128, 64), (512, 512, 512), (200, 72, 40), (128, 64, 8), (384, 256, 192), (130, 136, 520)]
 
 
@@ -60,7 +69,7 @@ def test_gemm_forward_nt(lib, relu):
     groups[len(SHAPES)]["active_steps"] = 0
     tiles = _tiles(L, dims)
     gt, tt = _up(groups), _up(tiles)
-    L.check(so.mt_gemm_launch(0, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, int(relu), 0, 0, _stream()), "gemm")
+    L.check(so.mt_gemm_launch(0, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, int(relu), 0, 0, 1, 0, NSTAGE, _stream()), "gemm")
     torch.cuda.synchronize()
     for (m, n, k), (x, w, b, y) in zip(SHAPES, keep):
         ref = x[:, :k].float() @ w[:, :k].float().t() + b
@@ -85,7 +94,7 @@ def test_gemm_forward_identity_asymmetric(lib):
     groups[0] = (x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, n, n, n, n, n, n, 0, 1)
     tiles = _tiles(L, [(0, n, n)])
     gt, tt = _up(groups), _up(tiles)
-    L.check(so.mt_gemm_launch(0, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, 0, 0, 0, _stream()), "gemm")
+    L.check(so.mt_gemm_launch(0, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, 0, 0, 0, 1, 0, NSTAGE, _stream()), "gemm")
     torch.cuda.synchronize()
     assert torch.equal(y.float(), w.float().t())
 
@@ -106,7 +115,7 @@ def test_gemm_dgrad_nn(lib, mask):
         keep.append((dy, w, h, dx)); dims.append((gi, m, k))
     tiles = _tiles(L, dims)
     gt, tt = _up(groups), _up(tiles)
-    L.check(so.mt_gemm_launch(1, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, int(mask), 0, 0, _stream()), "gemm")
+    L.check(so.mt_gemm_launch(1, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, int(mask), 0, 0, 1, 0, NSTAGE, _stream()), "gemm")
     torch.cuda.synchronize()
     for (m, n, k), (dy, w, h, dx) in zip(SHAPES, keep):
         ref = dy[:, :n].float() @ w[:, :k].float()
@@ -115,7 +124,8 @@ def test_gemm_dgrad_nn(lib, mask):
         torch.testing.assert_close(dx[:, :k].float(), ref, rtol=1e-2, atol=1e-2)
 
 
-def test_gemm_wgrad_tn(lib):
+@pytest.mark.parametrize("ksplits", [1, 3])
+def test_gemm_wgrad_tn(lib, ksplits):
     L, so = lib
     g = torch.Generator(device="cuda").manual_seed(3)
     groups = np.zeros(len(SHAPES), dtype=L.GEMM_GROUP_DTYPE)
@@ -124,15 +134,26 @@ def test_gemm_wgrad_tn(lib):
         ldk, ldn = (k + 7) // 8 * 8, (n + 7) // 8 * 8
         dy = torch.zeros(m, ldn, device="cuda", dtype=torch.bfloat16); dy[:, :n] = _rand_bf16(m, n, scale=0.1, gen=g)
         x = torch.zeros(m, ldk, device="cuda", dtype=torch.bfloat16); x[:, :k] = _rand_bf16(m, k, gen=g)
-        dw = torch.zeros(n, ldk, device="cuda")
-        db = torch.full((n,), 5.0, device="cuda")
-        groups[gi] = (dy.data_ptr(), x.data_ptr(), dw.data_ptr(), 0, db.data_ptr(), n, k, m, ldn, ldk, ldk, 0, 1)
-        keep.append((dy, x, dw, db)); dims.append((gi, n, k))
+        # one arena per group: [ksplits][dW | db]; the split stride is the same for every group
+        arena = torch.full((ksplits, 600 * 600), 5.0, device="cuda")
+        dw_all = arena[:, :n * ldk].view(ksplits, n, ldk)
+        dw_all.zero_()
+        db_all = arena[:, 590 * 600:590 * 600 + n]
+        groups[gi] = (dy.data_ptr(), x.data_ptr(), arena.data_ptr(), 0, db_all.data_ptr(), n, k, m, ldn, ldk, ldk, 0, 1)
+        keep.append((dy, x, dw_all, db_all)); dims.append((gi, n, k))
     tiles = _tiles(L, dims)
+    if ksplits > 1:
+        base = tiles[1:]
+        reps = []
+        for sp in range(ksplits):
+            t = base.copy(); t["ti"] = t["ti"] | (sp << 8); reps.append(t)
+        tiles = np.concatenate([tiles[:1]] + reps)
     gt, tt = _up(groups), _up(tiles)
-    L.check(so.mt_gemm_launch(2, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, 1, 0, 0, _stream()), "gemm")
+    L.check(so.mt_gemm_launch(2, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, 1, 0, 0, ksplits, 600 * 600, NSTAGE, _stream()),
+            "gemm")
     torch.cuda.synchronize()
-    for (m, n, k), (dy, x, dw, db) in zip(SHAPES, keep):
+    for (m, n, k), (dy, x, dw_all, db_all) in zip(SHAPES, keep):
+        dw, db = dw_all.sum(0), db_all.sum(0)
         ref = dy[:, :n].float().t() @ x[:, :k].float()
         torch.testing.assert_close(dw[:, :k], ref, rtol=2e-3, atol=2e-3)
         torch.testing.assert_close(db, dy[:, :n].float().sum(0), rtol=2e-3, atol=2e-3)
@@ -210,14 +231,15 @@ def test_head_loss(lib, loss, code):
 
 
 @pytest.mark.parametrize("name,code", [("adam", 0), ("adamw", 1), ("sgd", 2), ("rmsprop", 3)])
-@pytest.mark.parametrize("clip", [0.0, 0.5])
-def test_fused_optimizer_matches_torch(lib, name, code, clip):
+@pytest.mark.parametrize("clip,gsplits", [(0.0, 1), (0.5, 1), (0.5, 3)])
+def test_fused_optimizer_matches_torch(lib, name, code, clip, gsplits):
     L, so = lib
     from mitune.train.optim import build_optimizer
     g = torch.Generator(device="cuda").manual_seed(5)
     sizes, stride = [5000, 333, 2048], 6144
     T = len(sizes)
-    P = torch.zeros(T * stride, device="cuda"); G = torch.zeros_like(P); M = torch.zeros_like(P); V = torch.zeros_like(P)
+    P = torch.zeros(T * stride, device="cuda"); M = torch.zeros_like(P); V = torch.zeros_like(P)
+    G = torch.zeros(gsplits * T * stride, device="cuda")        # gradient slabs, summed by the kernel
     Pb = torch.zeros(T * stride, device="cuda", dtype=torch.bfloat16)
     hp = np.zeros(T, dtype=L.OPT_DTYPE)
     refs = []
@@ -235,7 +257,13 @@ def test_fused_optimizer_matches_torch(lib, name, code, clip):
     for step in range(5):
         for s, n in enumerate(sizes):
             gr = torch.randn(n, device="cuda", generator=g)
-            G[s * stride:s * stride + n] = gr
+            parts = torch.randn(gsplits, n, device="cuda", generator=g)
+            parts[0] = gr - parts[1:].sum(0)
+            gr = parts[0].clone()
+            for sp in range(1, gsplits):            # the kernel adds the slabs in this order
+                gr = gr + parts[sp]
+            for sp in range(gsplits):
+                G[(sp * T + s) * stride:(sp * T + s) * stride + n] = parts[sp]
             pr, opt = refs[s]
             pr.grad = gr.clone()
             if clip > 0:
@@ -243,7 +271,7 @@ def test_fused_optimizer_matches_torch(lib, name, code, clip):
             opt.step()
         L.check(so.mt_optim_launch(P.data_ptr(), G.data_ptr(), M.data_ptr(), V.data_ptr(), Pb.data_ptr(), stride,
                                    ht.data_ptr(), ids.data_ptr(), T, max(sizes), partials.data_ptr(), nb, int(clip > 0),
-                                   step, _stream()),
+                                   step, gsplits, T * stride, _stream()),
                 "optim")
     torch.cuda.synchronize()
     for s, n in enumerate(sizes):
