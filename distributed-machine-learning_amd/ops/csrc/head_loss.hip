@@ -31,7 +31,8 @@ __device__ __forceinline__ void loss_and_grad(int type, float out, float y, floa
 // Training: grid (row_chunks, active slots).  Workgroup (c, a) handles rows [c*HL_ROWS, (c+1)*HL_ROWS) of
 // slot ids[a] and writes one partial record {gw[0..W), gb, loss} to scratch; mt_head_reduce_kernel then adds
 // the records of a slot in chunk order (fixed order => bitwise reproducible, no float atomics).
-#define HL_ROWS 16
+#define HL_ROWS 32
+#define HL_RB 4          // rows a wave keeps in flight at once
 
 template <int NCHUNK>
 __global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSlot* __restrict__ slots,
@@ -63,39 +64,53 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSl
   const float inv_b = 1.f / (float)s.B;
   float loss_sum = 0.f, gb = 0.f;
 
-  for (int i = row_lo + wave; i < row_hi; i += HL_WAVES) {
-    u32x4 hv[NCHUNK];
-    float dot = 0.f;
+  // rows wave, wave+4, ... of the chunk; HL_RB of them are loaded before the first is reduced, so the
+  // row loads overlap instead of forming a chain of dependent memory round trips
+  for (int i0 = row_lo + wave; i0 < row_hi; i0 += HL_WAVES * HL_RB) {
+    u32x4 hv[HL_RB][NCHUNK];
 #pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) {
-      const int k0 = c * 512 + lane * 8;
-      hv[c] = u32x4{0u, 0u, 0u, 0u};
-      if (k0 < s.W) hv[c] = *reinterpret_cast<const u32x4*>(H + (size_t)i * s.ldh + k0);
+    for (int r = 0; r < HL_RB; ++r) {
+      const int i = i0 + r * HL_WAVES;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        dot += bf16_bits_to_f32(hv[c][e] & 0xFFFFu) * w[c][2 * e];
-        dot += bf16_bits_to_f32(hv[c][e] >> 16) * w[c][2 * e + 1];
+      for (int c = 0; c < NCHUNK; ++c) {
+        const int k0 = c * 512 + lane * 8;
+        const bool ok = (i < row_hi) && (k0 < s.W);
+        hv[r][c] = *reinterpret_cast<const u32x4*>(H + (ok ? ((size_t)i * s.ldh + k0) : (size_t)0));
+        if (!ok) hv[r][c] = u32x4{0u, 0u, 0u, 0u};
       }
     }
-    const float out = wave_sum(dot) + bias;
-    float l, g;
-    loss_and_grad(s.loss_type, out, s.y[i], l, g);
-    const float dout = g * inv_b;
-    loss_sum += l;
-    gb += dout;
 #pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) {
-      const int k0 = c * 512 + lane * 8;
-      if (k0 < s.W) {
-        u32x4 o;
+    for (int r = 0; r < HL_RB; ++r) {
+      const int i = i0 + r * HL_WAVES;
+      if (i >= row_hi) break;
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float h0 = bf16_bits_to_f32(hv[c][e] & 0xFFFFu), h1 = bf16_bits_to_f32(hv[c][e] >> 16);
-          gw[c][2 * e] += dout * h0;
-          gw[c][2 * e + 1] += dout * h1;
-          o[e] = pack_bf16x2(h0 > 0.f ? dout * w[c][2 * e] : 0.f, h1 > 0.f ? dout * w[c][2 * e + 1] : 0.f);
+          dot += bf16_bits_to_f32(hv[r][c][e] & 0xFFFFu) * w[c][2 * e];
+          dot += bf16_bits_to_f32(hv[r][c][e] >> 16) * w[c][2 * e + 1];
         }
-        *reinterpret_cast<u32x4*>(dH + (size_t)i * s.ldh + k0) = o;
+      const float out = wave_sum(dot) + bias;
+      float l, g;
+      loss_and_grad(s.loss_type, out, s.y[i], l, g);
+      const float dout = g * inv_b;
+      loss_sum += l;
+      gb += dout;
+#pragma unroll
+      for (int c = 0; c < NCHUNK; ++c) {
+        const int k0 = c * 512 + lane * 8;
+        if (k0 < s.W) {
+          u32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float h0 = bf16_bits_to_f32(hv[r][c][e] & 0xFFFFu), h1 = bf16_bits_to_f32(hv[r][c][e] >> 16);
+            gw[c][2 * e] += dout * h0;
+            gw[c][2 * e + 1] += dout * h1;
+            o[e] = pack_bf16x2(h0 > 0.f ? dout * w[c][2 * e] : 0.f, h1 > 0.f ? dout * w[c][2 * e + 1] : 0.f);
+          }
+          *reinterpret_cast<u32x4*>(dH + (size_t)i * s.ldh + k0) = o;
+        }
       }
     }
   }
@@ -127,7 +142,8 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_reduce_kernel(const MtHead
   for (int k = threadIdx.x; k < s.W + 2; k += HL_THREADS) {
     const int col = (k < s.W) ? k : rec - 2 + (k - s.W);
     float acc = 0.f;
-    for (int c = 0; c < nchunk; ++c) acc += base[(size_t)c * rec + col];
+#pragma unroll 8
+    for (int c = 0; c < nchunk; ++c) acc += base[(size_t)c * rec + col];     // independent loads, ordered adds
     if (k < s.W) s.gw[k] = acc;
     else if (k == s.W) s.gb[0] = acc;
     else s.loss_acc[0] += acc;
