@@ -126,7 +126,6 @@ class HipPackEngine(PackEngine):
             raise ValueError("max_layers <= 8 and max_width <= 2048")
         self.F = trainable.in_features
         self.Fpad = ceil8(self.F)
-        self.capacity = int(capacity or trainable.capacity or 256)
         dev = self.device
         # ---- datasets: f32 training table (gathered + converted per step), bf16 validation table
         self.Xtr = trainable.train[0].to(dev, torch.float32).contiguous()
@@ -137,6 +136,12 @@ class HipPackEngine(PackEngine):
         self.n_train, self.n_val = int(self.Xtr.shape[0]), int(self.Xva.shape[0])
         self.val_chunk = int(min(trainable.val_chunk, max(self.n_val, 1)))
         self.rows_max = max(self.max_batch, self.val_chunk)
+        if capacity or trainable.capacity:
+            self.capacity = int(capacity or trainable.capacity)
+        else:       # as many slots as the HBM budget allows (288 GB per MI355X), at most one full 256-trial pack
+            from ..utils.hbm import default_capacity
+            self.capacity = default_capacity(self.F, self.max_width, self.max_layers, self.rows_max, self.n_train,
+                                             self.n_val, trainable.hbm_budget_gb, hard_cap=256)
         # ---- slabs
         wp = ceil8(self.max_width)
         worst = SlotLayout(MLPTrialSpec(self.F, [self.max_width] * self.max_layers), self.Fpad)

@@ -81,6 +81,12 @@ class JsonLogger(Logger):
         if trial.logdir:
             os.makedirs(trial.logdir, exist_ok=True)
             dump_json(trial.config, os.path.join(trial.logdir, "params.json"))
+            try:       # the pickled twin keeps non-JSON values (tuples, numpy scalars) exactly
+                import pickle
+                with open(os.path.join(trial.logdir, "params.pkl"), "wb") as f:
+                    pickle.dump(trial.config, f)
+            except Exception:       # noqa: BLE001 - an unpicklable config value must not fail the trial
+                pass
 
     def on_result(self, trial, result):
         if trial.logdir:

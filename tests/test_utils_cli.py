@@ -1,0 +1,122 @@
+"""Utilities, ray-shaped import paths and the command line (CPU)."""
+import json
+import os
+import pickle
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import mitune
+from mitune import tune
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ray_shaped_import_paths():
+    from mitune.tune.schedulers import ASHAScheduler, AsyncHyperBandScheduler, PopulationBasedTraining, MedianStoppingRule, FIFOScheduler
+    from mitune.tune.suggest import BasicVariantGenerator, ConcurrencyLimiter
+    from mitune.tune.suggest.bayesopt import BayesOptSearch
+    assert ASHAScheduler is AsyncHyperBandScheduler
+    assert callable(BayesOptSearch) and callable(PopulationBasedTraining) and callable(MedianStoppingRule)
+    assert callable(FIFOScheduler) and callable(BasicVariantGenerator) and callable(ConcurrencyLimiter)
+
+
+def test_hbm_budget_is_monotone_and_capped():
+    from mitune.utils.hbm import default_capacity, mlp_pack_footprint
+    small = mlp_pack_footprint(64, 128, 3, 1024, 1000, 100)
+    big = mlp_pack_footprint(64, 512, 3, 4096, 1000, 100)
+    assert big.per_slot_bytes > small.per_slot_bytes > 0
+    assert default_capacity(64, 512, 3, 4096, 800_000, 200_000) == 1024            # hard cap
+    few = default_capacity(64, 8192, 4, 16384, 800_000, 200_000, budget_gb=40)
+    assert 1 <= few < 64
+    assert big.total(few) <= 40e9 or few == 1
+
+
+def test_phase_timer_accumulates():
+    from mitune.utils.timers import PhaseTimer
+    t = PhaseTimer()
+    for _ in range(3):
+        with t.phase("a"):
+            sum(range(1000))
+    with t.phase("b"):
+        pass
+    s = t.summary()
+    assert s["a"]["calls"] == 3 and s["b"]["calls"] == 1 and s["a"]["total_s"] >= 0
+
+
+def test_profiling_commands_respect_counter_limits():
+    from mitune.utils.profiling import PMC_PASSES, kernel_trace_cmd, pmc_cmd
+    limits = {"SQ_": 8, "TCC_": 4, "TCP_": 4, "TA_": 2, "TD_": 2, "GRBM_": 2}
+    for name, counters in PMC_PASSES.items():
+        for pre, lim in limits.items():
+            assert sum(c.startswith(pre) for c in counters) <= lim, name
+        cmd = pmc_cmd(["bench.py", "--steps", "1"], "out", name)
+        assert "--pmc" in cmd and "--sys-trace" not in cmd and "--runtime-trace" not in cmd
+        assert "python" in os.path.basename(cmd[cmd.index("--") + 1])      # the interpreter itself, no wrapper
+    k = kernel_trace_cmd(["bench.py"], "out")
+    assert "--kernel-trace" in k and "--stats" in k and "--pmc" not in k
+
+
+def test_seed_everything_reproducible():
+    from mitune.utils.seeding import seed_everything
+    seed_everything(7)
+    a = torch.rand(3)
+    seed_everything(7)
+    assert torch.equal(a, torch.rand(3))
+
+
+def test_params_pkl_written_next_to_params_json(tmp_path):
+    def f(config):
+        tune.report(loss=config["x"])
+    an = tune.run(f, config={"x": tune.uniform(0, 1), "shape": (2, 3)}, num_samples=1, local_dir=str(tmp_path), verbose=0)
+    d = an.trials[0].logdir
+    with open(os.path.join(d, "params.pkl"), "rb") as fh:
+        cfg = pickle.load(fh)        # a file this test wrote itself
+    assert cfg["shape"] == (2, 3)
+    assert json.load(open(os.path.join(d, "params.json")))["shape"] == [2, 3]
+
+
+def test_cli_info_and_analyze(tmp_path):
+    def f(config):
+        for i in range(2):
+            tune.report(loss=config["x"] + i)
+    tune.run(f, config={"x": tune.grid_search([3.0, 1.0, 2.0])}, local_dir=str(tmp_path), name="exp", metric="loss",
+             mode="min", verbose=0)
+    env = dict(os.environ, PYTHONPATH=REPO)
+    out = subprocess.run([sys.executable, "-m", "mitune", "analyze", str(tmp_path / "exp"), "--metric", "loss", "--mode",
+                          "min", "--top", "1"], capture_output=True, text=True, env=env, cwd=REPO, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "3 trials" in out.stdout and '"x": 1.0' in out.stdout.split("best config:")[1]
+    out = subprocess.run([sys.executable, "-m", "mitune", "info"], capture_output=True, text=True, env=env, cwd=REPO,
+                         timeout=120)
+    assert out.returncode == 0 and "kernel library" in out.stdout
+
+
+def test_diverged_trial_does_not_disturb_neighbours():
+    """One trial blowing up to NaN/inf must leave the other slots of the pack bit-identical."""
+    from mitune.packed import PackedTrainable
+    from mitune.packed.executor import PackedExecutor
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(512, 8, generator=g)
+    y = X[:, 0] - X[:, 1]
+    tr = PackedTrainable(train=(X[:384], y[:384]), val=(X[384:], y[384:]), max_epochs=3, engine="torch", dtype="f32",
+                         capacity=4, model_kwargs={"max_width": 32, "max_layers": 2, "max_batch": 64})
+
+    def search(lrs):
+        ex = PackedExecutor(tr, device=torch.device("cpu"), capacity=4, seed=0)
+        an = mitune.run(tr, config={"hidden_sizes": [32, 32], "batch_size": 64, "optimizer": "sgd",
+                                    "learning_rate": tune.grid_search(lrs)}, executor=ex, seed=0, verbose=0,
+                        local_dir=None, metric="validation_loss", mode="min")
+        return {t.config["learning_rate"]: t for t in an.trials}
+
+    clean = search([0.01, 0.02])
+    mixed = search([0.01, 0.02, 1e6])
+    bad = mixed[1e6].last_result["validation_loss"]
+    assert not (bad == bad and abs(bad) < 1e30)          # diverged: NaN or astronomically large
+    for lr in (0.01, 0.02):
+        assert mixed[lr].status == "TERMINATED"
+    best = min((t for t in mixed.values()), key=lambda t: t.last_result["validation_loss"]
+               if t.last_result["validation_loss"] == t.last_result["validation_loss"] else float("inf"))
+    assert best.config["learning_rate"] in (0.01, 0.02)
