@@ -12,6 +12,7 @@ and the next pending trials take it, so early stopping turns into throughput.
 """
 from __future__ import annotations
 
+import math
 import os
 import socket
 import time
@@ -68,11 +69,12 @@ class PackedExecutor(Executor):
         self._queued: List[Event] = []
         self._awaiting: Dict[str, Optional[str]] = {}          # trial_id -> decision (None = not yet)
         self._epoch_time = 0.0
+        self._diverged: set = set()
         self._t_total: Dict[str, float] = {}
         self.runner = None
         self.stats: Dict[str, Any] = {"epochs": 0, "slot_epochs": 0, "train_s": 0.0, "eval_s": 0.0,
                                       "comm_s": 0.0, "engine": self.engine.name, "world_size": self.world,
-                                      "capacity_per_gpu": self.capacity, "exploits": 0}
+                                      "capacity_per_gpu": self.capacity, "exploits": 0, "diverged": 0}
 
     def bind_runner(self, runner) -> None:
         self.runner = runner
@@ -137,6 +139,14 @@ class PackedExecutor(Executor):
         for row in rows.tolist():
             tr = by_index[int(row[0])]
             self._t_total[tr.trial_id] += self._epoch_time
+            diverged = not (math.isfinite(row[2]) and math.isfinite(row[3]))
+            if diverged and self.t.on_nonfinite == "error":
+                # every rank sees the same table, so every rank frees the same slot
+                self._drop(tr)
+                self.stats["diverged"] += 1
+                events.append(Event("error", tr, error=f"non-finite loss at epoch {int(row[1])}: "
+                                                       f"train_loss={row[2]}, validation_loss={row[3]}"))
+                continue
             result = {
                 "training_iteration": int(row[1]), "train_loss": row[2], "validation_loss": row[3],
                 "validation_mse": row[4], "validation_mape": row[5],
@@ -147,11 +157,19 @@ class PackedExecutor(Executor):
                 "iterations_since_restore": int(row[1]),
                 "rank": self._place[tr.trial_id][0], "slot": self._place[tr.trial_id][1],
             }
+            if diverged:
+                result["diverged"] = True
+                if self.t.on_nonfinite == "stop":
+                    self._diverged.add(tr.trial_id)
+                    self.stats["diverged"] += 1
             self._awaiting[tr.trial_id] = None
             events.append(Event("result", tr, result=result))
         return events
 
     def resolve(self, trial: Trial, decision: str) -> None:
+        if trial.trial_id in self._diverged:      # a NaN/inf slot is retired whatever the scheduler said
+            self._diverged.discard(trial.trial_id)
+            decision = STOP
         self._awaiting[trial.trial_id] = decision
         if all(d is not None for d in self._awaiting.values()):
             self._flush()
@@ -181,6 +199,14 @@ class PackedExecutor(Executor):
         if tr.logdir:
             keep = self.runner.keep_checkpoints_num if self.runner is not None else None
             ckpt.save_checkpoint(tr.logdir, tr.training_iteration, state, keep)
+
+    def _drop(self, tr: Trial) -> None:
+        owner, slot = self._place.pop(tr.trial_id)
+        if owner == self.rank:
+            self.engine.evict(slot)
+        self._free[owner].append(slot)
+        self._free[owner].sort()
+        self._live.pop(tr.trial_id)
 
     def _retire(self, tr: Trial) -> None:
         owner, slot = self._place.pop(tr.trial_id)

@@ -28,6 +28,7 @@ class PackedTrainable:
     val_chunk: int = 4096                                # validation rows per forward launch
     checkpoint_at_end: bool = False                      # write model.pt / optimizer.pt when a trial ends
     checkpoint_freq: int = 0                             # also every k epochs (0 = never)
+    on_nonfinite: str = "stop"                           # NaN/inf loss in a slot: "stop" | "error" | "ignore"
     name: str = "packed"
     model_kwargs: Dict[str, Any] = field(default_factory=dict)
 

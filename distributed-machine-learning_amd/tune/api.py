@@ -28,6 +28,7 @@ from typing import Any, Callable, Dict, List, Optional, Sequence, Union
 from .analysis import ExperimentAnalysis
 from .executor import Executor, ProcessExecutor, ThreadExecutor
 from .logger import DEFAULT_LOGGERS, Logger
+from .tbevents import TBXLogger
 from .runner import TrialRunner, TuneError
 from .trial import ERROR, PAUSED, PENDING, RUNNING, TERMINATED
 from ..schedulers.base import FIFOScheduler, TrialScheduler
@@ -189,7 +190,7 @@ def run(run_or_experiment: Any,
         raise ValueError(f"unknown executor {executor!r}")
 
     logger_objs: List[Logger] = []
-    for lg in (loggers if loggers is not None else (DEFAULT_LOGGERS if experiment_dir else ())):
+    for lg in (loggers if loggers is not None else (DEFAULT_LOGGERS + (TBXLogger,) if experiment_dir else ())):
         logger_objs.append(lg() if isinstance(lg, type) else lg)
 
     runner = TrialRunner(

@@ -10,6 +10,8 @@ expects to find there):
             params.json                    resolved config
             result.json                    JSON lines, one per report
             progress.csv                   same, tabular
+            events.out.tfevents.<ts>.<host>   same, as TensorBoard scalars (tune/tbevents.py)
+            params.pkl                     pickled config (keeps tuples / numpy scalars exactly)
             error.txt                      traceback if the trial failed
             checkpoint_<iter:06d>/         model.pt / optimizer.pt / meta.json
 """

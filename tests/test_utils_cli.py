@@ -115,8 +115,47 @@ def test_diverged_trial_does_not_disturb_neighbours():
     mixed = search([0.01, 0.02, 1e6])
     bad = mixed[1e6].last_result["validation_loss"]
     assert not (bad == bad and abs(bad) < 1e30)          # diverged: NaN or astronomically large
+    if bad != bad or bad == float("inf"):
+        assert mixed[1e6].last_result.get("diverged") and mixed[1e6].training_iteration < 3     # retired at once
     for lr in (0.01, 0.02):
-        assert mixed[lr].status == "TERMINATED"
+        assert mixed[lr].status == "TERMINATED" and mixed[lr].training_iteration == 3
+        # neighbours of the exploding slot trained exactly as they do without it
+        assert mixed[lr].last_result["validation_loss"] == clean[lr].last_result["validation_loss"]
     best = min((t for t in mixed.values()), key=lambda t: t.last_result["validation_loss"]
                if t.last_result["validation_loss"] == t.last_result["validation_loss"] else float("inf"))
     assert best.config["learning_rate"] in (0.01, 0.02)
+
+
+def test_nonfinite_slot_can_be_an_error():
+    from mitune.packed import PackedTrainable
+    from mitune.packed.executor import PackedExecutor
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(256, 8, generator=g)
+    y = X[:, 0].clone()
+    y[3] = float("nan")                       # a poisoned label makes every slot's loss NaN
+    tr = PackedTrainable(train=(X[:192], y[:192]), val=(X[192:], y[192:]), max_epochs=2, engine="torch", dtype="f32",
+                         capacity=2, on_nonfinite="error", model_kwargs={"max_width": 16, "max_layers": 1, "max_batch": 64})
+    ex = PackedExecutor(tr, device=torch.device("cpu"), capacity=2, seed=0)
+    an = mitune.run(tr, config={"hidden_sizes": [16], "batch_size": 64, "learning_rate": tune.grid_search([0.01, 0.02])},
+                    executor=ex, seed=0, verbose=0, local_dir=None, metric="validation_loss", mode="min",
+                    raise_on_failed_trial=False)
+    assert [t.status for t in an.trials] == ["ERROR", "ERROR"]
+    assert "non-finite" in an.trials[0].error_msg and ex.stats["diverged"] == 2
+
+
+def test_tensorboard_event_file_round_trip(tmp_path):
+    import glob
+    from mitune.tune.tbevents import crc32c, read_scalars
+
+    assert crc32c(b"123456789") == 0xE3069283            # the CRC-32C check value
+
+    def f(config):
+        for i in range(3):
+            tune.report(loss=config["x"] * (i + 1), acc=0.5)
+    an = tune.run(f, config={"x": 2.0}, num_samples=1, local_dir=str(tmp_path), verbose=0)
+    files = glob.glob(os.path.join(an.trials[0].logdir, "events.out.tfevents.*"))
+    assert len(files) == 1
+    sc = read_scalars(files[0])                            # verifies both checksums of every record
+    losses = [(s, v) for s, tag, v in sc if tag == "ray/tune/loss"]
+    assert losses == [(1, 2.0), (2, 4.0), (3, 6.0)]
+    assert any(tag == "ray/tune/time_total_s" for _, tag, _ in sc)
