@@ -44,18 +44,23 @@ def main():
     ap.add_argument("--trials", type=int, default=256)
     ap.add_argument("--max-t", type=int, default=16)
     ap.add_argument("--full-rows", type=int, default=1_000_000)
+    ap.add_argument("--device", default="cpu", help="cpu (the reference's path here) or cuda (eager PyTorch, one trial "
+                                                    "at a time on the MI355X: the reference's execution model on this GPU)")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
-    (Xtr, ytr), (Xva, yva) = headline.make_data(int(args.rows / 0.8), 64, "cpu")
+    dev = torch.device(args.device)
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    (Xtr, ytr), (Xva, yva) = headline.make_data(int(args.rows / 0.8), 64, dev)
     cfgs = list(sp.generate_variants(headline.search_space(), args.configs, seed=0))
     t_train, t_val = [], []
     for cfg in cfgs:
         spec = MLPTrialSpec.from_config(cfg, 64)
-        model = MLPRegressor(64, spec.hidden_sizes)
+        model = MLPRegressor(64, spec.hidden_sizes).to(dev)
         opt = torch.optim.AdamW(model.parameters(), lr=spec.learning_rate, weight_decay=spec.weight_decay)
         crit = torch.nn.MSELoss()
         n = Xtr.shape[0] // spec.batch_size * spec.batch_size
-        perm = torch.randperm(Xtr.shape[0])[:n]
+        perm = torch.randperm(Xtr.shape[0], device=dev)[:n]
+        sync()
         t0 = time.perf_counter()
         for i in range(0, n, spec.batch_size):
             idx = perm[i:i + spec.batch_size]
@@ -63,10 +68,12 @@ def main():
             loss = crit(model(Xtr[idx]), ytr[idx])
             loss.backward()
             opt.step()
+        sync()
         t1 = time.perf_counter()
         with torch.no_grad():
             for c0 in range(0, Xva.shape[0], 4096):
                 crit(model(Xva[c0:c0 + 4096]), yva[c0:c0 + 4096])
+        sync()
         t2 = time.perf_counter()
         t_train.append((t1 - t0) / n)
         t_val.append((t2 - t1) / Xva.shape[0])
@@ -76,7 +83,7 @@ def main():
     per_epoch = float(np.mean(t_train)) * train_rows + float(np.mean(t_val)) * val_rows
     epochs = asha_trial_epochs(args.trials, args.max_t)
     total_s = per_epoch * epochs
-    out = {"metric": "trials_completed_per_hour", "engine": "pytorch-eager-cpu", "threads": args.threads,
+    out = {"metric": "trials_completed_per_hour", "engine": f"pytorch-eager-{dev.type}", "threads": args.threads,
            "configs_timed": args.configs, "rows_timed": int(Xtr.shape[0]),
            "us_per_train_row": 1e6 * float(np.mean(t_train)), "us_per_val_row": 1e6 * float(np.mean(t_val)),
            "seconds_per_trial_epoch_800k": per_epoch, "trial_epochs": epochs, "search_seconds_sequential": total_s,
