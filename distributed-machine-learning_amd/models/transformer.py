@@ -22,8 +22,9 @@ hyper-parameter is live and every combination runs:
 * ``SimpleTransformerModel``  - the sample script's model: projection -> stock post-norm encoder
   (dff = 4 d) -> last token -> ``Linear(d, 1)`` (/root/reference/ray-tune-hpo-regression-sample.py:60-83).
 
-Attention math goes through ``mitune.ops.attention.short_attention`` which runs the fused HIP
-short-sequence kernel on a GPU and plain PyTorch elsewhere.
+Attention, dropout+residual+LayerNorm, PE add + dropout, the depthwise convolution and the regression
+head go through ``mitune.ops`` which runs hand-written HIP kernels on a GPU and plain PyTorch elsewhere;
+the remaining dense projections are library GEMMs.
 """
 from __future__ import annotations
 
@@ -35,6 +36,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops.attention import short_attention
+from ..ops.elementwise import depthwise_conv1d, pe_add_dropout
+from ..ops.head_mlp import head_mlp
 from ..ops.layernorm import residual_layer_norm
 
 ATTENTION_TYPES = ("scaled_dot_product", "multi_head_attention", "linear_attention")
@@ -60,7 +63,7 @@ class PositionalEncoding(nn.Module):
         s = x.size(1)
         if s > self.pe.size(0):      # a table sized by a hyper-parameter must never bound the data
             self.pe = sinusoid_table(s, self.d_model).to(self.pe.device)
-        return self.drop(x + self.pe[:s].to(x.dtype))
+        return pe_add_dropout(x, self.pe, self.drop.p, self.training)
 
 
 class DepthwiseSeparableConv(nn.Module):
@@ -74,10 +77,10 @@ class DepthwiseSeparableConv(nn.Module):
         self.pointwise = nn.Conv1d(d_model, dim_feedforward, 1)
         self.project = nn.Conv1d(dim_feedforward, d_model, 1)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:          # [B, S, d]
-        y = self.depthwise(x.transpose(1, 2))
-        y = self.project(F.relu(self.pointwise(y)))
-        return y.transpose(1, 2)
+    def forward(self, x: torch.Tensor) -> torch.Tensor:          # [B, S, d], channel-last throughout
+        y = depthwise_conv1d(x, self.depthwise.weight, self.depthwise.bias)
+        y = F.relu(F.linear(y, self.pointwise.weight.squeeze(-1), self.pointwise.bias))     # k=1 conv == linear
+        return F.linear(y, self.project.weight.squeeze(-1), self.project.bias)
 
 
 def _split_heads(t: torch.Tensor, h: int) -> torch.Tensor:       # [B, S, h*dh] -> [B, h, S, dh]
@@ -135,7 +138,7 @@ class LinearAttention(SelfAttention):
     def _mix(self, v: torch.Tensor) -> torch.Tensor:
         if self.local is None:
             return v
-        return v + self.local(v.transpose(1, 2)).transpose(1, 2)
+        return v + depthwise_conv1d(v, self.local.weight, self.local.bias)
 
 
 def build_attention(attention_type: str, d_model: int, num_heads: int, dropout: float, attn_kernel_size: int,
@@ -215,10 +218,9 @@ class TransformerModel(nn.Module):
         for i in range(self.num_encoder_layers):
             layer = self.layers[0] if self.shared_weights else self.layers[i]
             x = layer(x, drop_path=self.drop_rates[i])
-        h = x[:, -1, :]
-        for fc in (self.fc1, self.fc2, self.fc3, self.fc4):
-            h = F.relu(fc(h))
-        return self.fc5(h)                   # [B, 1]
+        fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5)
+        # last token of every sequence; the slice is a strided view that the fused head reads in place
+        return head_mlp(x[:, -1, :], [fc.weight for fc in fcs], [fc.bias for fc in fcs])      # [B, 1]
 
 
 class _PostNormLayer(nn.Module):

@@ -1,0 +1,46 @@
+"""Small fused ops of the Transformer path: positional-encoding add + dropout, channel-last depthwise conv1d.
+
+``pe_add_dropout``  <-> /root/reference/ray-tune-hpo-regression.py:53-54 (``x + pe[:S]`` then dropout)
+``depthwise_conv1d`` <-> /root/reference/ray-tune-hpo-regression.py:68,79-82 (``Conv1d(d, d, k, groups=d)``
+between two transposes)
+
+On a GPU both run as hand-written kernels (``csrc/posenc.hip``, ``csrc/conv1d.hip``) that work on the
+``[B, S, d]`` layout the encoder keeps, so no transpose and no mask tensor is ever materialised; elsewhere
+the plain PyTorch forms below are used (they are also the numerics references of the kernel tests).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+
+def pe_add_dropout_reference(x: torch.Tensor, pe: torch.Tensor, keep: Optional[torch.Tensor] = None, p: float = 0.0):
+    y = x + pe[: x.shape[1]].to(x.dtype)
+    if keep is not None:
+        y = y * keep.to(y.dtype) / (1.0 - p)
+    return y
+
+
+def pe_add_dropout(x: torch.Tensor, pe: torch.Tensor, p: float = 0.0, training: bool = False) -> torch.Tensor:
+    p = float(p) if training else 0.0
+    if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0:
+        from .elementwise_hip import FusedPosEncDropout
+        seed = torch.randint(0, 2 ** 31 - 1, (1,), device=x.device, dtype=torch.int64) if p > 0.0 else None
+        return FusedPosEncDropout.apply(x, pe, seed, p)
+    return F.dropout(x + pe[: x.shape[1]].to(x.dtype), p, training=p > 0.0)
+
+
+def depthwise_conv1d_reference(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """x [B, S, d]; weight [d, 1, k] (the ``nn.Conv1d(groups=d)`` parameter) or [d, k]; returns [B, S, d]."""
+    w = weight.reshape(weight.shape[0], 1, -1)
+    return F.conv1d(x.transpose(1, 2), w, bias, padding=w.shape[-1] // 2, groups=w.shape[0]).transpose(1, 2)
+
+
+def depthwise_conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    k = weight.shape[-1]
+    if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and k % 2 == 1 and k <= 7:
+        from .elementwise_hip import FusedDepthwiseConv1d
+        return FusedDepthwiseConv1d.apply(x, weight, bias)
+    return depthwise_conv1d_reference(x, weight, bias)

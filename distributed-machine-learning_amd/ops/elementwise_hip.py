@@ -1,0 +1,76 @@
+"""Autograd bindings of ``csrc/posenc.hip`` and ``csrc/conv1d.hip``."""
+from __future__ import annotations
+
+import torch
+
+from . import lib as L
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class FusedPosEncDropout(torch.autograd.Function):
+    """``dropout(x + pe[:S])`` with the keep mask recomputed from a device-resident seed in backward."""
+
+    @staticmethod
+    def forward(ctx, x, pe, seed, p: float):
+        so = L.load()
+        B, S, d = x.shape
+        if pe.shape[0] < S or pe.shape[1] != d:
+            raise ValueError(f"positional table {tuple(pe.shape)} does not cover a [{S}, {d}] sequence")
+        xc, pec = x.contiguous(), pe.contiguous().float()
+        y = torch.empty_like(xc)
+        L.check(so.mt_posenc_fwd_launch(xc.data_ptr(), pec.data_ptr(), y.data_ptr(), B * S, S, d,
+                                        seed.data_ptr() if seed is not None else None, float(p), _stream(x)),
+                "mt_posenc_fwd_launch")
+        ctx.seed, ctx.p = seed, float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        so = L.load()
+        dyc = dy.contiguous()
+        B, S, d = dyc.shape
+        dx = torch.empty_like(dyc)
+        L.check(so.mt_posenc_bwd_launch(dyc.data_ptr(), dx.data_ptr(), B * S, d,
+                                        ctx.seed.data_ptr() if ctx.seed is not None else None, ctx.p, _stream(dy)),
+                "mt_posenc_bwd_launch")
+        return dx, None, None, None
+
+
+class FusedDepthwiseConv1d(torch.autograd.Function):
+    """Depthwise conv over time on ``[B, S, d]`` without transposes; weight is ``[d, 1, k]`` or ``[d, k]``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        so = L.load()
+        B, S, d = x.shape
+        k = weight.shape[-1]
+        xc = x.contiguous()
+        w = weight.reshape(d, k).contiguous()
+        y = torch.empty_like(xc)
+        L.check(so.mt_dwconv_launch(xc.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                    y.data_ptr(), B * S, S, d, k, 0, _stream(x)), "mt_dwconv_launch")
+        ctx.save_for_backward(xc, w)
+        ctx.meta = (weight.shape, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        so = L.load()
+        xc, w = ctx.saved_tensors
+        wshape, has_bias = ctx.meta
+        B, S, d = xc.shape
+        k = w.shape[1]
+        dyc = dy.contiguous()
+        dx = torch.empty_like(xc)
+        L.check(so.mt_dwconv_launch(dyc.data_ptr(), w.data_ptr(), None, dx.data_ptr(), B * S, S, d, k, 1, _stream(dy)),
+                "mt_dwconv_launch(dx)")
+        chunks = int(so.mt_dwconv_chunks(B * S))
+        part = torch.empty(chunks, k + 1, d, device=xc.device, dtype=torch.float32)
+        L.check(so.mt_dwconv_wgrad_launch(xc.data_ptr(), dyc.data_ptr(), part.data_ptr(), B * S, S, d, k, _stream(dy)),
+                "mt_dwconv_wgrad_launch")
+        g = part.sum(0)                                   # [k + 1, d], fixed summation order
+        dw = g[:k].t().reshape(wshape)
+        return dx, dw, (g[k] if has_bias else None)

@@ -65,6 +65,22 @@ class MlpPlan(C.Structure):
                 ("gsplit_stride", c_size_t)]
 
 
+HM_MAXL = 5
+
+
+class FlatOpt(C.Structure):
+    """Device-resident optimiser record of ``csrc/flat_optim.hip`` (hyper-parameters + step counter)."""
+    _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("wd", c_float),
+                ("momentum", c_float), ("clip", c_float), ("opt_type", c_int32), ("warmup", c_int32),
+                ("total", c_int32), ("step", c_int32), ("pad", c_int32)]
+
+
+class HeadMlp(C.Structure):
+    _fields_ = [("W", c_void_p * HM_MAXL), ("b", c_void_p * HM_MAXL), ("dW", c_void_p * HM_MAXL),
+                ("db", c_void_p * HM_MAXL), ("dims", c_int32 * (HM_MAXL + 1)), ("n_layers", c_int32),
+                ("act_stride", c_int32), ("dz_stride", c_int32)]
+
+
 # numpy views of the same layouts, for building whole descriptor tables vectorised
 GEMM_GROUP_DTYPE = np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("aux", "<u8"), ("aux_out", "<u8"),
                              ("I", "<i4"), ("J", "<i4"), ("KK", "<i4"), ("lda", "<i4"), ("ldb", "<i4"),
@@ -144,6 +160,22 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_ln_bwd_blocks.argtypes = [C.c_int]
     for fn in (lib.mt_attn_fwd_launch, lib.mt_attn_bwd_launch, lib.mt_ln_fwd_launch, lib.mt_ln_bwd_launch,
                lib.mt_ln_bwd_blocks):
+        fn.restype = C.c_int
+    if lib.mt_flat_opt_sizeof() != C.sizeof(FlatOpt) or lib.mt_head_mlp_sizeof() != C.sizeof(HeadMlp):
+        raise KernelLibraryError("FlatOpt / HeadMlp layout mismatch between lib.py and the library")
+    lib.mt_flat_optim_blocks.argtypes = [C.c_long]
+    lib.mt_flat_optim_launch.argtypes = [c_void_p] * 4 + [C.c_long, c_void_p, c_void_p, C.c_int, C.c_int, c_void_p]
+    lib.mt_posenc_fwd_launch.argtypes = [c_void_p] * 3 + [C.c_long, C.c_int, C.c_int, c_void_p, c_float, c_void_p]
+    lib.mt_posenc_bwd_launch.argtypes = [c_void_p] * 2 + [C.c_long, C.c_int, c_void_p, c_float, c_void_p]
+    lib.mt_dwconv_chunks.argtypes = [C.c_long]
+    lib.mt_dwconv_launch.argtypes = [c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_dwconv_wgrad_launch.argtypes = [c_void_p] * 3 + [C.c_long, C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_head_mlp_fwd_launch.argtypes = [C.POINTER(HeadMlp), c_void_p, C.c_long, c_void_p, c_void_p, C.c_int, c_void_p]
+    lib.mt_head_mlp_bwd_launch.argtypes = [C.POINTER(HeadMlp), c_void_p, C.c_long, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           C.c_long, C.c_int, c_void_p]
+    for fn in (lib.mt_flat_optim_blocks, lib.mt_flat_optim_launch, lib.mt_posenc_fwd_launch, lib.mt_posenc_bwd_launch,
+               lib.mt_dwconv_chunks, lib.mt_dwconv_launch, lib.mt_dwconv_wgrad_launch, lib.mt_head_mlp_fwd_launch,
+               lib.mt_head_mlp_bwd_launch):
         fn.restype = C.c_int
     lib.mt_mlp_train_steps.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]
     lib.mt_mlp_eval.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]

@@ -96,6 +96,49 @@ def _fit(model: torch.nn.Module, config: Dict, data_loader, val_loader, epochs: 
     return model
 
 
+def _device_tensors(loader, device: torch.device):
+    """The loader's whole dataset as device tensors, or None when it is not a plain TensorDataset."""
+    ds = getattr(loader, "dataset", None)
+    tensors = getattr(ds, "tensors", None)
+    if tensors is None or len(tensors) != 2:
+        return None
+    return tensors[0].to(device, non_blocking=True), tensors[1].to(device, non_blocking=True)
+
+
+def _fit_graphed(model, config: Dict, data_loader, val_loader, epochs: int, criterion, device: torch.device,
+                 opt_name: str, lr: float, weight_decay: float, momentum: float = 0.9, clip: float = 0.0,
+                 warmup: int = 0, total: int = 0, report_checkpoints: bool = True) -> bool:
+    """GPU path: device-resident data, flat parameters, fused optimiser, hipGraph-replayed steps.
+
+    Returns False (having done nothing) when the loaders do not wrap plain tensors; the caller then runs the
+    eager loop.
+    """
+    from .graphed import FlatOptimizer, FlatParams, GraphedTrainer
+    train_t, val_t = _device_tensors(data_loader, device), _device_tensors(val_loader, device)
+    if train_t is None or val_t is None:
+        return False
+    flat = FlatParams(model)
+    opt = FlatOptimizer(flat, opt_name, lr, weight_decay, momentum, clip=clip, warmup=warmup, total=total)
+    start = _resume(model, opt)
+    opt.set_hyper(lr, weight_decay)           # PBT may have perturbed these since the checkpoint was taken
+    bs = int(getattr(data_loader, "batch_size", None) or 32)
+    trainer = GraphedTrainer(model, criterion, train_t[0], train_t[1], bs, opt, shuffle=True,
+                             seed=int(config.get("seed", 0)), use_graph=bool(config.get("hip_graph", True)))
+    for epoch in range(start, epochs):
+        train_loss = trainer.train_epoch()
+        metrics = trainer.evaluate(val_t[0], val_t[1], mape_eps=MAPE_EPS)
+        metrics["train_loss"] = train_loss
+        metrics["graphed"] = trainer.graphed
+        log.info("epoch %d  train_loss %.5f  validation_loss %.5f", epoch + 1, train_loss, metrics["validation_loss"])
+        ckpt = None
+        if report_checkpoints:
+            ckpt = {"model": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                    "optimizer": opt.state_dict(), "epoch": epoch + 1}
+        if session.is_session_enabled():
+            session.report(metrics, checkpoint=ckpt)
+    return True
+
+
 def _resume(model, optimizer) -> int:
     ck = session.get_checkpoint()
     if not ck or "model" not in ck:
@@ -104,7 +147,7 @@ def _resume(model, optimizer) -> int:
     try:
         if ck.get("optimizer"):
             optimizer.load_state_dict(ck["optimizer"])
-    except (ValueError, KeyError):
+    except (ValueError, KeyError, TypeError, AttributeError):
         pass       # e.g. PBT changed the optimiser family: keep fresh moments
     return int(ck.get("epoch", 0))
 
@@ -122,12 +165,15 @@ def train_dummy_model(config: Dict, data_loader, val_loader, epochs: int = 5) ->
     device = pick_device(config)
     model = SimpleTransformerModel(_infer_input_size(data_loader), config["d_model"], config["num_heads"],
                                    config["num_layers"], config.get("dropout", 0.1)).to(device)
+    n_epochs = int(config.get("epochs", epochs))
+    if device.type == "cuda" and _fit_graphed(model, config, data_loader, val_loader, n_epochs, torch.nn.MSELoss(), device,
+                                              "adamw", config["learning_rate"], config.get("weight_decay", 0.0)):
+        return
     opt = torch.optim.AdamW(model.parameters(), lr=config["learning_rate"], weight_decay=config.get("weight_decay", 0.0))
     start = _resume(model, opt)
     for g in opt.param_groups:            # PBT may have perturbed these since the checkpoint was taken
         g["lr"], g["weight_decay"] = config["learning_rate"], config.get("weight_decay", 0.0)
-    _fit(model, config, data_loader, val_loader, int(config.get("epochs", epochs)), opt, None,
-         torch.nn.MSELoss(), device, start_epoch=start)
+    _fit(model, config, data_loader, val_loader, n_epochs, opt, None, torch.nn.MSELoss(), device, start_epoch=start)
 
 
 def train_transformer_model(config: Dict, data_loader, val_loader, epochs: int = 20) -> None:
@@ -149,9 +195,6 @@ def train_transformer_model(config: Dict, data_loader, val_loader, epochs: int =
         key_dim_scaling=float(config.get("key_dim_scaling", 1.0)),
         shared_weights=bool(config.get("shared_weights", False)),
         stochastic_depth_rate=float(config.get("stochastic_depth_rate", 0.0))).to(device)
-    opt = build_optimizer(config.get("optimizer", "adamw"), model.parameters(), float(config["learning_rate"]),
-                          float(config.get("weight_decay", 0.0)), float(config.get("momentum", 0.9)))
-    start = _resume(model, opt)
     n_epochs = int(config.get("epochs", epochs))
     steps_per_epoch = max(1, len(data_loader))
     warm = int(config.get("warmup_steps", 0))
@@ -159,10 +202,18 @@ def train_transformer_model(config: Dict, data_loader, val_loader, epochs: int =
     # the search space's step counts are sized for long runs; never let the decay end before training does
     total = max(total, n_epochs * steps_per_epoch) if total else 0
     warm = min(warm, max(1, (n_epochs * steps_per_epoch) // 4)) if warm else 0
+    criterion = get_criterion(config.get("loss_function", "mse"))
+    if device.type == "cuda" and _fit_graphed(
+            model, config, data_loader, val_loader, n_epochs, criterion, device, config.get("optimizer", "adamw"),
+            float(config["learning_rate"]), float(config.get("weight_decay", 0.0)), float(config.get("momentum", 0.9)),
+            clip=float(config.get("gradient_clipping", 0.0)), warmup=warm, total=total):
+        return
+    opt = build_optimizer(config.get("optimizer", "adamw"), model.parameters(), float(config["learning_rate"]),
+                          float(config.get("weight_decay", 0.0)), float(config.get("momentum", 0.9)))
+    start = _resume(model, opt)
     sched = warmup_decay_scheduler(opt, warm, total) if (warm or total) else None
     if sched is not None:
         for _ in range(start * steps_per_epoch):
             sched.step()
-    _fit(model, config, data_loader, val_loader, n_epochs, opt, sched,
-         get_criterion(config.get("loss_function", "mse")), device,
+    _fit(model, config, data_loader, val_loader, n_epochs, opt, sched, criterion, device,
          clip=float(config.get("gradient_clipping", 0.0)), start_epoch=start)

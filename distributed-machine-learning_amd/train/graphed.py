@@ -1,0 +1,227 @@
+"""Single-trial training on the GPU without per-step host work: flat parameters, a device-state optimiser and a
+hipGraph-captured training step.
+
+The reference's loop (/root/reference/ray-tune-hpo-regression-sample.py:110-120 and
+/root/reference/ray-tune-hpo-regression.py:322-345) pays, per optimiser step, a DataLoader batch on the CPU, a
+host-to-device copy, a few hundred eager kernel launches of a tiny model and a ``loss.item()`` synchronisation.
+For models this small the GPU idles between launches.  Here:
+
+* the dataset lives on the device; a batch is an ``index_select`` with indices taken from a device-resident
+  permutation at a device-resident cursor;
+* all parameters are views of ONE f32 slab and all gradients views of a twin slab (``FlatParams``), so the
+  optimiser is one launch of ``csrc/flat_optim.hip`` whose learning rate, schedule and step counter are read
+  from device memory (``FlatOptimizer``) -- nothing about a step is a host-side value;
+* forward + loss + backward + clip + update + cursor advance are captured ONCE into a hipGraph and replayed for
+  every batch of every epoch (``GraphedTrainer``); the host reads one scalar per epoch.
+
+Dropout keeps drawing fresh masks under replay because every random op inside the step takes its seed/offset
+from the generator state that graph capture registers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import threading
+from typing import Callable, Dict, Optional
+
+import torch
+
+from .optim import OPT_CODES
+
+log = logging.getLogger("mitune")
+
+# one capture at a time per process
+_CAPTURE_LOCK = threading.Lock()
+# Set by the thread executor when several trial threads share one GPU: HIP stream capture is invalidated by
+# device work issued from sibling threads, so such trials step eagerly (each on its own stream) instead.
+SHARED_GPU_THREADS = False
+
+_ALIGN = 8        # parameter offsets in the slab are multiples of 8 floats (32 bytes)
+
+
+class FlatParams:
+    """Re-homes a module's trainable parameters into one contiguous f32 slab (and gradients into another)."""
+
+    def __init__(self, model: torch.nn.Module):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("model has no trainable parameters")
+        dev = self.params[0].device
+        offs, n = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("FlatParams needs f32 parameters")
+            offs.append(n)
+            n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.n, self.offsets = n, offs
+        self.P = torch.zeros(n, device=dev)
+        self.G = torch.zeros(n, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                self.P[o:o + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = self.P[o:o + p.numel()].view(p.shape)
+                p.grad = self.G[o:o + p.numel()].view(p.shape)     # autograd accumulates in place into the slab
+
+
+class FlatOptimizer:
+    """Adam / AdamW / SGD(momentum) / RMSprop(momentum) over a ``FlatParams`` slab, state on the device."""
+
+    def __init__(self, flat: FlatParams, name: str = "adamw", lr: float = 1e-3, weight_decay: float = 0.0,
+                 momentum: float = 0.9, betas=(0.9, 0.999), eps: float = 1e-8, clip: float = 0.0, warmup: int = 0,
+                 total: int = 0):
+        from ..ops import lib as L
+        self.so = L.load()
+        self.L = L
+        self.flat = flat
+        self.name = name.lower()
+        dev = flat.P.device
+        self.M = torch.zeros_like(flat.P)
+        self.V = torch.zeros_like(flat.P)
+        rec = L.FlatOpt(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, wd=weight_decay,
+                        momentum=momentum if self.name in ("sgd", "rmsprop") else 0.0, clip=max(0.0, clip),
+                        opt_type=OPT_CODES[self.name], warmup=int(warmup), total=int(total), step=0, pad=0)
+        self.state = torch.frombuffer(bytearray(bytes(rec)), dtype=torch.uint8).to(dev)
+        self._f32 = self.state.view(torch.float32)
+        self._i32 = self.state.view(torch.int32)
+        self.use_clip = clip > 0.0
+        nb = int(self.so.mt_flat_optim_blocks(flat.n))
+        self.partials = torch.zeros(max(nb, 1), device=dev)
+
+    # field slots of the FlatOpt record (4-byte words)
+    _LR, _WD, _STEP = 0, 4, 10
+
+    def set_hyper(self, lr: Optional[float] = None, weight_decay: Optional[float] = None) -> None:
+        if lr is not None:
+            self._f32[self._LR:self._LR + 1].fill_(float(lr))
+        if weight_decay is not None:
+            self._f32[self._WD:self._WD + 1].fill_(float(weight_decay))
+
+    def step(self) -> None:
+        f = self.flat
+        self.L.check(self.so.mt_flat_optim_launch(f.P.data_ptr(), f.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                                  f.n, self.state.data_ptr(), self.partials.data_ptr(),
+                                                  1 if self.use_clip else 0, 1,
+                                                  torch.cuda.current_stream(f.P.device).cuda_stream),
+                     "mt_flat_optim_launch")
+
+    def zero_grad(self) -> None:      # the update kernel already zeroes the slab; this is for completeness
+        self.flat.G.zero_()
+
+    @property
+    def steps_taken(self) -> int:
+        return int(self._i32[self._STEP].item())
+
+    def state_dict(self) -> Dict:
+        return {"flat": True, "name": self.name, "record": self.state.cpu().clone(), "M": self.M.cpu().clone(),
+                "V": self.V.cpu().clone()}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        if not sd.get("flat") or sd["M"].numel() != self.M.numel() or sd.get("name") != self.name:
+            raise ValueError("optimizer state does not match this flat optimizer")
+        self.M.copy_(sd["M"])
+        self.V.copy_(sd["V"])
+        self._i32[self._STEP:self._STEP + 1].copy_(sd["record"].view(torch.int32)[self._STEP:self._STEP + 1])
+
+
+class GraphedTrainer:
+    """Epochs of graph-replayed optimiser steps over a device-resident dataset.
+
+    ``X`` [N, ...] and ``Y`` [N, ...] must already be on the model's device.  One call of ``train_epoch`` shuffles
+    (a device ``randperm``), replays the captured step ``N // batch_size`` times, runs a ragged last batch eagerly
+    (kept, like a DataLoader without ``drop_last``) and returns the mean batch loss with one synchronisation.
+    """
+
+    def __init__(self, model: torch.nn.Module, criterion: Callable, X: torch.Tensor, Y: torch.Tensor, batch_size: int,
+                 optimizer: FlatOptimizer, shuffle: bool = True, seed: int = 0, use_graph: bool = True):
+        self.model, self.criterion, self.opt = model, criterion, optimizer
+        self.X, self.Y = X, Y
+        self.N, self.B = int(X.shape[0]), int(min(batch_size, X.shape[0]))
+        dev = X.device
+        self.shuffle = shuffle
+        self.gen = torch.Generator(device=dev).manual_seed(int(seed))
+        self.perm = torch.arange(self.N, device=dev)
+        self.ar = torch.arange(self.B, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.running = torch.zeros((), device=dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.graphed = False
+        if use_graph and not SHARED_GPU_THREADS and dev.type == "cuda" and self.N >= self.B:
+            try:
+                self._capture()
+                self.graphed = True
+            except Exception as e:       # noqa: BLE001 - fall back to eager stepping, loudly
+                log.warning("hipGraph capture of the training step failed (%s: %s); stepping eagerly",
+                            type(e).__name__, e)
+                self.graph = None
+                torch.cuda.synchronize(dev)
+
+    # ------------------------------------------------------------------ one optimiser step
+    def _step(self, rows: torch.Tensor) -> None:
+        x = self.X.index_select(0, rows)
+        y = self.Y.index_select(0, rows)
+        out = self.model(x).reshape(y.shape)
+        loss = self.criterion(out, y)
+        loss.backward()
+        self.opt.step()
+        self.running += loss.detach()
+
+    def _cursor_step(self) -> None:
+        self._step(self.perm.index_select(0, self.ar + self.pos))
+        self.pos += self.B
+
+    def _capture(self) -> None:
+        f, o = self.opt.flat, self.opt
+        keep = (f.P.clone(), o.M.clone(), o.V.clone(), o.state.clone())
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        self.model.train()
+        with torch.cuda.stream(side):          # warm-up off the caller's stream (allocator, lazy init, autotune)
+            for _ in range(2):
+                self.pos.zero_()
+                self._cursor_step()
+        cur.wait_stream(side)
+        with torch.no_grad():                  # undo the warm-up steps: training starts from the initial weights
+            f.P.copy_(keep[0]); o.M.copy_(keep[1]); o.V.copy_(keep[2]); o.state.copy_(keep[3])
+            f.G.zero_(); self.pos.zero_(); self.running.zero_()
+        cur.synchronize()                      # stream-level only: a device-wide wait would disturb other threads
+        g = torch.cuda.CUDAGraph()
+        with _CAPTURE_LOCK:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._cursor_step()
+        self.graph = g
+
+    # ------------------------------------------------------------------ epochs
+    def train_epoch(self) -> float:
+        self.model.train()
+        if self.shuffle:
+            self.perm.copy_(torch.randperm(self.N, device=self.perm.device, generator=self.gen))
+        self.pos.zero_()
+        self.running.zero_()
+        n_full = self.N // self.B
+        if self.graph is not None:
+            for _ in range(n_full):
+                self.graph.replay()
+        else:
+            for _ in range(n_full):
+                self._cursor_step()
+        batches = n_full
+        if self.N % self.B:
+            self._step(self.perm[n_full * self.B:])
+            batches += 1
+        return float(self.running) / max(batches, 1)
+
+    @torch.no_grad()
+    def evaluate(self, Xv: torch.Tensor, Yv: torch.Tensor, chunk: int = 4096, mape_eps: float = 1e-8) -> Dict[str, float]:
+        """Sample-weighted validation loss and MAPE over the whole validation set in large chunks."""
+        self.model.eval()
+        n = int(Xv.shape[0])
+        loss_sum = torch.zeros((), device=Xv.device, dtype=torch.float64)
+        ape_sum = torch.zeros((), device=Xv.device, dtype=torch.float64)
+        for c0 in range(0, n, chunk):
+            x, y = Xv[c0:c0 + chunk], Yv[c0:c0 + chunk]
+            out = self.model(x).reshape(y.shape)
+            loss_sum += self.criterion(out, y).double() * y.numel()
+            ape_sum += (torch.abs(y - out) / (torch.abs(y) + mape_eps)).sum().double()
+        both = torch.stack([loss_sum, ape_sum]).tolist()       # one synchronisation
+        return {"validation_loss": both[0] / max(n, 1), "validation_mape": 100.0 * both[1] / max(n, 1)}

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import multiprocessing as mp
 import os
+import contextlib
 import queue
 import threading
 import traceback
@@ -101,6 +102,16 @@ class ThreadExecutor(Executor):
     def num_running(self) -> int:
         return len(self._threads)
 
+    def _stream_scope(self):
+        """Trials that share a GPU (fractional ``gpu``) each run on a HIP stream of their own, so their kernels
+        overlap instead of queueing behind each other on the default stream."""
+        if 0 < self.gpus_per < 1 and self.gpu_ids:
+            import torch
+            from ..train import graphed
+            graphed.SHARED_GPU_THREADS = True      # graph capture is not safe while sibling threads use the device
+            return torch.cuda.stream(torch.cuda.Stream())
+        return contextlib.nullcontext()
+
     def start_trial(self, trial: Trial) -> None:
         reply: "queue.Queue[str]" = queue.Queue()
         self._replies[trial.trial_id] = reply
@@ -117,7 +128,8 @@ class ThreadExecutor(Executor):
                 time_offset=float(trial.last_result.get("time_total_s", 0.0)))
             _session._set_session(sess)
             try:
-                self.trainable(trial.config)
+                with self._stream_scope():
+                    self.trainable(trial.config)
                 self._events.put(Event("done", trial))
             except _session.StopTrial as st:
                 self._events.put(Event("done", trial, result={"decision": st.decision}))
