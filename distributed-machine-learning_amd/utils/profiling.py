@@ -12,13 +12,12 @@ import sys
 from typing import Dict, List, Sequence
 
 PMC_PASSES: Dict[str, List[str]] = {
-    "mfma_valu": ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16",
-                  "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY"],
-    "lds": ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY",
-            "SQ_ACTIVE_INST_LDS", "SQ_LDS_UNALIGNED_STALL", "SQ_LDS_ADDR_CONFLICT"],
+    "mfma": ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU",
+             "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"],
+    "lds": ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS",
+            "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_UNALIGNED_STALL", "SQ_INSTS_VMEM"],
     "hbm_read": ["FETCH_SIZE", "TCC_HIT_sum"],
-    "hbm_write": ["WRITE_SIZE", "TCC_MISS_sum", "TCC_EA0_ATOMIC_sum"],
-    "clock": ["GRBM_GUI_ACTIVE", "GRBM_COUNT"],
+    "hbm_write": ["WRITE_SIZE", "TCC_MISS_sum", "TCC_REQ_sum"],
 }
 
 
