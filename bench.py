@@ -94,8 +94,15 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
-        comm = TorchDistComm(backend="nccl")
-        device = comm.device
+        # RCCL over xGMI; MITUNE_COMM_BACKEND=gloo rehearses the multi-process path on a box with fewer GPUs than ranks
+        backend = os.environ.get("MITUNE_COMM_BACKEND", "nccl")
+        if backend == "nccl":
+            comm = TorchDistComm(backend="nccl")
+            device = comm.device
+        else:
+            comm = TorchDistComm(backend=backend)
+            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+            torch.cuda.set_device(device)
     else:
         device = torch.device("cuda", 0)
         torch.cuda.set_device(device)

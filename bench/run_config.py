@@ -114,7 +114,7 @@ def config5(args):
     dev = comm.device
     train, val = tabular_regression(args.rows5, 64, seed=5, device=dev)
     pop = args.population * comm.world_size
-    tr = PackedTrainable(model="ft_transformer", train=train, val=val, max_epochs=args.steps5, engine="torch",
+    tr = PackedTrainable(model="ft_transformer", train=train, val=val, max_epochs=args.steps5, engine=args.engine5,
                          dtype="bf16", capacity=args.population, name="config5_ft",
                          model_kwargs={"d_token": 192, "n_blocks": 3, "n_heads": 8})
     ex = PackedExecutor(tr, comm=comm, device=dev, capacity=args.population, seed=0)
@@ -129,9 +129,12 @@ def config5(args):
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
+    if an.best_result is None:
+        raise RuntimeError(f"no finite result: {[t.last_result for t in an.trials][:3]} stats={an.stats}")
     out = {"config": 5, "n_gpus": comm.world_size, "population": pop, "epochs": args.steps5, "rows": args.rows5,
            "elapsed_s": el, "trials_per_hour": pop / el * 3600, "exploits": an.stats["exploits"],
-           "best_validation_mse": an.best_result["validation_mse"], "dtype": "bf16"}
+           "best_validation_mse": an.best_result["validation_mse"], "dtype": "bf16",
+           "engine": an.stats["engine"]}
     comm.close()
     return out if comm.rank == 0 else None
 
@@ -147,6 +150,7 @@ def main():
     ap.add_argument("--rows5", type=int, default=200_000)
     ap.add_argument("--steps5", type=int, default=6)
     ap.add_argument("--population", type=int, default=8)
+    ap.add_argument("--engine5", default="auto", help="config 5 engine: auto (graph on a GPU) | graph | torch")
     ap.add_argument("--local-dir", default=None)
     ap.add_argument("--verbose", type=int, default=0)
     args = ap.parse_args()

@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .transformer import SelfAttention
+from ..ops.elementwise import dropout
 from ..ops.layernorm import residual_layer_norm
 
 
@@ -43,7 +44,7 @@ class ReGLU(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         a, g = self.up(x).chunk(2, dim=-1)
-        return self.down(F.dropout(a * F.relu(g), self.p, self.training))
+        return self.down(dropout(a * F.relu(g), self.p, self.training))
 
 
 class FTBlock(nn.Module):

@@ -36,7 +36,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops.attention import short_attention
-from ..ops.elementwise import depthwise_conv1d, pe_add_dropout
+from ..ops.elementwise import depthwise_conv1d, dropout, pe_add_dropout
 from ..ops.head_mlp import head_mlp
 from ..ops.layernorm import residual_layer_norm
 
@@ -172,7 +172,8 @@ class CustomEncoderLayer(nn.Module):
         if not self.training or rate <= 0.0:
             return None
         keep = 1.0 - rate
-        return torch.bernoulli(torch.full((x.size(0), 1, 1), keep, device=x.device, dtype=x.dtype)) / keep
+        from ..ops.elementwise import keep_mask
+        return keep_mask((x.size(0), 1, 1), rate, x.device).to(x.dtype) / keep
 
     def forward(self, src: torch.Tensor, drop_path: Optional[float] = None) -> torch.Tensor:
         rate = self.drop_path if drop_path is None else drop_path
@@ -239,7 +240,7 @@ class _PostNormLayer(nn.Module):
         p = self.p if self.training else 0.0
         a, _ = self.self_attn(x)
         x = residual_layer_norm(a, x, self.norm1.weight, self.norm1.bias, self.norm1.eps, dropout_p=p)
-        f = self.linear2(F.dropout(F.relu(self.linear1(x)), p, self.training))
+        f = self.linear2(dropout(F.relu(self.linear1(x)), p, self.training))
         return residual_layer_norm(f, x, self.norm2.weight, self.norm2.bias, self.norm2.eps, dropout_p=p)
 
 

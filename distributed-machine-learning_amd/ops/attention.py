@@ -56,7 +56,8 @@ def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kind: str
     keep = None
     if dropout_p > 0.0:
         shape = q.shape[:-1] + (k.shape[-2],)
-        keep = torch.bernoulli(torch.full(shape, 1.0 - dropout_p, device=q.device, dtype=torch.float32))
+        from .elementwise import keep_mask
+        keep = keep_mask(shape, dropout_p, q.device)
     if _hip_ok(q, k, v):
         from .attention_hip import FusedShortAttention, available
         if available():

@@ -1,0 +1,77 @@
+// Counter-based dropout for the Transformer path (gfx950): keep masks and fused dropout without the
+// framework's random-number generator.
+//
+// Element i is kept iff hash(seed, i) >= p * 2^32, with the 64-bit seed read from DEVICE memory at execution
+// time.  Nothing about a mask is a host-side value, so a training step captured in a hipGraph draws fresh
+// masks on every replay (the caller bumps the device counter inside the captured step), and the backward pass
+// recomputes the forward's mask from the same seed snapshot instead of storing it.
+//
+//   mt_keep_mask_launch     uint8 mask [n] (1 = keep) for kernels that take a mask operand (attention, LayerNorm)
+//   mt_dropout_launch       y = keep ? x / (1 - p) : 0 for f32 or bf16 data; the same call with dy gives dx
+#include "mt_common.h"
+
+__device__ __forceinline__ uint32_t dr_hash(uint32_t s0, uint32_t s1, uint32_t i) {
+  return mt_mix32(i * 0x9E3779B9u + s0) ^ mt_mix32((i >> 5) + s1 * 0x85EBCA6Bu + 0x27D4EB2Fu);
+}
+
+__global__ __launch_bounds__(256) void mt_keep_mask_kernel(uint8_t* __restrict__ out, long n, const int64_t* __restrict__ seed,
+                                                           uint32_t thresh) {
+  const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const uint64_t s = (uint64_t)seed[0];
+  const uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+  uint32_t w = 0u;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w |= (dr_hash(s0, s1, (uint32_t)(i4 + e)) >= thresh ? 1u : 0u) << (8 * e);
+  if (i4 + 4 <= n) *reinterpret_cast<uint32_t*>(out + i4) = w;
+  else for (long e = i4; e < n; ++e) out[e] = (uint8_t)((w >> (8 * (e - i4))) & 0xFFu);
+}
+
+template <typename T> struct DrIO;
+template <> struct DrIO<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct DrIO<uint16_t> {   // bf16 bits
+  static __device__ __forceinline__ float ld(const uint16_t* p) { return bf16_bits_to_f32(*p); }
+  static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = (uint16_t)f32_to_bf16_bits(v); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void mt_dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long n,
+                                                         const int64_t* __restrict__ seed, uint32_t thresh, float scale) {
+  const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const uint64_t s = (uint64_t)seed[0];
+  const uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+  const int cnt = (n - i4) < 4 ? (int)(n - i4) : 4;
+  for (int e = 0; e < cnt; ++e) {
+    const float v = DrIO<T>::ld(x + i4 + e);
+    DrIO<T>::st(y + i4 + e, dr_hash(s0, s1, (uint32_t)(i4 + e)) >= thresh ? v * scale : 0.f);
+  }
+}
+
+static inline uint32_t dr_thresh(float p) { return (uint32_t)((double)p * 4294967296.0); }
+
+extern "C" int mt_keep_mask_launch(void* out, long n, const int64_t* seed, float p, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (seed == nullptr || p < 0.f || p >= 1.f) return -2;
+  hipLaunchKernelGGL(mt_keep_mask_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, (uint8_t*)out, n, seed,
+                     dr_thresh(p));
+  return (int)hipGetLastError();
+}
+
+// dtype: 0 = f32, 1 = bf16.  x and y may alias.
+extern "C" int mt_dropout_launch(const void* x, void* y, long n, const int64_t* seed, float p, int dtype, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (seed == nullptr || p < 0.f || p >= 1.f) return -2;
+  dim3 grid((unsigned)((n + 1023) / 1024)), block(256);
+  const float scale = 1.f / (1.f - p);
+  if (dtype == 0)
+    hipLaunchKernelGGL(mt_dropout_kernel<float>, grid, block, 0, stream, (const float*)x, (float*)y, n, seed, dr_thresh(p), scale);
+  else if (dtype == 1)
+    hipLaunchKernelGGL(mt_dropout_kernel<uint16_t>, grid, block, 0, stream, (const uint16_t*)x, (uint16_t*)y, n, seed,
+                       dr_thresh(p), scale);
+  else return -2;
+  return (int)hipGetLastError();
+}

@@ -27,8 +27,8 @@ def pe_add_dropout(x: torch.Tensor, pe: torch.Tensor, p: float = 0.0, training: 
     p = float(p) if training else 0.0
     if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0:
         from .elementwise_hip import FusedPosEncDropout
-        seed = torch.randint(0, 2 ** 31 - 1, (1,), device=x.device, dtype=torch.int64) if p > 0.0 else None
-        return FusedPosEncDropout.apply(x, pe, seed, p)
+        from .rng import next_seed
+        return FusedPosEncDropout.apply(x, pe, next_seed(x.device) if p > 0.0 else None, p)
     return F.dropout(x + pe[: x.shape[1]].to(x.dtype), p, training=p > 0.0)
 
 
@@ -44,3 +44,23 @@ def depthwise_conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
         from .elementwise_hip import FusedDepthwiseConv1d
         return FusedDepthwiseConv1d.apply(x, weight, bias)
     return depthwise_conv1d_reference(x, weight, bias)
+
+
+def keep_mask(shape, p: float, device) -> torch.Tensor:
+    """0/1 keep mask with keep probability ``1 - p``: uint8 from the counter-based kernel on a GPU, float elsewhere."""
+    device = torch.device(device)
+    if device.type == "cuda":
+        from .elementwise_hip import hip_keep_mask
+        return hip_keep_mask(tuple(shape), float(p), device)
+    return torch.bernoulli(torch.full(tuple(shape), 1.0 - p, device=device, dtype=torch.float32))
+
+
+def dropout(x: torch.Tensor, p: float, training: bool = True) -> torch.Tensor:
+    """``F.dropout`` whose GPU path draws from the device counter (no mask tensor; backward recomputes the mask)."""
+    if not training or p <= 0.0:
+        return x
+    if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+        from .elementwise_hip import FusedDropout
+        from .rng import next_seed
+        return FusedDropout.apply(x, next_seed(x.device), float(p))
+    return F.dropout(x, p, True)

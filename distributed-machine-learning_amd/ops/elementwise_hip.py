@@ -74,3 +74,34 @@ class FusedDepthwiseConv1d(torch.autograd.Function):
         g = part.sum(0)                                   # [k + 1, d], fixed summation order
         dw = g[:k].t().reshape(wshape)
         return dx, dw, (g[k] if has_bias else None)
+
+
+def hip_keep_mask(shape, p: float, device) -> torch.Tensor:
+    from .rng import next_seed
+    so = L.load()
+    out = torch.empty(shape, dtype=torch.uint8, device=device)
+    seed = next_seed(device)
+    L.check(so.mt_keep_mask_launch(out.data_ptr(), out.numel(), seed.data_ptr(), p,
+                                   torch.cuda.current_stream(device).cuda_stream), "mt_keep_mask_launch")
+    return out
+
+
+class FusedDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seed, p: float):
+        so = L.load()
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        L.check(so.mt_dropout_launch(xc.data_ptr(), y.data_ptr(), xc.numel(), seed.data_ptr(), p,
+                                     0 if x.dtype == torch.float32 else 1, _stream(x)), "mt_dropout_launch")
+        ctx.seed, ctx.p = seed, p
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        so = L.load()
+        dyc = dy.contiguous()
+        dx = torch.empty_like(dyc)
+        L.check(so.mt_dropout_launch(dyc.data_ptr(), dx.data_ptr(), dyc.numel(), ctx.seed.data_ptr(), ctx.p,
+                                     0 if dy.dtype == torch.float32 else 1, _stream(dy)), "mt_dropout_launch(bwd)")
+        return dx, None, None

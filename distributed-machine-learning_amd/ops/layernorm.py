@@ -26,7 +26,8 @@ def residual_layer_norm(x: torch.Tensor, residual: torch.Tensor, weight: torch.T
                         eps: float = 1e-5, dropout_p: float = 0.0) -> torch.Tensor:
     keep = None
     if dropout_p > 0.0:
-        keep = torch.bernoulli(torch.full(x.shape, 1.0 - dropout_p, device=x.device, dtype=torch.float32))
+        from .elementwise import keep_mask
+        keep = keep_mask(x.shape, dropout_p, x.device)
     if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 2048 and x.shape[-1] % 4 == 0:
         from .layernorm_hip import FusedResidualLayerNorm, available
         if available():

@@ -35,9 +35,15 @@ _REC = 6   # trial_index, epoch, train_loss, validation_loss, validation_mse, va
 def make_engine(trainable: PackedTrainable, device: torch.device, capacity: Optional[int], seed: int) -> PackEngine:
     kind = trainable.engine
     if kind == "auto":
-        # the grouped-GEMM engine packs MLP trials; other families run slot by slot on the same device
-        # (their attention / LayerNorm still go through the fused HIP kernels)
-        kind = "hip" if (device.type == "cuda" and trainable.model == "mlp") else "torch"
+        # the grouped-GEMM engine packs MLP trials; other families run slot by slot on the same device, each
+        # slot's training step captured in a hipGraph (fused attention / LayerNorm / optimiser kernels inside)
+        if device.type == "cuda":
+            kind = "hip" if trainable.model == "mlp" else "graph"
+        else:
+            kind = "torch"
+    if kind == "graph":
+        from .engine_graph import GraphPackEngine
+        return GraphPackEngine(trainable, str(device), capacity, seed)
     if kind == "torch":
         return TorchPackEngine(trainable, str(device), capacity, seed)
     if kind == "hip":

@@ -19,6 +19,7 @@ from the generator state that graph capture registers.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import logging
 import threading
@@ -132,8 +133,11 @@ class GraphedTrainer:
     """
 
     def __init__(self, model: torch.nn.Module, criterion: Callable, X: torch.Tensor, Y: torch.Tensor, batch_size: int,
-                 optimizer: FlatOptimizer, shuffle: bool = True, seed: int = 0, use_graph: bool = True):
+                 optimizer: FlatOptimizer, shuffle: bool = True, seed: int = 0, use_graph: bool = True,
+                 drop_last: bool = False, forward_ctx: Optional[Callable] = None):
         self.model, self.criterion, self.opt = model, criterion, optimizer
+        self.drop_last = drop_last
+        self.forward_ctx = forward_ctx or contextlib.nullcontext      # e.g. a bf16 autocast factory
         self.X, self.Y = X, Y
         self.N, self.B = int(X.shape[0]), int(min(batch_size, X.shape[0]))
         dev = X.device
@@ -159,8 +163,9 @@ class GraphedTrainer:
     def _step(self, rows: torch.Tensor) -> None:
         x = self.X.index_select(0, rows)
         y = self.Y.index_select(0, rows)
-        out = self.model(x).reshape(y.shape)
-        loss = self.criterion(out, y)
+        with self.forward_ctx():
+            out = self.model(x)
+        loss = self.criterion(out.float().reshape(y.shape), y)
         loss.backward()
         self.opt.step()
         self.running += loss.detach()
@@ -206,7 +211,7 @@ class GraphedTrainer:
             for _ in range(n_full):
                 self._cursor_step()
         batches = n_full
-        if self.N % self.B:
+        if self.N % self.B and not self.drop_last:
             self._step(self.perm[n_full * self.B:])
             batches += 1
         return float(self.running) / max(batches, 1)
@@ -220,7 +225,9 @@ class GraphedTrainer:
         ape_sum = torch.zeros((), device=Xv.device, dtype=torch.float64)
         for c0 in range(0, n, chunk):
             x, y = Xv[c0:c0 + chunk], Yv[c0:c0 + chunk]
-            out = self.model(x).reshape(y.shape)
+            with self.forward_ctx():
+                out = self.model(x)
+            out = out.float().reshape(y.shape)
             loss_sum += self.criterion(out, y).double() * y.numel()
             ape_sum += (torch.abs(y - out) / (torch.abs(y) + mape_eps)).sum().double()
         both = torch.stack([loss_sum, ape_sum]).tolist()       # one synchronisation

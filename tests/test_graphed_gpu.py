@@ -199,3 +199,107 @@ def test_sample_workflow_runs_graphed_on_gpu(tmp_path):
     assert len(an.trials) == 3 and all(t.status == "TERMINATED" for t in an.trials)
     assert all(t.last_result["graphed"] for t in an.trials)
     assert an.best_config is not None
+
+
+# ------------------------------------------------------------------ graph pack engine (FT-Transformer slots)
+def _ft_trainable(engine):
+    from mitune.data import tabular_regression
+    from mitune.packed import PackedTrainable
+    train, val = tabular_regression(4096, 16, seed=3, device=DEV)
+    return PackedTrainable(model="ft_transformer", train=train, val=val, max_epochs=2, engine=engine, dtype="bf16",
+                           capacity=4, model_kwargs={"d_token": 32, "n_blocks": 1, "n_heads": 4})
+
+
+def test_graph_pack_engine_is_slot_invariant_and_matches_eager():
+    from mitune.packed.engine import TorchPackEngine
+    from mitune.packed.engine_graph import GraphPackEngine
+    cfg = {"learning_rate": 2e-3, "weight_decay": 1e-4, "batch_size": 256, "optimizer": "adamw"}
+    tr = _ft_trainable("graph")
+    res = {}
+    for slot in (0, 3):
+        eng = GraphPackEngine(tr, DEV, 4, seed=0)
+        eng.load(slot, 5, cfg)
+        if slot == 3:
+            eng.load(0, 9, dict(cfg, learning_rate=5e-3))           # a neighbour must not matter
+        for _ in range(2):
+            eng.train_epoch()
+        res[slot] = eng.evaluate()[slot]
+        assert eng._trainers[slot].graphed
+    assert abs(res[0]["validation_mse"] - res[3]["validation_mse"]) <= 2e-3 * res[0]["validation_mse"]
+    ref = TorchPackEngine(_ft_trainable("torch"), DEV, 4, seed=0)
+    ref.load(0, 5, cfg)
+    for _ in range(2):
+        ref.train_epoch()
+    want = ref.evaluate()[0]
+    assert abs(res[0]["validation_mse"] - want["validation_mse"]) <= 0.1 * want["validation_mse"]      # bf16 autocast
+    assert res[0]["validation_mse"] < 1.0
+
+
+def test_graph_pack_engine_pbt_clone_and_search():
+    import mitune
+    from mitune import tune
+    from mitune.packed.executor import PackedExecutor
+    from mitune.schedulers import PopulationBasedTraining
+    tr = _ft_trainable("auto")
+    tr.max_epochs = 4
+    ex = PackedExecutor(tr, device=torch.device(DEV), capacity=4, seed=0)
+    assert ex.engine.name == "graph"
+    pbt = PopulationBasedTraining(metric="validation_loss", mode="min", perturbation_interval=1,
+                                  hyperparam_mutations={"learning_rate": tune.loguniform(1e-4, 1e-2)},
+                                  quantile_fraction=0.25, seed=0)
+    an = mitune.run(tr, config={"learning_rate": tune.loguniform(1e-4, 1e-2), "batch_size": 256, "optimizer": "adamw"},
+                    num_samples=4, scheduler=pbt, executor=ex, seed=0, verbose=0, local_dir=None)
+    assert len(an.trials) == 4 and all(t.training_iteration == 4 for t in an.trials)
+    assert an.stats["exploits"] >= 1
+    assert math.isfinite(an.best_result["validation_mse"])
+
+
+# ------------------------------------------------------------------ counter-based dropout
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_counter_dropout_forward_backward_share_the_mask(dtype):
+    from mitune.ops import rng
+    from mitune.ops.elementwise import dropout
+    p = 0.3
+    x = (_rand(257, 131).abs() + 0.5).to(dtype).requires_grad_()       # odd sizes: exercises the ragged tail
+    rng.seed_all(11)
+    y = dropout(x, p, True)
+    kept = y != 0
+    assert abs(kept.float().mean().item() - (1 - p)) < 0.01
+    assert torch.allclose(y[kept].float(), (x.detach()[kept].float() / (1 - p)), rtol=1e-2 if dtype == torch.bfloat16 else 1e-6)
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad != 0, kept)
+    y2 = dropout(x, p, True)
+    assert not torch.equal(y2 != 0, kept)                                # the counter moved
+    rng.seed_all(11)
+    assert torch.equal(dropout(x, p, True) != 0, kept)                   # and is reproducible when pinned
+    assert dropout(x, p, False) is x
+
+
+def test_keep_mask_statistics():
+    from mitune.ops.elementwise import keep_mask
+    m = keep_mask((64, 8, 65, 65), 0.2, torch.device(DEV))
+    assert m.dtype == torch.uint8 and set(m.unique().tolist()) <= {0, 1}
+    f = m.float()
+    assert abs(f.mean().item() - 0.8) < 0.005
+    assert (f.mean(dim=(0, 1, 2)) - 0.8).abs().max() < 0.03              # no column structure
+    assert (f.mean(dim=(1, 2, 3)) - 0.8).abs().max() < 0.03
+    a, b = f[..., :-1].flatten(), f[..., 1:].flatten()                   # neighbours uncorrelated
+    assert abs(((a - 0.8) * (b - 0.8)).mean().item()) < 0.002
+
+
+def test_many_graphs_with_dropout_and_eager_work_between_epochs_stay_finite():
+    """Three captured slots with dropout, eager validation between epochs: the scenario that produced NaNs with the
+    framework generator's graph-registered state."""
+    from mitune.data import tabular_regression
+    from mitune.packed import PackedTrainable
+    from mitune.packed.engine_graph import GraphPackEngine
+    train, val = tabular_regression(40960, 64, seed=5, device=DEV)
+    tr = PackedTrainable(model="ft_transformer", train=train, val=val, max_epochs=2, engine="graph", dtype="bf16", capacity=3,
+                         model_kwargs={"d_token": 192, "n_blocks": 3, "n_heads": 8})
+    eng = GraphPackEngine(tr, DEV, 3, seed=0)
+    for i in range(3):
+        eng.load(i, i, {"learning_rate": 3e-4, "weight_decay": 1e-5, "batch_size": 1024, "optimizer": "adamw"})
+    for _ in range(2):
+        eng.train_epoch()
+        ev = eng.evaluate()
+        assert all(math.isfinite(v["validation_mse"]) and math.isfinite(v["train_loss"]) for v in ev.values())
