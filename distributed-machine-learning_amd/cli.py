@@ -1,6 +1,6 @@
 """Command line: ``python -m mitune <command>``.
 
-    python -m mitune build [--force]                 compile ops/csrc/*.hip for gfx950 into ops/libmitune_hip.so
+    python -m mitune build [--force] [--sanitize]    compile ops/csrc/*.hip for gfx950 into ops/libmitune_hip.so
     python -m mitune run SCRIPT [args...]            run an experiment script (sets up sys.path, prints the best config)
     python -m mitune analyze EXPERIMENT_DIR [--metric M --mode min|max --top N]
     python -m mitune info                            devices, library status, HBM budget for the default pack shape
@@ -19,6 +19,9 @@ import sys
 
 def _cmd_build(args) -> int:
     from .ops import build
+    if args.sanitize:
+        print(build.build_sanitized())
+        return 0
     print(build.build(force=args.force))
     return 0
 
@@ -65,7 +68,9 @@ def _cmd_info(args) -> int:
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="mitune")
     sub = ap.add_subparsers(dest="cmd", required=True)
-    b = sub.add_parser("build"); b.add_argument("--force", action="store_true"); b.set_defaults(fn=_cmd_build)
+    b = sub.add_parser("build"); b.add_argument("--force", action="store_true")
+    b.add_argument("--sanitize", action="store_true", help="host-side ASan/UBSan build (libmitune_hip_asan.so)")
+    b.set_defaults(fn=_cmd_build)
     r = sub.add_parser("run"); r.add_argument("script"); r.add_argument("script_args", nargs=argparse.REMAINDER)
     r.set_defaults(fn=_cmd_run)
     a = sub.add_parser("analyze"); a.add_argument("experiment_dir"); a.add_argument("--metric"); a.add_argument("--mode")

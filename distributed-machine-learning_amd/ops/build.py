@@ -61,6 +61,23 @@ def build(force: bool = False, verbose: bool = True, extra_flags: List[str] | No
     return LIB
 
 
+def build_sanitized(verbose: bool = True) -> str:
+    """Host-side AddressSanitizer + UBSan build of the launchers and the step driver (``libmitune_hip_asan.so``).
+
+    Only the host half is instrumented (``-Xarch_host -fsanitize=...``); device code is compiled as usual.  Load it
+    with ``LD_PRELOAD=$(clang -print-file-name=libclang_rt.asan-x86_64.so)`` to screen descriptor handling and
+    launch-argument code on a CPU-only machine; it is never the library the framework loads by default.
+    """
+    out = os.path.join(HERE, "libmitune_hip_asan.so")
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+           "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined", "-Xarch_host",
+           "-fno-omit-frame-pointer", "-o", out] + sources()
+    if verbose:
+        print("[mitune] " + " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
