@@ -29,7 +29,7 @@ def up(arr):
 
 
 class Problem:
-    def __init__(self, mode, T, B, W, ksplits=1):
+    def __init__(self, mode, T, B, W, ksplits=1, edge=128):
         g = torch.Generator(device="cuda").manual_seed(0)
         self.mode, self.T, self.B, self.W, self.ksplits = mode, T, B, W, ksplits
         x = (torch.randn(T, B, W, device="cuda", generator=g)).to(torch.bfloat16)
@@ -47,13 +47,13 @@ class Problem:
         for t in range(T):
             if mode == 0:
                 groups[t] = (x[t].data_ptr(), w[t].data_ptr(), y[t].data_ptr(), bias[t].data_ptr(), 0, B, W, W, W, W, W, 0, 1)
-                tl.append((t, B // 128, W // 128, W // 64))
+                tl.append((t, -(-B // edge), -(-W // edge), W // 64))
             elif mode == 1:
                 groups[t] = (dy[t].data_ptr(), w[t].data_ptr(), y[t].data_ptr(), x[t].data_ptr(), 0, B, W, W, W, W, W, W, 1)
-                tl.append((t, B // 128, W // 128, W // 64))
+                tl.append((t, -(-B // edge), -(-W // edge), W // 64))
             else:
                 groups[t] = (dy[t].data_ptr(), x[t].data_ptr(), dw[0, t].data_ptr(), 0, db[0, t].data_ptr(), W, W, B, W, W, W, 0, 1)
-                tl.append((t, W // 128, W // 128, B // 64))
+                tl.append((t, -(-W // edge), -(-W // edge), B // 64))
         tiles = balanced_tiles(tl, ksplits if mode == 2 else 1)
         self.keep = (x, w, dy, y, bias, arena)
         self.gt, self.tt, self.ntiles = up(groups), up(tiles), len(tiles)
@@ -118,11 +118,14 @@ def main():
         for mode in (0, 1, 2):
             for ks in ((1, 4) if mode == 2 else (1,)):
                 prob = Problem(mode, T, args.batch, args.width, ks)
+                big = Problem(mode, T, args.batch, args.width, ks, edge=256)
                 t2 = [prob.time(fn, args.iters, 1, 2) for _ in range(3)]
                 t4 = [prob.time(fn, args.iters, 1, 4) for _ in range(3)]
-                us = min(min(t2), min(t4))
+                tb = [big.time(fn, args.iters, 1, 256) for _ in range(3)]
+                us = min(min(t2), min(t4), min(tb))
                 print(f"slots {T:4d}  {names[mode]}  ksplits {ks}  tiles {prob.ntiles:5d}  2-stage {min(t2):8.2f} us  "
-                      f"4-stage {min(t4):8.2f} us  best {prob.flop / us / 1e6:8.1f} TFLOP/s", flush=True)
+                      f"4-stage {min(t4):8.2f} us  256-tile {min(tb):8.2f} us  best {prob.flop / us / 1e6:8.1f} TFLOP/s",
+                      flush=True)
                 if args.ablate and ks == 1:
                     for label, fl in (("no-mfma", 1 | 256), ("no-steady-loads", 1 | 512), ("no-epilogue", 1 | 1024),
                                       ("loads-only", 1 | 256 | 1024), ("mfma-only", 1 | 512 | 1024)):

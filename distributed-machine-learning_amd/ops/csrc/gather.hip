@@ -9,7 +9,9 @@
 __global__ __launch_bounds__(256) void mt_gather_kernel(const MtGatherSlot* __restrict__ slots,
                                                         const int32_t* __restrict__ ids,
                                                         const float* __restrict__ X, const float* __restrict__ Y,
-                                                        uint32_t n_rows, int F, int Fpad, int hb, int step) {
+                                                        uint32_t n_rows, int F, int Fpad, int hb, int step_imm,
+                                                        const int* __restrict__ step_base) {
+  const int step = mt_step(step_imm, step_base);
   const MtGatherSlot s = slots[ids[blockIdx.y]];
   if (step >= s.active_steps) return;
   const int cpr = Fpad >> 3;                 // 16-byte output chunks per row
@@ -45,6 +47,7 @@ extern "C" int mt_gather_launch(const MtGatherSlot* slots, const int32_t* ids, i
   if (Fpad % 8 != 0 || Fpad / 8 > 256 || Fpad < F) return -2;
   const int rows_per_block = 256 / (Fpad / 8);
   dim3 grid((max_batch + rows_per_block - 1) / rows_per_block, n_slots), block(256);
-  hipLaunchKernelGGL(mt_gather_kernel, grid, block, 0, stream, slots, ids, X, Y, n_rows, F, Fpad, hb, step);
+  hipLaunchKernelGGL(mt_gather_kernel, grid, block, 0, stream, slots, ids, X, Y, n_rows, F, Fpad, hb, step,
+                     mt_step_base_tls);
   return (int)hipGetLastError();
 }

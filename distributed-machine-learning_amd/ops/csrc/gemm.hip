@@ -334,13 +334,244 @@ __device__ __forceinline__ void gemm_tile(const MtGemmGroup* __restrict__ groups
   }
 }
 
+// ====================================================================================================
+// 256 x 256 output tiles (experimental; selected only when a caller passes nstage = 256).
+//
+// Measured slower than the 128-tile forms with this simple two-barrier K-loop and one wave per SIMD (256 slots of
+// 512^3: forward 166 us vs 122 us): a 256-tile only pays with a finely interleaved ds_read / LDS-DMA / MFMA schedule
+// across two waves per SIMD.  Kept because it is numerically verified and is the starting point for that schedule.
+//
+// With K <= 512 a tile is a chain of at most 8 K-steps, each waiting on one global->LDS round trip, so a CU's
+// rate is (output area per resident tile) / (round-trip time).  A 128x128 tile moves 32 KB per K-step for 2*128*128*64
+// flop; a 256x256 tile moves 64 KB for four times that, i.e. half the bytes per flop through the same latency-bound
+// pipe.  Layout: a stage holds four 16-KiB images [A rows 0-127 | A rows 128-255 | B cols 0-127 | B cols 128-255] in
+// exactly the image formats of the 128-tile path (same staging and fragment code); wave (wr, wc) owns output
+// quadrant (wr, wc) = 128x128 = 8 x 8 accumulators (256 accumulator registers per lane, one wave per SIMD), and
+// two 64-KiB stages fill 128 KiB of the CU's 160 KiB LDS (one workgroup per CU).  Waves whose quadrant lies outside
+// the group's matrix (edge tiles of narrow layers) skip their MFMAs but still stage and synchronise.
+#define BIGT 256
+#define BIG_STAGE_BYTES 65536
+
+template <bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void mma_stage_big(f32x4 (&acc)[8][8], const uint8_t* imgA, const uint8_t* imgB, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    bf16x8 b_[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      if constexpr (B_KMAJ) b_[n] = frag_kmajor(imgB, n * 16, ks, lane);
+      else b_[n] = frag_mnmajor(imgB, n * 16, ks, lane);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      bf16x8 a_;
+      if constexpr (A_KMAJ) a_ = frag_kmajor(imgA, m * 16, ks, lane);
+      else a_ = frag_mnmajor(imgA, m * 16, ks, lane);
+#pragma unroll
+      for (int n = 0; n < 8; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_[n], a_, acc[m][n], 0, 0, 0);
+    }
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void gemm_tile_big(const MtGemmGroup* __restrict__ groups, const MtTile tile, int step,
+                                              int flags, int arow0, int i_override, int ksplits, size_t split_stride,
+                                              uint8_t* lds) {
+  constexpr bool A_KMAJ = (MODE != 2);
+  constexpr bool B_KMAJ = (MODE == 0);
+  if (tile.group < 0) return;
+  MtGemmGroup g = groups[tile.group];
+  if (step >= g.active_steps) return;
+  if (i_override > 0) {
+    g.I = i_override;
+    g.A = reinterpret_cast<const uint16_t*>(g.A) + (size_t)arow0 * g.lda;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int split = (MODE == 2) ? (tile.ti >> 8) : 0;
+  const int i0 = (tile.ti & 0xFF) * BIGT, j0 = tile.tj * BIGT;
+  if (i0 >= g.I || j0 >= g.J) return;
+  const uint16_t* A = reinterpret_cast<const uint16_t*>(g.A);
+  const uint16_t* B = reinterpret_cast<const uint16_t*>(g.B);
+  const bool live = (i0 + wr * 128 < g.I) && (j0 + wc * 128 < g.J);      // wave-uniform
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const bool want_db = (MODE == 2) && (flags & MT_GEMM_FLAG_DBIAS) && tile.tj == 0 && g.aux_out != nullptr;
+  float db0 = 0.f, db1 = 0.f;
+
+  const int nk_all = (g.KK + BK - 1) / BK;
+  int kt_lo = 0, kt_hi = nk_all;
+  if (MODE == 2 && ksplits > 1) {
+    const int per = (nk_all + ksplits - 1) / ksplits;
+    kt_lo = split * per;
+    kt_hi = (kt_lo + per < nk_all) ? kt_lo + per : nk_all;
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int n_it = kt_hi - kt_lo;
+  auto issue = [&](int slot, int kt) {      // 16 LDS-DMA pieces per wave: tile kt -> the four images of stage `slot`
+    uint8_t* st = lds + slot * BIG_STAGE_BYTES;
+    // The 16 per-lane source addresses are recomputed for every K-tile (a few dozen integer ops next to 128 MFMAs):
+    // hoisted out of the loop they would pin ~40 registers for its whole length and spill the accumulator file.
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    stage_tile<A_KMAJ>(st, A, g.lda, i0, g.I, kt * BK, g.KK, wave_u, ln);
+    stage_tile<A_KMAJ>(st + 16384, A, g.lda, i0 + 128, g.I, kt * BK, g.KK, wave_u, ln);
+    stage_tile<B_KMAJ>(st + 32768, B, g.ldb, j0, g.J, kt * BK, g.KK, wave_u, ln);
+    stage_tile<B_KMAJ>(st + 49152, B, g.ldb, j0 + 128, g.J, kt * BK, g.KK, wave_u, ln);
+  };
+
+  if (n_it > 0) issue(0, kt_lo);
+  if (n_it > 1) issue(1, kt_lo + 1);
+  for (int it = 0; it < n_it; ++it) {
+    const int cur = it & 1;
+    const uint8_t* st = lds + cur * BIG_STAGE_BYTES;
+    if (it + 1 < n_it) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (live) mma_stage_big<A_KMAJ, B_KMAJ>(acc, st + wr * 16384, st + 32768 + wc * 16384, lane);
+    if (want_db) { db0 += colsum_stage(st, tid); db1 += colsum_stage(st + 16384, tid); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < n_it) issue(cur, kt_lo + it + 2);
+  }
+
+  // ------------------------------------------------------------------------------ epilogues
+  const int fq = lane >> 4, fr = lane & 15;
+  const int qi0 = i0 + wr * 128, qj0 = j0 + wc * 128;      // this wave's quadrant
+  if (MODE == 2) {
+    float* C = reinterpret_cast<float*>(g.C) + (size_t)split * split_stride;
+    if (live) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int row = qi0 + m * 16 + fr;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const int col = qj0 + n * 16 + fq * 4;
+          if (row < g.I) {
+            float* dst = C + (size_t)row * g.ldc + col;
+            if (col + 3 < g.J) *reinterpret_cast<f32x4*>(dst) = acc[m][n];
+            else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (col + j < g.J) dst[j] = acc[m][n][j];
+            }
+          }
+        }
+      }
+    }
+    if (want_db) {
+      float* red = reinterpret_cast<float*>(lds);    // all waves are past the last K-step barrier
+      red[tid] = db0;
+      red[256 + tid] = db1;
+      __syncthreads();
+      float* out = reinterpret_cast<float*>(g.aux_out) + (size_t)split * split_stride;
+      if (tid < 128) {
+        if (i0 + tid < g.I) out[i0 + tid] = red[tid] + red[tid + 128];
+        if (i0 + 128 + tid < g.I) out[i0 + 128 + tid] = red[256 + tid] + red[256 + tid + 128];
+      }
+    }
+    return;
+  }
+  if (!live) return;
+  {
+    uint8_t* img = lds + wave * 32768;       // this wave's own 128x128 bf16 staging image (wave-private: no barrier)
+    const bool relu = (MODE == 0) && (flags & MT_GEMM_FLAG_RELU);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int lcol = n * 16 + fq * 4;
+      float bb[4] = {0.f, 0.f, 0.f, 0.f};
+      if (MODE == 0 && g.aux != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (qj0 + lcol + j < g.J) bb[j] = reinterpret_cast<const float*>(g.aux)[qj0 + lcol + j];
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int lrow = m * 16 + fr;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[m][n][j] + bb[j];
+          if (relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(img + ctile_off(lrow, lcol >> 3) + (lcol & 7) * 2) = pk;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    uint16_t* C = reinterpret_cast<uint16_t*>(g.C);
+    const uint16_t* msk = (MODE == 1 && (flags & MT_GEMM_FLAG_MASK)) ? reinterpret_cast<const uint16_t*>(g.aux)
+                                                                    : nullptr;
+#pragma unroll 1
+    for (int t0 = 0; t0 < 32; t0 += 8) {
+      u32x4 hv[8];
+      if (msk != nullptr) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int q = lane + 64 * (t0 + t);
+          const int row = qi0 + (q >> 4), col = qj0 + (q & 15) * 8;
+          const bool ok = (row < g.I && col < g.J);
+          hv[t] = *reinterpret_cast<const u32x4*>(msk + (ok ? ((size_t)row * g.ldaux + col) : (size_t)0));
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int q = lane + 64 * (t0 + t);
+        const int lrow = q >> 4, ch = q & 15;
+        const int row = qi0 + lrow, col = qj0 + ch * 8;
+        u32x4 v = *reinterpret_cast<const u32x4*>(img + ctile_off(lrow, ch));
+        if (msk != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t hw = hv[t][e];
+            const uint32_t lo_ok = ((hw & 0x8000u) == 0u && (hw & 0x7FFFu) != 0u) ? 0x0000FFFFu : 0u;
+            const uint32_t hi_ok = ((hw & 0x80000000u) == 0u && (hw & 0x7FFF0000u) != 0u) ? 0xFFFF0000u : 0u;
+            v[e] &= (lo_ok | hi_ok);
+          }
+        }
+        if (row < g.I && col < g.J) *reinterpret_cast<u32x4*>(C + (size_t)row * g.ldc + col) = v;
+      }
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS) void mt_gemm256_kernel(const MtGemmGroup* __restrict__ groups,
+                                                              const MtTile* __restrict__ tiles, int step, int flags,
+                                                              int arow0, int i_override, int ksplits,
+                                                              size_t split_stride, const int* __restrict__ step_base) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BIG_STAGE_BYTES];
+  gemm_tile_big<MODE>(groups, tiles[blockIdx.x], mt_step(step, step_base), flags, arow0, i_override, ksplits,
+                      split_stride, lds);
+}
+
+__global__ __launch_bounds__(NTHREADS) void mt_gemm256_bwd_kernel(const MtGemmGroup* __restrict__ wgroups,
+                                                                  const MtTile* __restrict__ wtiles, int n_wtiles,
+                                                                  const MtGemmGroup* __restrict__ dgroups,
+                                                                  const MtTile* __restrict__ dtiles, int step_imm,
+                                                                  int ksplits, size_t split_stride,
+                                                                  const int* __restrict__ step_base) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BIG_STAGE_BYTES];
+  const int step = mt_step(step_imm, step_base);
+  if ((int)blockIdx.x < n_wtiles)
+    gemm_tile_big<2>(wgroups, wtiles[blockIdx.x], step, MT_GEMM_FLAG_DBIAS, 0, 0, ksplits, split_stride, lds);
+  else
+    gemm_tile_big<1>(dgroups, dtiles[blockIdx.x - n_wtiles], step, MT_GEMM_FLAG_MASK, 0, 0, 1, 0, lds);
+}
+
 template <int MODE, int NSTAGE>
 __global__ __launch_bounds__(NTHREADS) void mt_gemm_kernel(const MtGemmGroup* __restrict__ groups,
                                                            const MtTile* __restrict__ tiles, int step, int flags,
                                                            int arow0, int i_override, int ksplits,
-                                                           size_t split_stride) {
+                                                           size_t split_stride, const int* __restrict__ step_base) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * STAGE_BYTES];
-  gemm_tile<MODE, NSTAGE>(groups, tiles[blockIdx.x], step, flags, arow0, i_override, ksplits, split_stride, lds);
+  gemm_tile<MODE, NSTAGE>(groups, tiles[blockIdx.x], mt_step(step, step_base), flags, arow0, i_override, ksplits, split_stride, lds);
 }
 
 // Backward of one layer in ONE launch: the weight-gradient tiles and the input-gradient tiles both
@@ -349,9 +580,11 @@ template <int NSTAGE>
 __global__ __launch_bounds__(NTHREADS) void mt_gemm_bwd_kernel(const MtGemmGroup* __restrict__ wgroups,
                                                                const MtTile* __restrict__ wtiles, int n_wtiles,
                                                                const MtGemmGroup* __restrict__ dgroups,
-                                                               const MtTile* __restrict__ dtiles, int step,
-                                                               int ksplits, size_t split_stride) {
+                                                               const MtTile* __restrict__ dtiles, int step_imm,
+                                                               int ksplits, size_t split_stride,
+                                                               const int* __restrict__ step_base) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * STAGE_BYTES];
+  const int step = mt_step(step_imm, step_base);
   if ((int)blockIdx.x < n_wtiles)
     gemm_tile<2, NSTAGE>(wgroups, wtiles[blockIdx.x], step, MT_GEMM_FLAG_DBIAS, 0, 0, ksplits, split_stride, lds);
   else
@@ -359,7 +592,7 @@ __global__ __launch_bounds__(NTHREADS) void mt_gemm_bwd_kernel(const MtGemmGroup
 }
 
 // nstage: 2 = throughput form (two workgroups per CU), 4 = latency form (one workgroup per CU, three
-// tiles in flight); 0 lets the launcher choose from the tile count.
+// tiles in flight); 0 lets the launcher choose from the tile count.  256 = the tile list holds 256x256 tiles.
 static int pick_nstage(int nstage, int ntiles) {
   if (nstage == 2 || nstage == 4) return nstage;
   return ntiles <= 320 ? 4 : 2;
@@ -371,9 +604,23 @@ extern "C" int mt_gemm_launch(int mode, const MtGemmGroup* groups, const MtTile*
   if (ntiles <= 0) return 0;
   if (ksplits < 1 || ksplits > 255 || (mode != 2 && ksplits != 1)) return -5;
   dim3 grid(ntiles), block(NTHREADS);
+  if (nstage == 256) {
+#define MT_GEMM_BIG(M, KS, SS) \
+  hipLaunchKernelGGL((mt_gemm256_kernel<M>), grid, block, 0, stream, groups, tiles, step, flags, arow0, i_override, KS, SS, \
+                     mt_step_base_tls)
+    switch (mode) {
+      case 0: MT_GEMM_BIG(0, 1, (size_t)0); break;
+      case 1: MT_GEMM_BIG(1, 1, (size_t)0); break;
+      case 2: MT_GEMM_BIG(2, ksplits, split_stride); break;
+      default: return -1;
+    }
+#undef MT_GEMM_BIG
+    return (int)hipGetLastError();
+  }
   const bool deep = pick_nstage(nstage, ntiles) == 4;
 #define MT_GEMM_GO(M, N, KS, SS) \
-  hipLaunchKernelGGL((mt_gemm_kernel<M, N>), grid, block, 0, stream, groups, tiles, step, flags, arow0, i_override, KS, SS)
+  hipLaunchKernelGGL((mt_gemm_kernel<M, N>), grid, block, 0, stream, groups, tiles, step, flags, arow0, i_override, KS, SS, \
+                     mt_step_base_tls)
   switch (mode) {
     case 0: if (deep) MT_GEMM_GO(0, 4, 1, (size_t)0); else MT_GEMM_GO(0, 2, 1, (size_t)0); break;
     case 1: if (deep) MT_GEMM_GO(1, 4, 1, (size_t)0); else MT_GEMM_GO(1, 2, 1, (size_t)0); break;
@@ -390,11 +637,16 @@ extern "C" int mt_gemm_bwd_launch(const MtGemmGroup* wgroups, const MtTile* wtil
   if (n_wtiles + n_dtiles <= 0) return 0;
   if (ksplits < 1 || ksplits > 255) return -5;
   dim3 grid(n_wtiles + n_dtiles), block(NTHREADS);
+  if (nstage == 256) {
+    hipLaunchKernelGGL(mt_gemm256_bwd_kernel, grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles, step,
+                       ksplits, split_stride, mt_step_base_tls);
+    return (int)hipGetLastError();
+  }
   if (pick_nstage(nstage, n_wtiles + n_dtiles) == 4)
     hipLaunchKernelGGL(mt_gemm_bwd_kernel<4>, grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles, step,
-                       ksplits, split_stride);
+                       ksplits, split_stride, mt_step_base_tls);
   else
     hipLaunchKernelGGL(mt_gemm_bwd_kernel<2>, grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles, step,
-                       ksplits, split_stride);
+                       ksplits, split_stride, mt_step_base_tls);
   return (int)hipGetLastError();
 }

@@ -36,9 +36,10 @@ __device__ __forceinline__ void loss_and_grad(int type, float out, float y, floa
 
 template <int NCHUNK>
 __global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSlot* __restrict__ slots,
-                                                                  const int32_t* __restrict__ ids, int step,
+                                                                  const int32_t* __restrict__ ids, int step_imm,
                                                                   float* __restrict__ scratch, int max_chunks,
-                                                                  int rec) {
+                                                                  int rec, const int* __restrict__ step_base) {
+  const int step = mt_step(step_imm, step_base);
   const int slot = ids[blockIdx.y];
   const MtHeadSlot s = slots[slot];
   if (step >= s.active_steps) return;
@@ -131,9 +132,11 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSl
 }
 
 __global__ __launch_bounds__(HL_THREADS) void mt_head_reduce_kernel(const MtHeadSlot* __restrict__ slots,
-                                                                    const int32_t* __restrict__ ids, int step,
+                                                                    const int32_t* __restrict__ ids, int step_imm,
                                                                     const float* __restrict__ scratch,
-                                                                    int max_chunks, int rec) {
+                                                                    int max_chunks, int rec,
+                                                                    const int* __restrict__ step_base) {
+  const int step = mt_step(step_imm, step_base);
   const int slot = ids[blockIdx.x];
   const MtHeadSlot s = slots[slot];
   if (step >= s.active_steps) return;
@@ -241,13 +244,17 @@ extern "C" int mt_head_loss_launch(const MtHeadSlot* slots, const int32_t* ids, 
   const int max_chunks = (max_batch + HL_ROWS - 1) / HL_ROWS;
   dim3 grid(max_chunks, n_active), block(HL_THREADS);
   if (max_width <= 512)
-    hipLaunchKernelGGL(mt_head_loss_kernel<1>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec);
+    hipLaunchKernelGGL(mt_head_loss_kernel<1>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
+                       mt_step_base_tls);
   else if (max_width <= 1024)
-    hipLaunchKernelGGL(mt_head_loss_kernel<2>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec);
+    hipLaunchKernelGGL(mt_head_loss_kernel<2>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
+                       mt_step_base_tls);
   else if (max_width <= 2048)
-    hipLaunchKernelGGL(mt_head_loss_kernel<4>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec);
+    hipLaunchKernelGGL(mt_head_loss_kernel<4>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
+                       mt_step_base_tls);
   else return -2;
-  hipLaunchKernelGGL(mt_head_reduce_kernel, dim3(n_active), block, 0, stream, slots, ids, step, scratch, max_chunks, rec);
+  hipLaunchKernelGGL(mt_head_reduce_kernel, dim3(n_active), block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
+                     mt_step_base_tls);
   return (int)hipGetLastError();
 }
 

@@ -15,6 +15,14 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define MT_WAVE 64
 
+// Optional device-resident step base.  Launchers forward this thread's pointer to every step-aware kernel, which
+// adds *step_base to its immediate `step` argument.  The step driver sets it while it captures a hipGraph, so that
+// a captured block of steps can be replayed at any position of an epoch; everywhere else it is null.
+extern thread_local const int* mt_step_base_tls;
+__device__ __forceinline__ int mt_step(int step, const int* __restrict__ step_base) {
+  return step_base != nullptr ? step + *step_base : step;
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
 
 // Round-to-nearest-even f32 -> bf16 through the compiler's cast (v_cvt_pk_bf16_f32 on gfx950),

@@ -18,8 +18,10 @@
 __global__ __launch_bounds__(OPT_THREADS) void mt_sqnorm_kernel(const float* __restrict__ G, size_t slot_stride,
                                                                 const MtOptSlot* __restrict__ hp,
                                                                 const int32_t* __restrict__ ids,
-                                                                float* __restrict__ partials, int max_blocks, int step,
-                                                                int gsplits, size_t gsplit_stride) {
+                                                                float* __restrict__ partials, int max_blocks, int step_imm,
+                                                                int gsplits, size_t gsplit_stride,
+                                                                const int* __restrict__ step_base) {
+  const int step = mt_step(step_imm, step_base);
   const int slot = ids[blockIdx.y];
   const MtOptSlot h = hp[slot];
   float acc = 0.f;
@@ -57,7 +59,9 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict
                                                                const MtOptSlot* __restrict__ hp,
                                                                const int32_t* __restrict__ ids,
                                                                const float* __restrict__ partials, int max_blocks,
-                                                               int step, int gsplits, size_t gsplit_stride) {
+                                                               int step_imm, int gsplits, size_t gsplit_stride,
+                                                               const int* __restrict__ step_base) {
+  const int step = mt_step(step_imm, step_base);
   const int slot = ids[blockIdx.y];
   const MtOptSlot h = hp[slot];
   if (step >= h.active_steps) return;
@@ -178,10 +182,11 @@ extern "C" int mt_optim_launch(float* P, const float* G, float* M, float* V, voi
   if (use_clip) {
     if (partials == nullptr) return -3;
     hipLaunchKernelGGL(mt_sqnorm_kernel, grid, block, 0, stream, G, slot_stride, hp, ids, partials, max_blocks, step, gsplits,
-                       gsplit_stride);
+                       gsplit_stride, mt_step_base_tls);
   }
   hipLaunchKernelGGL(mt_optim_kernel<false>, grid, block, 0, stream, P, G, M, V, reinterpret_cast<uint16_t*>(Pb),
-                     slot_stride, hp, ids, use_clip ? partials : nullptr, max_blocks, step, gsplits, gsplit_stride);
+                     slot_stride, hp, ids, use_clip ? partials : nullptr, max_blocks, step, gsplits, gsplit_stride,
+                     mt_step_base_tls);
   return (int)hipGetLastError();
 }
 
@@ -194,6 +199,6 @@ extern "C" int mt_optim_launch_bf16g(float* P, const void* Gb, float* M, float* 
   const int nb = (max_params + OPT_PER_BLOCK - 1) / OPT_PER_BLOCK;
   dim3 grid(nb, n_active), block(OPT_THREADS);
   hipLaunchKernelGGL(mt_optim_kernel<true>, grid, block, 0, stream, P, reinterpret_cast<const float*>(Gb), M, V,
-                     reinterpret_cast<uint16_t*>(Pb), slot_stride, hp, ids, nullptr, 0, step, 1, (size_t)0);
+                     reinterpret_cast<uint16_t*>(Pb), slot_stride, hp, ids, nullptr, 0, step, 1, (size_t)0, mt_step_base_tls);
   return (int)hipGetLastError();
 }

@@ -62,7 +62,11 @@ struct MtMlpPlan {
   int32_t max_blocks;
   int32_t ksplits;        // wgrad contraction splits; G holds that many slabs of gsplit_stride floats
   size_t gsplit_stride;
+  int32_t fwd_big[MT_MAX_LAYERS];   // 1: this layer's forward tile list holds 256x256 tiles
+  int32_t bwd_big[MT_MAX_LAYERS];   // 1: this layer's wgrad and dgrad tile lists hold 256x256 tiles
 };
+
+thread_local const int* mt_step_base_tls = nullptr;
 
 #define MT_TRY(x)            \
   do {                       \
@@ -70,7 +74,7 @@ struct MtMlpPlan {
     if (_e != 0) return _e;  \
   } while (0)
 
-extern "C" int mt_mlp_train_steps(const MtMlpPlan* p, int step0, int nsteps, hipStream_t stream) {
+static int mlp_enqueue_steps(const MtMlpPlan* p, int step0, int nsteps, hipStream_t stream) {
   if (p->n_hidden < 1 || p->n_hidden > MT_MAX_LAYERS) return -10;
   const int L = p->n_hidden;
   for (int step = step0; step < step0 + nsteps; ++step) {
@@ -78,18 +82,95 @@ extern "C" int mt_mlp_train_steps(const MtMlpPlan* p, int step0, int nsteps, hip
                             p->Fpad, p->hb, step, stream));
     for (int l = 0; l < L; ++l)
       MT_TRY(mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], step, MT_GEMM_FLAG_RELU, 0, 0,
-                            1, 0, 0, stream));
+                            1, 0, p->fwd_big[l] ? 256 : 0, stream));
     MT_TRY(mt_head_loss_launch(p->head, p->active_ids, p->n_active, p->max_batch, p->max_width, step,
                                p->head_scratch, stream));
     for (int l = L - 1; l >= 0; --l)     // layer 0 has no input gradient: its dgrad tile list is empty
       MT_TRY(mt_gemm_bwd_launch(p->wgrad_groups[l], p->wgrad_tiles[l], p->wgrad_ntiles[l], p->dgrad_groups[l],
                                 p->dgrad_tiles[l], l > 0 ? p->dgrad_ntiles[l] : 0, step, p->ksplits,
-                                p->gsplit_stride, 0, stream));
+                                p->gsplit_stride, p->bwd_big[l] ? 256 : 0, stream));
     MT_TRY(mt_optim_launch(p->P, p->G, p->M, p->V, p->Pb, p->slot_stride, p->opt, p->active_ids, p->n_active,
                            p->max_params, p->partials, p->max_blocks, p->use_clip, step, p->ksplits,
                            p->gsplit_stride, stream));
   }
   return 0;
+}
+
+extern "C" int mt_mlp_train_steps(const MtMlpPlan* p, int step0, int nsteps, hipStream_t stream) {
+  return mlp_enqueue_steps(p, step0, nsteps, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Graph replay.  A block of `nsteps` consecutive steps is captured ONCE per plan into a hipGraph whose kernels
+// take their step number as (immediate k) + (*counter); the last node adds nsteps to the counter.  Replaying the
+// graph r times therefore runs steps [c, c + r*nsteps) of the epoch for one host call per block instead of one per
+// kernel (about 11 launches per step otherwise), which is what lets several independent chains of a small pack be
+// fed concurrently from one host thread.  Everything the kernels read besides the counter sits in descriptor
+// tables that the engine rewrites in place between epochs, so a graph stays valid until the pack's membership
+// changes.
+__global__ void mt_counter_add_kernel(int* counter, int delta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *counter = *counter + delta;
+}
+
+struct MtStepGraph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  int nsteps;
+};
+
+extern "C" void* mt_mlp_graph_create(const MtMlpPlan* p, int nsteps, int* counter, hipStream_t stream, int* err) {
+  *err = 0;
+  if (nsteps < 1 || counter == nullptr || stream == nullptr) { *err = -11; return nullptr; }
+  if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { *err = -12; return nullptr; }
+  mt_step_base_tls = counter;
+  int rc = mlp_enqueue_steps(p, 0, nsteps, stream);
+  mt_step_base_tls = nullptr;
+  if (rc == 0) {
+    hipLaunchKernelGGL(mt_counter_add_kernel, dim3(1), dim3(64), 0, stream, counter, nsteps);
+    rc = (int)hipGetLastError();
+  }
+  hipGraph_t graph = nullptr;
+  const hipError_t e_end = hipStreamEndCapture(stream, &graph);
+  if (rc != 0 || e_end != hipSuccess || graph == nullptr) {
+    if (graph != nullptr) (void)hipGraphDestroy(graph);
+    *err = rc != 0 ? rc : -13;
+    return nullptr;
+  }
+  hipGraphExec_t exec = nullptr;
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    *err = -14;
+    return nullptr;
+  }
+  MtStepGraph* g = new MtStepGraph{graph, exec, nsteps};
+  return g;
+}
+
+extern "C" int mt_mlp_graph_replay(void* handle, int times, hipStream_t stream) {
+  MtStepGraph* g = static_cast<MtStepGraph*>(handle);
+  if (g == nullptr) return -11;
+  for (int i = 0; i < times; ++i)
+    if (hipGraphLaunch(g->exec, stream) != hipSuccess) return -15;
+  return 0;
+}
+
+extern "C" void mt_mlp_graph_destroy(void* handle) {
+  MtStepGraph* g = static_cast<MtStepGraph*>(handle);
+  if (g == nullptr) return;
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
+}
+
+// Direct launches of steps [*counter, *counter + nsteps) (the remainder of an epoch that is not a whole block).
+extern "C" int mt_mlp_train_steps_at(const MtMlpPlan* p, int* counter, int nsteps, hipStream_t stream) {
+  if (nsteps <= 0) return 0;
+  mt_step_base_tls = counter;
+  const int rc = mlp_enqueue_steps(p, 0, nsteps, stream);
+  mt_step_base_tls = nullptr;
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(mt_counter_add_kernel, dim3(1), dim3(64), 0, stream, counter, nsteps);
+  return (int)hipGetLastError();
 }
 
 // Validation sweep: the forward tables of an evaluation plan all read rows of ONE shared bf16 copy of
@@ -102,7 +183,7 @@ extern "C" int mt_mlp_eval(const MtMlpPlan* p, int n_val_rows, int chunk_rows, h
     const int rows = (n_val_rows - r0) < chunk_rows ? (n_val_rows - r0) : chunk_rows;
     for (int l = 0; l < L; ++l)
       MT_TRY(mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], 0, MT_GEMM_FLAG_RELU,
-                            l == 0 ? r0 : 0, rows, 1, 0, 0, stream));
+                            l == 0 ? r0 : 0, rows, 1, 0, p->fwd_big[l] ? 256 : 0, stream));
     MT_TRY(mt_head_eval_launch(p->head, p->active_ids, p->n_active, p->max_width, r0, rows, chunk_rows,
                                p->head_scratch, stream));
   }

@@ -62,7 +62,8 @@ class MlpPlan(C.Structure):
                 ("head", c_void_p), ("P", c_void_p), ("G", c_void_p), ("M", c_void_p), ("V", c_void_p),
                 ("Pb", c_void_p), ("slot_stride", c_size_t), ("opt", c_void_p), ("partials", c_void_p),
                 ("active_ids", c_void_p), ("head_scratch", c_void_p), ("max_blocks", c_int32), ("ksplits", c_int32),
-                ("gsplit_stride", c_size_t)]
+                ("gsplit_stride", c_size_t),
+                ("fwd_big", c_int32 * MT_MAX_LAYERS), ("bwd_big", c_int32 * MT_MAX_LAYERS)]
 
 
 HM_MAXL = 5
@@ -182,6 +183,14 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn.restype = C.c_int
     lib.mt_mlp_train_steps.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]
     lib.mt_mlp_eval.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]
+    lib.mt_mlp_graph_create.argtypes = [C.POINTER(MlpPlan), C.c_int, c_void_p, c_void_p, C.POINTER(C.c_int)]
+    lib.mt_mlp_graph_create.restype = c_void_p
+    lib.mt_mlp_graph_replay.argtypes = [c_void_p, C.c_int, c_void_p]
+    lib.mt_mlp_graph_replay.restype = C.c_int
+    lib.mt_mlp_graph_destroy.argtypes = [c_void_p]
+    lib.mt_mlp_graph_destroy.restype = None
+    lib.mt_mlp_train_steps_at.argtypes = [C.POINTER(MlpPlan), c_void_p, C.c_int, c_void_p]
+    lib.mt_mlp_train_steps_at.restype = C.c_int
     for fn in (lib.mt_gemm_launch, lib.mt_gather_launch, lib.mt_head_loss_launch, lib.mt_head_eval_launch,
                lib.mt_optim_launch, lib.mt_mlp_train_steps, lib.mt_mlp_eval):
         fn.restype = C.c_int

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -36,6 +37,13 @@ from ..train.optim import OPT_CODES
 TILE = 128
 N_XCD = 8
 MAX_KSPLITS = 4        # weight-gradient slabs kept per slot (split-K over the batch for small packs)
+MAX_STREAMS = 4        # concurrent step chains, one HIP stream each
+BIG_TILE = 256         # tile edge of the throughput-form GEMM kernels
+# 256-tiles are OFF by default (threshold 0 disables them): with the simple two-barrier K-loop they measured slower than
+# the 128-tile forms at every pack size (256 slots x 512^3: fwd 166 vs 122 us, dgrad 309 vs 135, wgrad 242 vs 160);
+# MITUNE_BIG_MIN_TILES=<n> turns them on for launches with at least n such tiles.
+BIG_MIN_TILES = int(os.environ.get("MITUNE_BIG_MIN_TILES", "0"))
+GRAPH_STEPS = 25       # steps per captured hipGraph block (3125 = 125 blocks; shorter epochs run the rest directly)
 
 
 def ceil8(x: int) -> int:
@@ -77,6 +85,11 @@ class SlotLayout:
 
 class _HSlot:
     __slots__ = ("trial_index", "spec", "layout", "epoch", "step", "config")
+
+
+class _Chain:
+    """One group of slots trained as an independent chain of launches on its own stream."""
+    __slots__ = ("ids", "tag", "plan", "steps", "counter", "graph")
 
 
 def balanced_tiles(groups: List[Tuple[int, int, int, int]], ksplits: int = 1) -> np.ndarray:
@@ -167,6 +180,17 @@ class HipPackEngine(PackEngine):
         self.slots: Dict[int, _HSlot] = {}
         self._tables: Dict[str, Any] = {}
         self._dirty = True
+        # Optional concurrent chains: trials are independent, so a pack can be split into up to MAX_STREAMS chains on
+        # separate HIP streams.  One host thread cannot feed several chains kernel by kernel (a launch costs ~3.5 us
+        # of host time), so each chain's steps are captured in blocks of GRAPH_STEPS as a hipGraph that reads its step
+        # number from a device counter and is replayed block after block.  OFF by default ("streams": n or
+        # MITUNE_STREAMS=n enables it): on the machines measured, kernels of different streams did not overlap
+        # (rocprofv3 trace: overlap factor 1.03 with four chains), so splitting only shrank the launches.
+        self._streams = [torch.cuda.Stream(device=dev) for _ in range(MAX_STREAMS)]
+        self._counters = torch.zeros(MAX_STREAMS, device=dev, dtype=torch.int32)
+        self._chain_scratch = [torch.zeros_like(self.head_scratch) for _ in range(MAX_STREAMS - 1)]
+        self._chains: List[_Chain] = []
+        self.n_streams_override = int(os.environ.get("MITUNE_STREAMS", kw.get("streams", 0)) or 0)
         self._train_loss: Dict[int, float] = {}
 
     # ------------------------------------------------------------------ slot management
@@ -269,17 +293,25 @@ class HipPackEngine(PackEngine):
 
     # ------------------------------------------------------------------ descriptor tables
     def _upload(self, name: str, arr: np.ndarray) -> int:
-        t = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(self.device)
-        self._tables[name] = t
+        """Copy a descriptor table to the device; a table of unchanged size keeps its buffer (and address: captured
+        graphs hold these pointers), so refreshing it between epochs is an in-place copy."""
+        host = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy())
+        t = self._tables.get(name)
+        if isinstance(t, torch.Tensor) and t.numel() == host.numel():
+            t.copy_(host)
+        else:
+            t = host.to(self.device)
+            self._tables[name] = t
         return t.data_ptr()
 
     def _act_ptr(self, buf: torch.Tensor, slot: int, elem_bytes: int = 2) -> int:
         return buf.data_ptr() + slot * self.act_stride * elem_bytes
 
-    def _choose_ksplits(self) -> int:
+    def _choose_ksplits(self, ids: Optional[List[int]] = None) -> int:
         """Split the wgrad contraction when the pack is too small to give every CU a weight-gradient tile."""
         per_layer: Dict[int, int] = {}
-        for s in self.slots.values():
+        for slot in (ids if ids is not None else sorted(self.slots)):
+            s = self.slots[slot]
             lay = s.layout
             for l, h in enumerate(lay.hidden):
                 per_layer[l] = per_layer.get(l, 0) + ((h + TILE - 1) // TILE) * ((lay.in_dims[l] + TILE - 1) // TILE)
@@ -290,9 +322,10 @@ class HipPackEngine(PackEngine):
             return MAX_KSPLITS
         return 2 if busiest <= 192 else 1
 
-    def _build_gemm_tables(self, eval_mode: bool) -> Dict[str, Any]:
-        Lmax = max(len(s.spec.hidden_sizes) for s in self.slots.values())
-        ksplits = 1 if eval_mode else self._choose_ksplits()
+    def _build_gemm_tables(self, eval_mode: bool, ids: List[int], tag: str) -> Dict[str, Any]:
+        members = [(slot, self.slots[slot]) for slot in ids]
+        Lmax = max(len(s.spec.hidden_sizes) for _, s in members)
+        ksplits = 1 if eval_mode else self._choose_ksplits(ids)
         self._ksplits = ksplits
         T = self.capacity
         out: Dict[str, Any] = {"n_hidden": Lmax}
@@ -302,8 +335,8 @@ class HipPackEngine(PackEngine):
             fwd = np.zeros(T, dtype=L.GEMM_GROUP_DTYPE)
             dg = np.zeros(T, dtype=L.GEMM_GROUP_DTYPE)
             wg = np.zeros(T, dtype=L.GEMM_GROUP_DTYPE)
-            fl, dl, wl = [], [], []
-            for slot, s in self.slots.items():
+            fl, dl, wl = [], [], []            # (slot, rows, cols, weight) per GEMM; tiled below
+            for slot, s in members:
                 lay = s.layout
                 if l >= len(lay.hidden):
                     continue
@@ -318,50 +351,66 @@ class HipPackEngine(PackEngine):
                 fwd[slot] = (a_in, pb_base + (base + lay.w_off[l]) * 2, self._act_ptr(self.H[l], slot),
                              p_base + (base + lay.b_off[l]) * 4, 0,
                              bsz, h, k_real, k_ld, k_ld, o_ld, 0, steps)
-                ti = (bsz + TILE - 1) // TILE
-                fl.append((slot, ti, (h + TILE - 1) // TILE, (k_real + 63) // 64))
+                fl.append((slot, bsz, h, (k_real + 63) // 64))
                 if eval_mode:
                     continue
                 if l > 0:
                     dg[slot] = (self._act_ptr(self.dZ[l], slot), pb_base + (base + lay.w_off[l]) * 2,
                                 self._act_ptr(self.dZ[l - 1], slot), self._act_ptr(self.H[l - 1], slot), 0,
                                 bsz, k_real, h, o_ld, k_ld, k_ld, k_ld, steps)
-                    dl.append((slot, ti, (k_real + TILE - 1) // TILE, (h + 63) // 64))
+                    dl.append((slot, bsz, k_real, (h + 63) // 64))
                 wg[slot] = (self._act_ptr(self.dZ[l], slot), a_in, g_base + (base + lay.w_off[l]) * 4, 0,
                             g_base + (base + lay.b_off[l]) * 4,
                             h, k_real, bsz, o_ld, k_ld, k_ld, 0, steps)
-                wl.append((slot, (h + TILE - 1) // TILE, (k_real + TILE - 1) // TILE, (bsz + 63) // 64))
-            tag = "e" if eval_mode else "t"
-            ft = balanced_tiles(fl)
+                wl.append((slot, h, k_real, (bsz + 63) // 64))
+            def tiled(lst, edge):
+                return [(g_, (r_ + edge - 1) // edge, (c_ + edge - 1) // edge, w_) for g_, r_, c_, w_ in lst]
+
+            def count(lst, edge):
+                return sum(a * b for _, a, b, _ in tiled(lst, edge))
+
+            # 256-tiles halve the bytes staged per flop; they pay once a launch still has enough of them to fill the chip
+            big_f = BIG_MIN_TILES > 0 and count(fl, BIG_TILE) >= BIG_MIN_TILES
+            big_b = (BIG_MIN_TILES > 0 and (not eval_mode) and ksplits == 1
+                     and count(dl, BIG_TILE) + count(wl, BIG_TILE) >= BIG_MIN_TILES)
+            out[f"big_fwd{l}"], out[f"big_bwd{l}"] = int(big_f), int(big_b)
+            ft = balanced_tiles(tiled(fl, BIG_TILE if big_f else TILE))
             out[f"fwd{l}"] = (self._upload(f"{tag}fwd_g{l}", fwd), self._upload(f"{tag}fwd_t{l}", ft), len(ft))
             if not eval_mode:
-                dt, wt = balanced_tiles(dl), balanced_tiles(wl, ksplits)
-                out[f"dgrad{l}"] = (self._upload(f"dg_g{l}", dg), self._upload(f"dg_t{l}", dt), len(dt))
-                out[f"wgrad{l}"] = (self._upload(f"wg_g{l}", wg), self._upload(f"wg_t{l}", wt), len(wt))
+                edge = BIG_TILE if big_b else TILE
+                dt, wt = balanced_tiles(tiled(dl, edge)), balanced_tiles(tiled(wl, edge), ksplits)
+                out[f"dgrad{l}"] = (self._upload(f"{tag}dg_g{l}", dg), self._upload(f"{tag}dg_t{l}", dt), len(dt))
+                out[f"wgrad{l}"] = (self._upload(f"{tag}wg_g{l}", wg), self._upload(f"{tag}wg_t{l}", wt), len(wt))
         return out
 
-    def _build_plan(self, eval_mode: bool) -> L.MlpPlan:
+    def _build_plan(self, eval_mode: bool, slot_ids: Optional[List[int]] = None, tag: Optional[str] = None,
+                    scratch: Optional[torch.Tensor] = None) -> L.MlpPlan:
         T = self.capacity
-        gt = self._build_gemm_tables(eval_mode)
+        slot_ids = sorted(self.slots) if slot_ids is None else sorted(slot_ids)
+        members = [(slot, self.slots[slot]) for slot in slot_ids]
+        tag = tag or ("e" if eval_mode else "t")
+        gt = self._build_gemm_tables(eval_mode, slot_ids, tag)
         plan = L.MlpPlan()
-        ids = np.array(sorted(self.slots), dtype=np.int32)
+        ids = np.array(slot_ids, dtype=np.int32)
         plan.n_hidden, plan.n_active = gt["n_hidden"], len(ids)
-        plan.active_ids = self._upload("eids" if eval_mode else "tids", ids)
-        plan.head_scratch, plan.max_blocks = self.head_scratch.data_ptr(), self.max_blocks
+        plan.active_ids = self._upload(tag + "ids", ids)
+        plan.head_scratch = (scratch if scratch is not None else self.head_scratch).data_ptr()
+        plan.max_blocks = self.max_blocks
         plan.ksplits, plan.gsplit_stride = self._ksplits, self.capacity * self.stride
-        plan.max_batch = max(s.spec.batch_size for s in self.slots.values())
-        plan.max_width = max(max(s.spec.hidden_sizes) for s in self.slots.values())
-        plan.max_params = max(s.layout.total for s in self.slots.values())
+        plan.max_batch = max(s.spec.batch_size for _, s in members)
+        plan.max_width = max(max(s.spec.hidden_sizes) for _, s in members)
+        plan.max_params = max(s.layout.total for _, s in members)
         plan.F, plan.Fpad, plan.hb, plan.n_rows = self.F, self.Fpad, half_bits(self.n_train), self.n_train
-        plan.use_clip = int(any(s.spec.gradient_clipping > 0 for s in self.slots.values()))
+        plan.use_clip = int(any(s.spec.gradient_clipping > 0 for _, s in members))
         plan.X, plan.Y = self.Xtr.data_ptr(), self.ytr.data_ptr()
         for l in range(gt["n_hidden"]):
             plan.fwd_groups[l], plan.fwd_tiles[l], plan.fwd_ntiles[l] = gt[f"fwd{l}"]
+            plan.fwd_big[l], plan.bwd_big[l] = gt[f"big_fwd{l}"], gt[f"big_bwd{l}"]
             if not eval_mode:
                 plan.dgrad_groups[l], plan.dgrad_tiles[l], plan.dgrad_ntiles[l] = gt[f"dgrad{l}"]
                 plan.wgrad_groups[l], plan.wgrad_tiles[l], plan.wgrad_ntiles[l] = gt[f"wgrad{l}"]
         head = np.zeros(T, dtype=L.HEAD_DTYPE)
-        for slot, s in self.slots.items():
+        for slot, s in members:
             lay, last = s.layout, len(s.layout.hidden) - 1
             base = slot * self.stride
             steps = 1 if eval_mode else self.n_train // min(s.spec.batch_size, self.n_train)
@@ -372,21 +421,22 @@ class HipPackEngine(PackEngine):
                           self.loss_acc.data_ptr() + slot * 4, self.metrics.data_ptr() + slot * 24,
                           self.val_chunk if eval_mode else s.spec.batch_size, lay.hidden[last], lay.out_ld[last],
                           LOSS_CODES[s.spec.loss_function], steps, 0)
-        plan.head = self._upload("ehead" if eval_mode else "thead", head)
+        plan.head = self._upload(tag + "head", head)
         plan.P, plan.G, plan.M, plan.V, plan.Pb = (self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
                                                    self.V.data_ptr(), self.Pb.data_ptr())
         plan.slot_stride = self.stride
         plan.partials = self.partials.data_ptr()
         return plan
 
-    def _epoch_tables(self, plan: L.MlpPlan) -> int:
-        """Gather keys and optimiser step bases change every epoch; returns the pack's step count."""
+    def _epoch_tables(self, plan: L.MlpPlan, slot_ids: Optional[List[int]] = None, tag: str = "t") -> int:
+        """Gather keys and optimiser step bases change every epoch; returns the chain's step count."""
         T = self.capacity
         gat = np.zeros(T, dtype=L.GATHER_DTYPE)
         opt = np.zeros(T, dtype=L.OPT_DTYPE)
         max_steps = 0
         x0_stride = self.rows_max * self.Fpad * 2
-        for slot, s in self.slots.items():
+        for slot in (sorted(self.slots) if slot_ids is None else slot_ids):
+            s = self.slots[slot]
             sp = s.spec
             b = min(sp.batch_size, self.n_train)
             steps = self.n_train // b
@@ -396,23 +446,78 @@ class HipPackEngine(PackEngine):
             opt[slot] = (sp.learning_rate, sp.beta1, sp.beta2, sp.eps, sp.weight_decay, sp.momentum,
                          sp.gradient_clipping, OPT_CODES[sp.optimizer], sp.warmup_steps, sp.total_steps,
                          s.layout.total, steps, s.step, (0, 0, 0))
-        plan.gather = self._upload("gather", gat)
-        plan.opt = self._upload("opt", opt)
+        plan.gather = self._upload(tag + "gather", gat)
+        plan.opt = self._upload(tag + "opt", opt)
         return max_steps
+
+    # ------------------------------------------------------------------ chains
+    def _n_chains(self) -> int:
+        if self.n_streams_override:
+            return max(1, min(MAX_STREAMS, self.n_streams_override, len(self.slots)))
+        return 1
+
+    def _drop_graphs(self) -> None:
+        for ch in self._chains:
+            if ch.graph:
+                self.lib.mt_mlp_graph_destroy(ch.graph)
+                ch.graph = None
+
+    def _build_chains(self) -> None:
+        torch.cuda.synchronize(self.device)      # nothing may still be replaying a graph that is about to go
+        self._drop_graphs()
+        n = self._n_chains()
+        # deal slots round-robin in (batch size, size) order so every chain gets a similar mix and step count
+        order = sorted(self.slots, key=lambda k: (self.slots[k].spec.batch_size, -self.slots[k].layout.total, k))
+        self._chains = []
+        for c in range(n):
+            ch = _Chain()
+            ch.ids = sorted(order[c::n])
+            ch.tag = f"t{c}_"
+            ch.plan = self._build_plan(False, ch.ids, ch.tag, None if c == 0 else self._chain_scratch[c - 1])
+            ch.steps = 0
+            ch.counter = self._counters[c:c + 1]
+            ch.graph = None
+            self._chains.append(ch)
+        if n > 1:
+            torch.cuda.synchronize(self.device)
+            for ch, st in zip(self._chains, self._streams):
+                self._epoch_tables(ch.plan, ch.ids, ch.tag)       # gives the per-epoch tables their (stable) addresses
+                err = C.c_int(0)
+                ch.graph = self.lib.mt_mlp_graph_create(C.byref(ch.plan), GRAPH_STEPS, ch.counter.data_ptr(),
+                                                        st.cuda_stream, C.byref(err))
+                if not ch.graph:
+                    raise L.KernelLibraryError(f"hipGraph capture of a training block failed with code {err.value}")
 
     # ------------------------------------------------------------------ training / evaluation
     def train_epoch(self):
         if not self.slots:
             return
-        if self._dirty or "train_plan" not in self._tables:
-            self._tables["train_plan"] = self._build_plan(eval_mode=False)
+        if self._dirty or not self._chains:
+            self._build_chains()
             self._tables["eval_plan"] = self._build_plan(eval_mode=True)
             self._dirty = False
-        plan = self._tables["train_plan"]
-        steps = self._epoch_tables(plan)
+        for ch in self._chains:
+            ch.steps = self._epoch_tables(ch.plan, ch.ids, ch.tag)
         self.loss_acc.zero_()
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        L.check(self.lib.mt_mlp_train_steps(C.byref(plan), 0, steps, stream), "mt_mlp_train_steps")
+        main = torch.cuda.current_stream(self.device)
+        if len(self._chains) == 1:
+            ch = self._chains[0]
+            L.check(self.lib.mt_mlp_train_steps(C.byref(ch.plan), 0, ch.steps, main.cuda_stream), "mt_mlp_train_steps")
+        else:
+            self._counters.zero_()
+            pairs = list(zip(self._chains, self._streams))
+            for _, st in pairs:
+                st.wait_stream(main)           # tables, counters and zeroed loss accumulators were issued on `main`
+            blocks = [ch.steps // GRAPH_STEPS for ch in self._chains]
+            for b in range(max(blocks)):       # interleaved so that no chain gets a head start
+                for (ch, st), nb in zip(pairs, blocks):
+                    if b < nb:
+                        L.check(self.lib.mt_mlp_graph_replay(ch.graph, 1, st.cuda_stream), "mt_mlp_graph_replay")
+            for (ch, st), nb in zip(pairs, blocks):
+                L.check(self.lib.mt_mlp_train_steps_at(C.byref(ch.plan), ch.counter.data_ptr(),
+                                                       ch.steps - nb * GRAPH_STEPS, st.cuda_stream),
+                        "mt_mlp_train_steps_at")
+                main.wait_stream(st)
         losses = self.loss_acc.to("cpu")           # the epoch's only host synchronisation
         for slot, s in self.slots.items():
             n = self.n_train // min(s.spec.batch_size, self.n_train)
@@ -424,7 +529,7 @@ class HipPackEngine(PackEngine):
         if not self.slots:
             return {}
         if self._dirty or "eval_plan" not in self._tables:
-            self._tables["train_plan"] = self._build_plan(eval_mode=False)
+            self._build_chains()
             self._tables["eval_plan"] = self._build_plan(eval_mode=True)
             self._dirty = False
         plan = self._tables["eval_plan"]
@@ -439,3 +544,8 @@ class HipPackEngine(PackEngine):
                          "validation_mse": float(m[slot, 1]) / self.n_val,
                          "validation_mape": 100.0 * float(m[slot, 2]) / self.n_val}
         return out
+
+    def close(self) -> None:
+        if self._chains:
+            torch.cuda.synchronize(self.device)
+            self._drop_graphs()

@@ -93,3 +93,21 @@ def test_end_to_end_packed_search_on_gpu(tmp_path):
     assert len(an.trials) == 24 and an.stats["engine"] == "hip"
     assert an.best_result["validation_loss"] < 0.3 * float(val[1].var())
     assert an.best_checkpoint is not None
+
+
+def test_concurrent_chains_match_single_stream():
+    """Splitting a pack into concurrent per-stream chains changes scheduling, never a trial's arithmetic."""
+    from mitune.packed import PackedTrainable
+    from mitune.packed.engine_hip import HipPackEngine
+    train, val = _data(seed=4)
+    cfgs = [(i, dict(CONFIGS[i % 4], learning_rate=1e-3 * (1 + i % 3))) for i in range(8)]
+    out = {}
+    for streams in (1, 4):
+        tr = PackedTrainable(train=train, val=val, max_epochs=2, val_chunk=512,
+                             model_kwargs={"max_width": 256, "max_layers": 3, "max_batch": 512, "streams": streams})
+        hist, states = _run(HipPackEngine, tr, cfgs, list(range(8)), 2, device="cuda", capacity=8, seed=2)
+        out[streams] = (hist, states)
+    for slot in range(8):
+        a, b = out[1][0][-1][slot], out[4][0][-1][slot]
+        assert a["validation_mse"] == pytest.approx(b["validation_mse"], rel=2e-3), slot
+        assert a["train_loss"] == pytest.approx(b["train_loss"], rel=2e-3), slot

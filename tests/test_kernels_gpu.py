@@ -30,9 +30,10 @@ def _up(arr: np.ndarray) -> torch.Tensor:
 def _tiles(L, dims):
     """dims: list of (group, I, J) -> plain (unbalanced) tile list incl. one padding entry."""
     rows = [(-1, 0, 0)]
+    edge = 256 if NSTAGE == 256 else 128
     for g, i, j in dims:
-        for ti in range((i + 127) // 128):
-            for tj in range((j + 127) // 128):
+        for ti in range((i + edge - 1) // edge):
+            for tj in range((j + edge - 1) // edge):
                 rows.append((g, ti, tj))
     return np.array(rows, dtype=L.TILE_DTYPE)
 
@@ -44,7 +45,7 @@ def _rand_bf16(*shape, scale=1.0, gen=None):
 NSTAGE = 0          # 0: launcher picks the pipeline depth; the parametrised test below forces both forms
 
 
-@pytest.fixture(params=[2, 4], autouse=True)
+@pytest.fixture(params=[2, 4, 256], autouse=True)
 def _both_pipeline_depths(request, monkeypatch):
     monkeypatch.setattr(sys.modules[__name__], "NSTAGE", request.param)
 
