@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from .transformer import SelfAttention
 from ..ops.elementwise import dropout
 from ..ops.layernorm import residual_layer_norm
+from ..ops.linear import linear
 
 
 class FeatureTokenizer(nn.Module):
@@ -43,8 +44,8 @@ class ReGLU(nn.Module):
         self.p = dropout
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        a, g = self.up(x).chunk(2, dim=-1)
-        return self.down(dropout(a * F.relu(g), self.p, self.training))
+        a, g = linear(x, self.up.weight, self.up.bias).chunk(2, dim=-1)
+        return linear(dropout(a * F.relu(g), self.p, self.training), self.down.weight, self.down.bias)
 
 
 class FTBlock(nn.Module):

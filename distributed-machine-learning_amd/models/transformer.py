@@ -39,6 +39,7 @@ from ..ops.attention import short_attention
 from ..ops.elementwise import depthwise_conv1d, dropout, pe_add_dropout
 from ..ops.head_mlp import head_mlp
 from ..ops.layernorm import residual_layer_norm
+from ..ops.linear import linear
 
 ATTENTION_TYPES = ("scaled_dot_product", "multi_head_attention", "linear_attention")
 
@@ -116,11 +117,11 @@ class SelfAttention(nn.Module):
     def forward(self, query: torch.Tensor, key: Optional[torch.Tensor] = None, value: Optional[torch.Tensor] = None
                 ) -> Tuple[torch.Tensor, None]:
         x = query                                  # self-attention: key/value arguments are accepted, not used
-        q, k = self.qk_proj(x).chunk(2, dim=-1)
-        v = self._mix(self.v_proj(x))
+        q, k = linear(x, self.qk_proj.weight, self.qk_proj.bias).chunk(2, dim=-1)
+        v = self._mix(linear(x, self.v_proj.weight, self.v_proj.bias))
         o = short_attention(_split_heads(q, self.h), _split_heads(k, self.h), _split_heads(v, self.h),
                             kind=self.kind, dropout_p=self.p if self.training else 0.0)
-        return self.out_proj(_merge_heads(o)), None
+        return linear(_merge_heads(o), self.out_proj.weight, self.out_proj.bias), None
 
 
 class LinearAttention(SelfAttention):
@@ -240,7 +241,8 @@ class _PostNormLayer(nn.Module):
         p = self.p if self.training else 0.0
         a, _ = self.self_attn(x)
         x = residual_layer_norm(a, x, self.norm1.weight, self.norm1.bias, self.norm1.eps, dropout_p=p)
-        f = self.linear2(dropout(F.relu(self.linear1(x)), p, self.training))
+        f = linear(dropout(F.relu(linear(x, self.linear1.weight, self.linear1.bias)), p, self.training),
+                   self.linear2.weight, self.linear2.bias)
         return residual_layer_norm(f, x, self.norm2.weight, self.norm2.bias, self.norm2.eps, dropout_p=p)
 
 

@@ -151,7 +151,8 @@ __device__ __forceinline__ float colsum_stage(const uint8_t* ldsA, int tid) {
   return s;
 }
 
-// One 128x128 output tile.  ksplits > 1 (wgrad only): tile.ti carries the split index in its high byte.
+// One 128x128 output tile.  ksplits > 1 (wgrad only): tile.ti (int16) carries the split index in bits 8..14,
+// so at most 127 splits.
 template <int MODE, int NSTAGE>
 __device__ __forceinline__ void gemm_tile(const MtGemmGroup* __restrict__ groups, const MtTile tile, int step,
                                           int flags, int arow0, int i_override, int ksplits, size_t split_stride,
@@ -602,7 +603,7 @@ extern "C" int mt_gemm_launch(int mode, const MtGemmGroup* groups, const MtTile*
                               int flags, int arow0, int i_override, int ksplits, size_t split_stride, int nstage,
                               hipStream_t stream) {
   if (ntiles <= 0) return 0;
-  if (ksplits < 1 || ksplits > 255 || (mode != 2 && ksplits != 1)) return -5;
+  if (ksplits < 1 || ksplits > 127 || (mode != 2 && ksplits != 1)) return -5;
   dim3 grid(ntiles), block(NTHREADS);
   if (nstage == 256) {
 #define MT_GEMM_BIG(M, KS, SS) \
@@ -635,7 +636,7 @@ extern "C" int mt_gemm_bwd_launch(const MtGemmGroup* wgroups, const MtTile* wtil
                                   const MtGemmGroup* dgroups, const MtTile* dtiles, int n_dtiles, int step,
                                   int ksplits, size_t split_stride, int nstage, hipStream_t stream) {
   if (n_wtiles + n_dtiles <= 0) return 0;
-  if (ksplits < 1 || ksplits > 255) return -5;
+  if (ksplits < 1 || ksplits > 127) return -5;
   dim3 grid(n_wtiles + n_dtiles), block(NTHREADS);
   if (nstage == 256) {
     hipLaunchKernelGGL(mt_gemm256_bwd_kernel, grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles, step,
@@ -648,5 +649,49 @@ extern "C" int mt_gemm_bwd_launch(const MtGemmGroup* wgroups, const MtTile* wtil
   else
     hipLaunchKernelGGL(mt_gemm_bwd_kernel<2>, grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles, step,
                        ksplits, split_stride, mt_step_base_tls);
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Stand-alone weight gradient of one dense layer:  dW[out][in] = dY[M][out]^T . X[M][in]  (+ db = column sums of dY),
+// contraction over M tokens split `ksplits` ways into f32 slabs that the caller adds.  Same tile code as the grouped
+// path (mode TN), but the single group and the tile coordinates come from kernel arguments and blockIdx, so no
+// descriptor table has to be uploaded per call (this runs inside autograd, under hipGraph capture).  For the long,
+// skinny shapes of token-major Transformer layers (M ~ 10^4..10^5, out/in a few hundred) the BLAS library picks a
+// 64x64 tile without splitting the contraction and leaves most CUs idle.
+template <int NSTAGE>
+__global__ __launch_bounds__(NTHREADS) void mt_wgrad_single_kernel(MtGemmGroup g, int tiles_i, int ksplits,
+                                                                   size_t split_stride, int flags) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * STAGE_BYTES];
+  const int b = blockIdx.x;
+  const int sp = b % ksplits, t = b / ksplits;
+  MtTile tile;
+  tile.group = 0;
+  tile.ti = (int16_t)((t % tiles_i) | (sp << 8));
+  tile.tj = (int16_t)(t / tiles_i);
+  gemm_tile<2, NSTAGE>(&g, tile, 0, flags, 0, 0, ksplits, split_stride, lds);
+}
+
+// C: f32 [ksplits][split_stride] slabs, slab s holds dW partial at offset 0 (row stride `in`); db (may be null): f32,
+// slab s of it at db + s * split_stride.  M, out, in: out % 8 == 0 and in % 8 == 0 (16-byte operand rows).
+extern "C" int mt_wgrad_single_launch(const void* dY, const void* X, float* C, float* db, int M, int out, int in,
+                                      int ksplits, size_t split_stride, hipStream_t stream) {
+  if (M <= 0 || out <= 0 || in <= 0) return 0;
+  if ((out & 7) || (in & 7) || ksplits < 1 || ksplits > 127) return -2;
+  const int tiles_i = (out + BM - 1) / BM, tiles_j = (in + BN - 1) / BN;
+  if (tiles_i > 255) return -2;
+  MtGemmGroup g;
+  g.A = dY; g.B = X; g.C = C; g.aux = nullptr; g.aux_out = db;
+  g.I = out; g.J = in; g.KK = M;
+  g.lda = out; g.ldb = in; g.ldc = in; g.ldaux = 0;
+  g.active_steps = 1;
+  const int nblocks = tiles_i * tiles_j * ksplits;
+  const int flags = db != nullptr ? MT_GEMM_FLAG_DBIAS : 0;
+  if (nblocks <= 320)
+    hipLaunchKernelGGL(mt_wgrad_single_kernel<4>, dim3(nblocks), dim3(NTHREADS), 0, stream, g, tiles_i, ksplits,
+                       split_stride, flags);
+  else
+    hipLaunchKernelGGL(mt_wgrad_single_kernel<2>, dim3(nblocks), dim3(NTHREADS), 0, stream, g, tiles_i, ksplits,
+                       split_stride, flags);
   return (int)hipGetLastError();
 }

@@ -1,0 +1,67 @@
+"""Dense layer whose weight gradient runs on the split-contraction MFMA kernel.
+
+``linear(x, weight, bias)`` is ``F.linear`` everywhere except in one place: on a GPU, under bf16 autocast, with a long
+token dimension (FT-Transformer and sequence-encoder layers see M = batch x tokens ~ 10^4..10^5 rows against a few
+hundred features), the backward's ``dW = dY^T X`` is a long skinny contraction for which the BLAS library picked a
+64x64 tile and no K split (87 TFLOP/s measured).  Here it goes to ``mt_wgrad_single_launch`` (``csrc/gemm.hip``):
+128x128 tiles, the token dimension split over enough workgroups to fill the chip, f32 partial slabs added in a fixed
+order, and the bias gradient produced by the same pass from the tiles it already holds.  Forward and the input
+gradient stay library GEMMs.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+MIN_ROWS = 4096        # below this the library GEMM is fine and the slab reduction is pure overhead
+
+
+def _eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    if not (x.is_cuda and torch.is_autocast_enabled() and torch.is_grad_enabled() and weight.requires_grad):
+        return False
+    if torch.get_autocast_dtype("cuda") != torch.bfloat16:
+        return False
+    out_f, in_f = weight.shape
+    rows = x.numel() // max(in_f, 1)
+    return rows >= MIN_ROWS and out_f % 8 == 0 and in_f % 8 == 0 and out_f <= 128 * 255
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if _eligible(x, weight):
+        return SplitKLinear.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
+class SplitKLinear(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        from . import lib as L
+        so = L.load()
+        x, weight = ctx.saved_tensors
+        out_f, in_f = weight.shape
+        dyc = dy.reshape(-1, out_f).to(torch.bfloat16).contiguous()
+        xc = x.reshape(-1, in_f).contiguous()
+        M = xc.shape[0]
+        dx = (dyc @ weight).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        tiles = ((out_f + 127) // 128) * ((in_f + 127) // 128)
+        ksplits = max(1, min(127, (M + 63) // 64, (768 + tiles - 1) // tiles))     # 127: split index field
+        slab = (out_f * in_f + out_f + 63) // 64 * 64
+        arena = torch.empty(ksplits, slab, device=x.device, dtype=torch.float32)
+        db_ptr = arena.data_ptr() + out_f * in_f * 4 if ctx.has_bias else None
+        L.check(so.mt_wgrad_single_launch(dyc.data_ptr(), xc.data_ptr(), arena.data_ptr(), db_ptr, M, out_f, in_f,
+                                          ksplits, slab, torch.cuda.current_stream(x.device).cuda_stream),
+                "mt_wgrad_single_launch")
+        total = arena.sum(0) if ksplits > 1 else arena[0]
+        dw = total[:out_f * in_f].view(out_f, in_f)
+        db = total[out_f * in_f:out_f * in_f + out_f] if ctx.has_bias else None
+        return dx, dw, db

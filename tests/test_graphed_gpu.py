@@ -303,3 +303,28 @@ def test_many_graphs_with_dropout_and_eager_work_between_epochs_stay_finite():
         eng.train_epoch()
         ev = eng.evaluate()
         assert all(math.isfinite(v["validation_mse"]) and math.isfinite(v["train_loss"]) for v in ev.values())
+
+
+# ------------------------------------------------------------------ split-contraction weight gradient
+@pytest.mark.parametrize("M,in_f,out_f", [(66560, 192, 576), (8192, 256, 192), (5000, 72, 40)])
+def test_split_k_linear_matches_reference(M, in_f, out_f):
+    from mitune.ops.linear import SplitKLinear, linear
+    x = _rand(M, in_f, seed=1).requires_grad_()
+    w = _rand(out_f, in_f, seed=2, scale=in_f ** -0.5).requires_grad_()
+    b = _rand(out_f, seed=3, scale=0.1).requires_grad_()
+    dy = _rand(M, out_f, seed=4)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = linear(x, w, b)
+        assert "SplitKLinear" in type(y.grad_fn).__name__
+    y.backward(dy.to(y.dtype))
+    got = (y.float().detach(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+    assert got[2].dtype == torch.float32
+    x.grad = w.grad = b.grad = None
+    # reference on the same bf16-rounded operands, accumulated in f32
+    xb, wb, dyb = x.detach().bfloat16().float(), w.detach().bfloat16().float(), dy.bfloat16().float()
+    ref_y = xb @ wb.t() + b.detach().bfloat16().float()
+    ref_dw, ref_db, ref_dx = dyb.t() @ xb, dyb.sum(0), dyb @ wb
+    assert torch.allclose(got[0], ref_y, rtol=2e-2, atol=2e-2 * ref_y.abs().max().item())
+    assert torch.allclose(got[2], ref_dw, rtol=1e-3, atol=1e-3 * ref_dw.abs().max().item())
+    assert torch.allclose(got[3], ref_db, rtol=1e-3, atol=1e-3 * ref_db.abs().max().item())
+    assert torch.allclose(got[1], ref_dx, rtol=2e-2, atol=2e-2 * ref_dx.abs().max().item())
