@@ -21,25 +21,28 @@
 #include "mt_common.h"
 
 #define AT_THREADS 256
-#define AT_PITCH_CH 8          // 16-byte chunks per row of a [row][64] image
-#define AT_IMG_BYTES (128 * 128)
+// Q/K/V/dO images are [rows_pad][64] bf16 (8 chunks of 16 B per row) or, when both head dims are <= 32, [rows_pad][32]
+// (4 chunks): half the LDS, so twice the workgroups per CU for the small heads of narrow models (d_model/h = 24..32).
 #define AT_RELU_EPS 1e-6f
 
 typedef __attribute__((address_space(3))) uint8_t at_lds_u8;
 typedef __attribute__((ext_vector_type(8))) short at_s16x8;
 
 __device__ __forceinline__ int img_off(int row, int chunk, int cpr) {
-  return row * cpr * 16 + ((chunk ^ (row & (cpr - 1))) << 4);
+  // 64-byte rows put rows r and r+4 on the same banks, so their swizzle also folds in bits 2..3 of the row
+  const int swz = (cpr == 4) ? ((row ^ (row >> 2)) & 3) : (row & (cpr - 1));
+  return row * cpr * 16 + ((chunk ^ swz) << 4);
 }
 
-// global [rows][cols] bf16 (row stride ld elements) -> zero-padded LDS image [rows_pad][64]
+// global [rows][cols] bf16 (row stride ld elements) -> zero-padded LDS image [rows_pad][PCHQ * 8]
+template <int PCHQ>
 __device__ __forceinline__ void stage_image(uint8_t* lds, const uint16_t* __restrict__ src, int rows, int cols, int ld,
                                             int rows_pad, int tid) {
-  for (int q = tid; q < rows_pad * AT_PITCH_CH; q += AT_THREADS) {
-    const int r = q >> 3, c = q & 7;
+  for (int q = tid; q < rows_pad * PCHQ; q += AT_THREADS) {
+    const int r = q / PCHQ, c = q % PCHQ;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (r < rows && c * 8 < cols) v = *reinterpret_cast<const u32x4*>(src + (size_t)r * ld + c * 8);
-    *reinterpret_cast<u32x4*>(lds + img_off(r, c, AT_PITCH_CH)) = v;
+    *reinterpret_cast<u32x4*>(lds + img_off(r, c, PCHQ)) = v;
   }
 }
 
@@ -80,22 +83,22 @@ __device__ __forceinline__ float group_max(float v) {
 }
 
 // Scores for 16 queries (block qb) against all keys, transposed: acc[kb][j] = S[query][key = 16kb + 4g + j].
-template <int NKB>
+template <int NKB, int PCHQ>
 __device__ __forceinline__ void scores_T(f32x4 (&acc)[NKB], const uint8_t* ldsK, const uint8_t* ldsQ, int qb, int dsteps,
                                          int lane) {
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) acc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int ks = 0; ks < dsteps; ++ks) {
-    const bf16x8 qf = frag_rows(ldsQ, qb * 16, ks, lane, AT_PITCH_CH);
+    const bf16x8 qf = frag_rows(ldsQ, qb * 16, ks, lane, PCHQ);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      const bf16x8 kf = frag_rows(ldsK, kb * 16, ks, lane, AT_PITCH_CH);
+      const bf16x8 kf = frag_rows(ldsK, kb * 16, ks, lane, PCHQ);
       acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, acc[kb], 0, 0, 0);
     }
   }
 }
 
-template <int NKB>   // NKB = padded sequence length / 16 (2, 4, 6 or 8)
+template <int NKB, int PCHQ>   // NKB = padded sequence length / 16 (2, 4, 6 or 8); PCHQ = 16-byte chunks per image row
 __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const uint16_t* __restrict__ Q,
                                                                  const uint16_t* __restrict__ K,
                                                                  const uint16_t* __restrict__ V,
@@ -103,20 +106,21 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const uint16_t*
                                                                  uint16_t* __restrict__ O, float* __restrict__ stat,
                                                                  int S, int dk, int dv, float scale, float keep_scale,
                                                                  int kind) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * AT_IMG_BYTES];
-  uint8_t *ldsQ = lds, *ldsK = lds + AT_IMG_BYTES, *ldsV = lds + 2 * AT_IMG_BYTES;
+  constexpr int SP = NKB * 16;
+  constexpr int IMG = SP * PCHQ * 16;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * IMG];
+  uint8_t *ldsQ = lds, *ldsK = lds + IMG, *ldsV = lds + 2 * IMG;
   const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, fr = lane & 15;
-  constexpr int SP = NKB * 16;
-  stage_image(ldsQ, Q + (size_t)bh * S * dk, S, dk, dk, SP, tid);
-  stage_image(ldsK, K + (size_t)bh * S * dk, S, dk, dk, SP, tid);
-  stage_image(ldsV, V + (size_t)bh * S * dv, S, dv, dv, SP, tid);
+  stage_image<PCHQ>(ldsQ, Q + (size_t)bh * S * dk, S, dk, dk, SP, tid);
+  stage_image<PCHQ>(ldsK, K + (size_t)bh * S * dk, S, dk, dk, SP, tid);
+  stage_image<PCHQ>(ldsV, V + (size_t)bh * S * dv, S, dv, dv, SP, tid);
   __syncthreads();
   const int dsteps = (dk + 31) / 32, nvb = (dv + 15) / 16;
 
   for (int qb = wave; qb < NKB; qb += 4) {
     f32x4 acc[NKB];
-    scores_T<NKB>(acc, ldsK, ldsQ, qb, dsteps, lane);
+    scores_T<NKB, PCHQ>(acc, ldsK, ldsQ, qb, dsteps, lane);
     const int query = qb * 16 + fr;
     float norm;
     if (kind == 0) {
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const uint16_t*
 #pragma unroll
       for (int s2 = 0; s2 < NKB / 2; ++s2) {
         const bf16x8 pf = pack_frag(acc[2 * s2], acc[2 * s2 + 1]);
-        const bf16x8 vf = frag_cols(ldsV, nb * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, lane, AT_PITCH_CH);
+        const bf16x8 vf = frag_cols(ldsV, nb * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, lane, PCHQ);
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o, 0, 0, 0);
       }
       const int n = nb * 16 + fr;
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const uint16_t*
   }
 }
 
-template <int NKB>
+template <int NKB, int PCHQ>
 __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const uint16_t* __restrict__ Q,
                                                                  const uint16_t* __restrict__ K,
                                                                  const uint16_t* __restrict__ V,
@@ -205,23 +209,24 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const uint16_t*
   constexpr int SP = NKB * 16;
   constexpr int PCH = (SP <= 64) ? 8 : 16;        // chunks per row of the [key][query] images
   constexpr int PT_BYTES = SP * PCH * 16;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * AT_IMG_BYTES + 2 * PT_BYTES];
-  uint8_t *ldsQ = lds, *ldsK = lds + AT_IMG_BYTES, *ldsV = lds + 2 * AT_IMG_BYTES, *ldsdO = lds + 3 * AT_IMG_BYTES;
-  uint8_t *ldsPT = lds + 4 * AT_IMG_BYTES, *ldsST = ldsPT + PT_BYTES;
+  constexpr int IMG = SP * PCHQ * 16;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * IMG + 2 * PT_BYTES];
+  uint8_t *ldsQ = lds, *ldsK = lds + IMG, *ldsV = lds + 2 * IMG, *ldsdO = lds + 3 * IMG;
+  uint8_t *ldsPT = lds + 4 * IMG, *ldsST = ldsPT + PT_BYTES;
   const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, fr = lane & 15;
-  stage_image(ldsQ, Q + (size_t)bh * S * dk, S, dk, dk, SP, tid);
-  stage_image(ldsK, K + (size_t)bh * S * dk, S, dk, dk, SP, tid);
-  stage_image(ldsV, V + (size_t)bh * S * dv, S, dv, dv, SP, tid);
-  stage_image(ldsdO, dO + (size_t)bh * S * dv, S, dv, dv, SP, tid);
+  stage_image<PCHQ>(ldsQ, Q + (size_t)bh * S * dk, S, dk, dk, SP, tid);
+  stage_image<PCHQ>(ldsK, K + (size_t)bh * S * dk, S, dk, dk, SP, tid);
+  stage_image<PCHQ>(ldsV, V + (size_t)bh * S * dv, S, dv, dv, SP, tid);
+  stage_image<PCHQ>(ldsdO, dO + (size_t)bh * S * dv, S, dv, dv, SP, tid);
   __syncthreads();
   const int dsteps = (dk + 31) / 32, vsteps = (dv + 31) / 32, nkd = (dk + 15) / 16, nvb = (dv + 15) / 16;
 
   // ---------------------------------------------------------------- query-parallel phase
   for (int qb = wave; qb < NKB; qb += 4) {
     f32x4 p[NKB], dp[NKB];
-    scores_T<NKB>(p, ldsK, ldsQ, qb, dsteps, lane);
-    scores_T<NKB>(dp, ldsV, ldsdO, qb, vsteps, lane);     // dP^T[key][query] = V . dO^T, same layout
+    scores_T<NKB, PCHQ>(p, ldsK, ldsQ, qb, dsteps, lane);
+    scores_T<NKB, PCHQ>(dp, ldsV, ldsdO, qb, vsteps, lane);     // dP^T[key][query] = V . dO^T, same layout
     const int query = qb * 16 + fr;
     const float st = (query < S) ? stat[(size_t)bh * S + query] : 1.f;
     const float inv_z = (kind == 1) ? 1.f / st : 0.f;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const uint16_t*
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s2 = 0; s2 < NKB / 2; ++s2) {
-        const bf16x8 kf = frag_cols(ldsK, db * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, lane, AT_PITCH_CH);
+        const bf16x8 kf = frag_cols(ldsK, db * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, lane, PCHQ);
         const bf16x8 sf = pack_frag(dp[2 * s2], dp[2 * s2 + 1]);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, a, 0, 0, 0);
       }
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const uint16_t*
 #pragma unroll
       for (int s2 = 0; s2 < NKB / 2; ++s2) {
         const bf16x8 pf = frag_rows(ldsPT, kb * 16, s2, lane, PCH);
-        const bf16x8 of = frag_cols(ldsdO, nb * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, lane, AT_PITCH_CH);
+        const bf16x8 of = frag_cols(ldsdO, nb * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, lane, PCHQ);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, of, a, 0, 0, 0);
       }
       const int n = nb * 16 + fr;
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const uint16_t*
 #pragma unroll
       for (int s2 = 0; s2 < NKB / 2; ++s2) {
         const bf16x8 sf = frag_rows(ldsST, kb * 16, s2, lane, PCH);
-        const bf16x8 qf = frag_cols(ldsQ, db * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, lane, AT_PITCH_CH);
+        const bf16x8 qf = frag_cols(ldsQ, db * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, lane, PCHQ);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, qf, a, 0, 0, 0);
       }
       const int d = db * 16 + fr;
@@ -333,9 +338,11 @@ extern "C" int mt_attn_fwd_launch(const void* Q, const void* K, const void* V, c
   if (BH <= 0) return 0;
   if (S < 1 || S > 128 || dk > 64 || dv > 64 || (dk & 7) || (dv & 7)) return -2;
   dim3 grid(BH), block(AT_THREADS);
-#define AT_FWD(N)                                                                                              \
-  hipLaunchKernelGGL(mt_attn_fwd_kernel<N>, grid, block, 0, stream, (const uint16_t*)Q, (const uint16_t*)K,    \
+  const bool narrow = dk <= 32 && dv <= 32;
+#define AT_FWD1(N, P)                                                                                          \
+  hipLaunchKernelGGL((mt_attn_fwd_kernel<N, P>), grid, block, 0, stream, (const uint16_t*)Q, (const uint16_t*)K, \
                      (const uint16_t*)V, (const uint8_t*)keep, (uint16_t*)O, stat, S, dk, dv, scale, keep_scale, kind)
+#define AT_FWD(N) do { if (narrow) AT_FWD1(N, 4); else AT_FWD1(N, 8); } while (0)
   switch (nkb_for(S)) {
     case 2: AT_FWD(2); break;
     case 4: AT_FWD(4); break;
@@ -344,6 +351,7 @@ extern "C" int mt_attn_fwd_launch(const void* Q, const void* K, const void* V, c
     default: return -3;
   }
 #undef AT_FWD
+#undef AT_FWD1
   return (int)hipGetLastError();
 }
 
@@ -353,10 +361,12 @@ extern "C" int mt_attn_bwd_launch(const void* Q, const void* K, const void* V, c
   if (BH <= 0) return 0;
   if (S < 1 || S > 128 || dk > 64 || dv > 64 || (dk & 7) || (dv & 7)) return -2;
   dim3 grid(BH), block(AT_THREADS);
-#define AT_BWD(N)                                                                                              \
-  hipLaunchKernelGGL(mt_attn_bwd_kernel<N>, grid, block, 0, stream, (const uint16_t*)Q, (const uint16_t*)K,    \
+  const bool narrow = dk <= 32 && dv <= 32;
+#define AT_BWD1(N, P)                                                                                          \
+  hipLaunchKernelGGL((mt_attn_bwd_kernel<N, P>), grid, block, 0, stream, (const uint16_t*)Q, (const uint16_t*)K, \
                      (const uint16_t*)V, (const uint16_t*)dO, (const uint8_t*)keep, stat, dQ, dK, dV, S, dk, dv, \
                      scale, keep_scale, kind)
+#define AT_BWD(N) do { if (narrow) AT_BWD1(N, 4); else AT_BWD1(N, 8); } while (0)
   switch (nkb_for(S)) {
     case 2: AT_BWD(2); break;
     case 4: AT_BWD(4); break;
