@@ -75,6 +75,8 @@ class PackedExecutor(Executor):
         self._queued: List[Event] = []
         self._awaiting: Dict[str, Optional[str]] = {}          # trial_id -> decision (None = not yet)
         self._epoch_time = 0.0
+        self._n_undecided = 0
+        self._hostname = socket.gethostname()
         self._diverged: set = set()
         self._t_total: Dict[str, float] = {}
         self.runner = None
@@ -112,20 +114,20 @@ class PackedExecutor(Executor):
             return out
         if not self._live:
             return []
-        if any(d is None for d in self._awaiting.values()):
+        if self._n_undecided > 0:
             return []      # the runner still owes decisions for the previous round
         t0 = time.time()
         self.engine.train_epoch()
         t1 = time.time()
         local = self.engine.evaluate()
         t2 = time.time()
-        table = torch.full((self.capacity, _REC), -1.0, dtype=torch.float64)
         mine = {slot: tid for tid, (r, slot) in self._place.items() if r == self.rank}
+        rows_local = [[-1.0] * _REC for _ in range(self.capacity)]
         for slot, m in local.items():
             tr = self._live[mine[slot]]
-            table[slot] = torch.tensor([tr.index, tr.training_iteration + 1, m["train_loss"],
-                                        m["validation_loss"], m["validation_mse"], m["validation_mape"]],
-                                       dtype=torch.float64)
+            rows_local[slot] = [float(tr.index), float(tr.training_iteration + 1), m["train_loss"], m["validation_loss"],
+                                m["validation_mse"], m["validation_mape"]]
+        table = torch.tensor(rows_local, dtype=torch.float64)         # one conversion, not one per slot
         gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
         t3 = time.time()
         self._epoch_time = t3 - t0
@@ -140,35 +142,37 @@ class PackedExecutor(Executor):
         rows = rows[rows[:, 0] >= 0]
         rows = rows[torch.argsort(rows[:, 0])]
         now = time.time()
+        const = {"time_this_iter_s": self._epoch_time, "timestamp": int(now),
+                 "date": time.strftime("%Y-%m-%d_%H-%M-%S", time.localtime(now)), "done": False,
+                 "experiment_id": self.experiment_id, "pid": os.getpid(), "hostname": self._hostname,
+                 "node_ip": "127.0.0.1"}
         events: List[Event] = []
         self._awaiting = {}
-        for row in rows.tolist():
-            tr = by_index[int(row[0])]
-            self._t_total[tr.trial_id] += self._epoch_time
-            diverged = not (math.isfinite(row[2]) and math.isfinite(row[3]))
-            if diverged and self.t.on_nonfinite == "error":
+        self._n_undecided = 0
+        on_nonfinite, isfinite, t_total, place = self.t.on_nonfinite, math.isfinite, self._t_total, self._place
+        for idx, it, train_loss, val_loss, val_mse, val_mape in rows.tolist():
+            tr = by_index[int(idx)]
+            tid = tr.trial_id
+            t_total[tid] += self._epoch_time
+            diverged = not (isfinite(train_loss) and isfinite(val_loss))
+            if diverged and on_nonfinite == "error":
                 # every rank sees the same table, so every rank frees the same slot
                 self._drop(tr)
                 self.stats["diverged"] += 1
-                events.append(Event("error", tr, error=f"non-finite loss at epoch {int(row[1])}: "
-                                                       f"train_loss={row[2]}, validation_loss={row[3]}"))
+                events.append(Event("error", tr, error=f"non-finite loss at epoch {int(it)}: "
+                                                       f"train_loss={train_loss}, validation_loss={val_loss}"))
                 continue
-            result = {
-                "training_iteration": int(row[1]), "train_loss": row[2], "validation_loss": row[3],
-                "validation_mse": row[4], "validation_mape": row[5],
-                "time_this_iter_s": self._epoch_time, "time_total_s": self._t_total[tr.trial_id],
-                "timestamp": int(now), "date": time.strftime("%Y-%m-%d_%H-%M-%S", time.localtime(now)),
-                "done": False, "trial_id": tr.trial_id, "experiment_id": self.experiment_id,
-                "pid": os.getpid(), "hostname": socket.gethostname(), "node_ip": "127.0.0.1",
-                "iterations_since_restore": int(row[1]),
-                "rank": self._place[tr.trial_id][0], "slot": self._place[tr.trial_id][1],
-            }
+            rank, slot = place[tid]
+            result = dict(const, training_iteration=int(it), train_loss=train_loss, validation_loss=val_loss,
+                          validation_mse=val_mse, validation_mape=val_mape, time_total_s=t_total[tid], trial_id=tid,
+                          iterations_since_restore=int(it), rank=rank, slot=slot)
             if diverged:
                 result["diverged"] = True
-                if self.t.on_nonfinite == "stop":
-                    self._diverged.add(tr.trial_id)
+                if on_nonfinite == "stop":
+                    self._diverged.add(tid)
                     self.stats["diverged"] += 1
-            self._awaiting[tr.trial_id] = None
+            self._awaiting[tid] = None
+            self._n_undecided += 1
             events.append(Event("result", tr, result=result))
         return events
 
@@ -176,8 +180,10 @@ class PackedExecutor(Executor):
         if trial.trial_id in self._diverged:      # a NaN/inf slot is retired whatever the scheduler said
             self._diverged.discard(trial.trial_id)
             decision = STOP
+        if self._awaiting.get(trial.trial_id, "") is None:
+            self._n_undecided -= 1
         self._awaiting[trial.trial_id] = decision
-        if all(d is not None for d in self._awaiting.values()):
+        if self._n_undecided == 0:
             self._flush()
 
     # ------------------------------------------------------------------ applying decisions

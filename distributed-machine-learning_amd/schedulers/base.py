@@ -63,9 +63,17 @@ class TrialScheduler:
         pass
 
     def choose_trial_to_run(self, runner) -> Optional[Trial]:
-        for t in runner.trials:
-            if t.status == PENDING:
+        nxt = getattr(runner, "next_pending", None)
+        if nxt is not None:                  # O(1): the runner keeps its PENDING trials in a queue
+            t = nxt()
+            if t is not None:
                 return t
+            if not runner.num_paused:
+                return None
+        else:
+            for t in runner.trials:
+                if t.status == PENDING:
+                    return t
         for t in runner.trials:
             if t.status == PAUSED and getattr(t, "resumable", True):
                 return t

@@ -8,6 +8,7 @@ scheduler (CONTINUE / STOP / PAUSE / RESTART) and the searcher, retry failed tri
 """
 from __future__ import annotations
 
+import collections
 import os
 import time
 from typing import Any, Callable, Dict, List, Optional, Sequence, Union
@@ -49,6 +50,9 @@ class TrialRunner:
         self.time_budget_s, self.fail_fast = time_budget_s, fail_fast
         self.trials: List[Trial] = []
         self._by_id: Dict[str, Trial] = {}
+        self._pending_q: "collections.deque[Trial]" = collections.deque()    # PENDING trials in arrival order
+        self.num_paused = 0
+        self._unfinished = 0
         self._searcher_done = False
         self._t0 = time.time()
         self._last_save = 0.0
@@ -61,7 +65,28 @@ class TrialRunner:
     def add_trial(self, trial: Trial) -> None:
         self.trials.append(trial)
         self._by_id[trial.trial_id] = trial
+        if trial.status == PENDING:
+            self._pending_q.append(trial)
+        elif trial.status == PAUSED:
+            self.num_paused += 1
+        if not trial.is_finished:
+            self._unfinished += 1
         self.scheduler.on_trial_add(self, trial)
+
+    def _set_status(self, trial: Trial, status: str) -> None:
+        """Status change with the O(1) bookkeeping that keeps scheduling cost linear in the number of trials."""
+        was_done, was_paused = trial.is_finished, trial.status == PAUSED
+        trial.set_status(status)
+        if status == PENDING:
+            self._pending_q.append(trial)
+        self.num_paused += int(status == PAUSED) - int(was_paused)
+        self._unfinished += int(was_done) - int(trial.is_finished)
+
+    def next_pending(self) -> Optional[Trial]:
+        q = self._pending_q
+        while q and q[0].status != PENDING:
+            q.popleft()
+        return q[0] if q else None
 
     def get_trial(self, trial_id: str) -> Optional[Trial]:
         return self._by_id.get(trial_id)
@@ -87,7 +112,7 @@ class TrialRunner:
     def is_finished(self) -> bool:
         if not self._searcher_done:
             return False
-        return all(t.is_finished for t in self.trials)
+        return self._unfinished == 0
 
     def _start_trials(self) -> None:
         while self.executor.has_capacity():
@@ -101,7 +126,7 @@ class TrialRunner:
 
     def _launch(self, trial: Trial) -> None:
         fresh = trial.start_time is None
-        trial.set_status(RUNNING)
+        self._set_status(trial, RUNNING)
         if fresh:
             for lg in self.loggers:
                 lg.on_trial_start(trial)
@@ -208,7 +233,7 @@ class TrialRunner:
     def _finish(self, trial: Trial, status: str) -> None:
         if trial.last_result:
             trial.last_result["done"] = True
-        trial.set_status(status)
+        self._set_status(trial, status)
         if status == TERMINATED:
             self.scheduler.on_trial_complete(self, trial, trial.last_result)
             self.searcher.on_trial_complete(trial.trial_id, trial.last_result, error=False)
@@ -228,14 +253,14 @@ class TrialRunner:
             donor = self._by_id.get(req["donor"])
             trial.config = req["config"]
             trial.restore_from = donor.checkpoint if donor is not None else trial.checkpoint
-            trial.set_status(PENDING)
+            self._set_status(trial, PENDING)
             self.stats["num_restarts"] += 1
             if trial.logdir:
                 dump_json(trial.config, os.path.join(trial.logdir, "params.json"))
             return
         if decision == PAUSE:
             trial.restore_from = trial.checkpoint
-            trial.set_status(PAUSED)
+            self._set_status(trial, PAUSED)
             return
         self._finish(trial, TERMINATED)
 
@@ -250,7 +275,7 @@ class TrialRunner:
             raise TuneError(f"trial {trial.trial_id} failed (fail_fast):\n{ev.error}")
         if self.max_failures < 0 or trial.num_failures <= self.max_failures:
             trial.restore_from = trial.checkpoint
-            trial.set_status(PENDING)      # retried from its newest checkpoint
+            self._set_status(trial, PENDING)      # retried from its newest checkpoint
             return
         self._finish(trial, ERROR)
 
@@ -296,4 +321,6 @@ class TrialRunner:
             self.trials.append(t)
             self._by_id[t.trial_id] = t
             if not t.is_finished:
+                self._unfinished += 1
+                self._pending_q.append(t)
                 self.scheduler.on_trial_add(self, t)

@@ -317,6 +317,18 @@ def grid_axes(space: Dict) -> List[Tuple[Tuple, List[Any]]]:
     return [(p, v.values) for p, v in _walk(space) if isinstance(v, GridSearch)]
 
 
+def _copy_containers(node: Any) -> Any:
+    """Copy of the dict/list skeleton of a search space; leaves (domains, scalars, user objects) are shared.
+    A full deepcopy per trial was a third of the scheduling cost of a 2048-trial search."""
+    if isinstance(node, dict):
+        return {k: _copy_containers(v) for k, v in node.items()}
+    if isinstance(node, list):
+        return [_copy_containers(v) for v in node]
+    if isinstance(node, tuple):
+        return tuple(_copy_containers(v) for v in node)
+    return node
+
+
 def resolve(space: Dict, rng: np.random.Generator, grid_assignment: Dict[Tuple, Any] | None = None) -> Dict:
     """Sample one concrete config from ``space``.
 
@@ -324,7 +336,7 @@ def resolve(space: Dict, rng: np.random.Generator, grid_assignment: Dict[Tuple, 
     ``sample_from`` leaves are retried until every key they read has been resolved, which
     gives dependency-ordered evaluation without declaring the dependencies.
     """
-    cfg = copy.deepcopy(space)
+    cfg = _copy_containers(space)
     if grid_assignment:
         for p, v in grid_assignment.items():
             _set(cfg, p, v)

@@ -87,12 +87,19 @@ class Trial:
     def record_result(self, result: Dict) -> None:
         self.results.append(result)
         self.last_result = result
+        best = self.metric_best
         for k, v in result.items():
-            if isinstance(v, (int, float)) and not isinstance(v, bool):
-                b = self.metric_best.setdefault(k, {"min": v, "max": v})
-                if v == v:  # NaN never becomes a best value
-                    b["min"] = v if b["min"] != b["min"] else min(b["min"], v)
-                    b["max"] = v if b["max"] != b["max"] else max(b["max"], v)
+            tv = type(v)
+            if tv is float or tv is int:
+                b = best.get(k)
+                if b is None:
+                    best[k] = {"min": v, "max": v}
+                elif v == v:  # NaN never becomes a best value
+                    lo, hi = b["min"], b["max"]
+                    if lo != lo or v < lo:
+                        b["min"] = v
+                    if hi != hi or v > hi:
+                        b["max"] = v
 
     # ------------------------------------------------------------------ persistence
     def to_json(self) -> Dict:
