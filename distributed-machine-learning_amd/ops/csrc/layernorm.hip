@@ -66,6 +66,69 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_fwd_kernel(const float* __re
   if (lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
 }
 
+// Narrow rows (d <= 256: one float4 per lane).  One row per wave leaves a wave with two 16-byte loads in flight and
+// two serial reductions; here a wave takes LN_SMALL_ROWS rows at once -- every load is issued before the first
+// reduction, out-of-range lanes read a clamped address and select zero (no branch around a load), and the
+// reductions of the rows interleave.
+#define LN_SMALL_ROWS 4
+__global__ __launch_bounds__(LN_THREADS) void mt_ln_fwd_small_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                                     const uint8_t* __restrict__ keep,
+                                                                     const float* __restrict__ w, const float* __restrict__ b,
+                                                                     float* __restrict__ y, float* __restrict__ z,
+                                                                     float* __restrict__ stats, int M, int d, float eps,
+                                                                     float keep_scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * 4 + wave) * LN_SMALL_ROWS;
+  if (row0 >= M) return;
+  const int nv = d >> 2;
+  const bool col_ok = lane < nv;
+  const int c4 = col_ok ? 4 * lane : 0;
+  f32x4 v[LN_SMALL_ROWS];
+  float sum[LN_SMALL_ROWS];
+#pragma unroll
+  for (int i = 0; i < LN_SMALL_ROWS; ++i) {
+    const bool ok = col_ok && (row0 + i < M);
+    const size_t off = (size_t)(row0 + i < M ? row0 + i : row0) * d + c4;
+    f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+    const f32x4 rv = *reinterpret_cast<const f32x4*>(res + off);
+    if (keep != nullptr) {        // uniform
+      const uint32_t kw = *reinterpret_cast<const uint32_t*>(keep + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xv[e] *= ((kw >> (8 * e)) & 0xFFu) ? keep_scale : 0.f;
+    }
+    const f32x4 zv = xv + rv;
+    v[i] = ok ? zv : f32x4{0.f, 0.f, 0.f, 0.f};
+    sum[i] = (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  float mean[LN_SMALL_ROWS], rstd[LN_SMALL_ROWS];
+#pragma unroll
+  for (int i = 0; i < LN_SMALL_ROWS; ++i) mean[i] = wave_sum(sum[i]) / (float)d;
+#pragma unroll
+  for (int i = 0; i < LN_SMALL_ROWS; ++i) {
+    float var = 0.f;
+    if (col_ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float c0 = v[i][e] - mean[i]; var += c0 * c0; }
+    }
+    sum[i] = var;
+  }
+#pragma unroll
+  for (int i = 0; i < LN_SMALL_ROWS; ++i) rstd[i] = rsqrtf(wave_sum(sum[i]) / (float)d + eps);
+  const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c4), bv = *reinterpret_cast<const f32x4*>(b + c4);
+#pragma unroll
+  for (int i = 0; i < LN_SMALL_ROWS; ++i) {
+    if (col_ok && row0 + i < M) {
+      const size_t off = (size_t)(row0 + i) * d + c4;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean[i]) * rstd[i] * wv[e] + bv[e];
+      *reinterpret_cast<f32x4*>(z + off) = v[i];
+      *reinterpret_cast<f32x4*>(y + off) = o;
+    }
+    if (lane == 0 && row0 + i < M) { stats[2 * (size_t)(row0 + i)] = mean[i]; stats[2 * (size_t)(row0 + i) + 1] = rstd[i]; }
+  }
+}
+
 __global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                                const float* __restrict__ stats,
                                                                const uint8_t* __restrict__ keep,
@@ -158,8 +221,12 @@ extern "C" int mt_ln_fwd_launch(const float* x, const float* res, const void* ke
                                 hipStream_t stream) {
   if (M <= 0) return 0;
   if (d > 2048 || (d & 3)) return -2;
-  hipLaunchKernelGGL(mt_ln_fwd_kernel, dim3((M + 3) / 4), dim3(LN_THREADS), 0, stream, x, res, (const uint8_t*)keep, w,
-                     b, y, z, stats, M, d, eps, keep_scale);
+  if (d <= 256)
+    hipLaunchKernelGGL(mt_ln_fwd_small_kernel, dim3((M + 4 * LN_SMALL_ROWS - 1) / (4 * LN_SMALL_ROWS)), dim3(LN_THREADS), 0,
+                       stream, x, res, (const uint8_t*)keep, w, b, y, z, stats, M, d, eps, keep_scale);
+  else
+    hipLaunchKernelGGL(mt_ln_fwd_kernel, dim3((M + 3) / 4), dim3(LN_THREADS), 0, stream, x, res, (const uint8_t*)keep, w,
+                       b, y, z, stats, M, d, eps, keep_scale);
   return (int)hipGetLastError();
 }
 
