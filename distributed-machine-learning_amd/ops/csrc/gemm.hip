@@ -35,7 +35,7 @@
 // wgrad can split its contraction (the batch) over several workgroups: split s writes its partial sums to
 // slab s of the gradient buffer and the optimiser adds the slabs in order (deterministic, no atomics);
 // that trades bytes for latency when a pack has too few tiles to fill 256 CUs.
-#include "mt_common.h"
+#include "mt_bodies.h"
 
 #define BM 128
 #define BN 128
@@ -581,15 +581,18 @@ template <int NSTAGE>
 __global__ __launch_bounds__(NTHREADS) void mt_gemm_bwd_kernel(const MtGemmGroup* __restrict__ wgroups,
                                                                const MtTile* __restrict__ wtiles, int n_wtiles,
                                                                const MtGemmGroup* __restrict__ dgroups,
-                                                               const MtTile* __restrict__ dtiles, int step_imm,
-                                                               int ksplits, size_t split_stride,
-                                                               const int* __restrict__ step_base) {
+                                                               const MtTile* __restrict__ dtiles, int n_dtiles,
+                                                               int step_imm, int ksplits, size_t split_stride,
+                                                               const int* __restrict__ step_base, MtHeadReduceArgs hr) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * STAGE_BYTES];
   const int step = mt_step(step_imm, step_base);
-  if ((int)blockIdx.x < n_wtiles)
-    gemm_tile<2, NSTAGE>(wgroups, wtiles[blockIdx.x], step, MT_GEMM_FLAG_DBIAS, 0, 0, ksplits, split_stride, lds);
-  else
-    gemm_tile<1, NSTAGE>(dgroups, dtiles[blockIdx.x - n_wtiles], step, MT_GEMM_FLAG_MASK, 0, 0, 1, 0, lds);
+  const int b = (int)blockIdx.x;
+  if (b < n_wtiles)
+    gemm_tile<2, NSTAGE>(wgroups, wtiles[b], step, MT_GEMM_FLAG_DBIAS, 0, 0, ksplits, split_stride, lds);
+  else if (b < n_wtiles + n_dtiles)
+    gemm_tile<1, NSTAGE>(dgroups, dtiles[b - n_wtiles], step, MT_GEMM_FLAG_MASK, 0, 0, 1, 0, lds);
+  else      // riders of the last layer's launch: add up the head kernel's partial records, one workgroup per slot
+    mt_head_reduce_body(hr.slots, hr.ids, step, hr.scratch, hr.max_chunks, hr.rec, b - n_wtiles - n_dtiles);
 }
 
 // nstage: 2 = throughput form (two workgroups per CU), 4 = latency form (one workgroup per CU, three
@@ -632,24 +635,35 @@ extern "C" int mt_gemm_launch(int mode, const MtGemmGroup* groups, const MtTile*
   return (int)hipGetLastError();
 }
 
-extern "C" int mt_gemm_bwd_launch(const MtGemmGroup* wgroups, const MtTile* wtiles, int n_wtiles,
-                                  const MtGemmGroup* dgroups, const MtTile* dtiles, int n_dtiles, int step,
-                                  int ksplits, size_t split_stride, int nstage, hipStream_t stream) {
-  if (n_wtiles + n_dtiles <= 0) return 0;
+// hr.n_slots > 0 appends that many workgroups which reduce the head kernel's partial records (see mt_bodies.h).
+extern "C" int mt_gemm_bwd_head_launch(const MtGemmGroup* wgroups, const MtTile* wtiles, int n_wtiles,
+                                       const MtGemmGroup* dgroups, const MtTile* dtiles, int n_dtiles, int step,
+                                       int ksplits, size_t split_stride, int nstage, MtHeadReduceArgs hr,
+                                       hipStream_t stream) {
+  if (n_wtiles + n_dtiles + hr.n_slots <= 0) return 0;
   if (ksplits < 1 || ksplits > 127) return -5;
-  dim3 grid(n_wtiles + n_dtiles), block(NTHREADS);
+  if (nstage == 256 && hr.n_slots > 0) return -6;
+  dim3 grid(n_wtiles + n_dtiles + hr.n_slots), block(NTHREADS);
   if (nstage == 256) {
     hipLaunchKernelGGL(mt_gemm256_bwd_kernel, grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles, step,
                        ksplits, split_stride, mt_step_base_tls);
     return (int)hipGetLastError();
   }
   if (pick_nstage(nstage, n_wtiles + n_dtiles) == 4)
-    hipLaunchKernelGGL(mt_gemm_bwd_kernel<4>, grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles, step,
-                       ksplits, split_stride, mt_step_base_tls);
+    hipLaunchKernelGGL(mt_gemm_bwd_kernel<4>, grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles, n_dtiles,
+                       step, ksplits, split_stride, mt_step_base_tls, hr);
   else
-    hipLaunchKernelGGL(mt_gemm_bwd_kernel<2>, grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles, step,
-                       ksplits, split_stride, mt_step_base_tls);
+    hipLaunchKernelGGL(mt_gemm_bwd_kernel<2>, grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles, n_dtiles,
+                       step, ksplits, split_stride, mt_step_base_tls, hr);
   return (int)hipGetLastError();
+}
+
+extern "C" int mt_gemm_bwd_launch(const MtGemmGroup* wgroups, const MtTile* wtiles, int n_wtiles,
+                                  const MtGemmGroup* dgroups, const MtTile* dtiles, int n_dtiles, int step,
+                                  int ksplits, size_t split_stride, int nstage, hipStream_t stream) {
+  MtHeadReduceArgs none = {nullptr, nullptr, nullptr, 0, 0, 0};
+  return mt_gemm_bwd_head_launch(wgroups, wtiles, n_wtiles, dgroups, dtiles, n_dtiles, step, ksplits, split_stride,
+                                 nstage, none, stream);
 }
 
 // ----------------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@
 //
 // Evaluation kernel: same head forward, then adds {sum loss, sum squared error, sum |err|/(|y|+eps)}
 // for the chunk into the slot's f64 metric accumulators -- the table the scheduler all-gathers.
-#include "mt_common.h"
+#include "mt_bodies.h"
 
 #define HL_THREADS 256
 #define HL_WAVES 4
@@ -31,7 +31,6 @@ __device__ __forceinline__ void loss_and_grad(int type, float out, float y, floa
 // Training: grid (row_chunks, active slots).  Workgroup (c, a) handles rows [c*HL_ROWS, (c+1)*HL_ROWS) of
 // slot ids[a] and writes one partial record {gw[0..W), gb, loss} to scratch; mt_head_reduce_kernel then adds
 // the records of a slot in chunk order (fixed order => bitwise reproducible, no float atomics).
-#define HL_ROWS 32
 #define HL_RB 4          // rows a wave keeps in flight at once
 
 template <int NCHUNK>
@@ -136,21 +135,7 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_reduce_kernel(const MtHead
                                                                     const float* __restrict__ scratch,
                                                                     int max_chunks, int rec,
                                                                     const int* __restrict__ step_base) {
-  const int step = mt_step(step_imm, step_base);
-  const int slot = ids[blockIdx.x];
-  const MtHeadSlot s = slots[slot];
-  if (step >= s.active_steps) return;
-  const int nchunk = (s.B + HL_ROWS - 1) / HL_ROWS;
-  const float* base = scratch + (size_t)slot * max_chunks * rec;
-  for (int k = threadIdx.x; k < s.W + 2; k += HL_THREADS) {
-    const int col = (k < s.W) ? k : rec - 2 + (k - s.W);
-    float acc = 0.f;
-#pragma unroll 8
-    for (int c = 0; c < nchunk; ++c) acc += base[(size_t)c * rec + col];     // independent loads, ordered adds
-    if (k < s.W) s.gw[k] = acc;
-    else if (k == s.W) s.gb[0] = acc;
-    else s.loss_acc[0] += acc;
-  }
+  mt_head_reduce_body(slots, ids, mt_step(step_imm, step_base), scratch, max_chunks, rec, blockIdx.x);
 }
 
 // Evaluation: grid (row_chunks, active slots); each workgroup writes {sum loss, sum sq err, sum abs pct err}
@@ -237,8 +222,9 @@ extern "C" long mt_head_scratch_floats(int n_slots, int max_rows, int max_width)
 }
 
 // ids: the n_active physical slot numbers to process; scratch: mt_head_scratch_floats(n_slots_total, ...) floats.
-extern "C" int mt_head_loss_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch,
-                                   int max_width, int step, float* scratch, hipStream_t stream) {
+// with_reduce = 0 leaves the partial records in scratch for a later launch to add (mt_gemm_bwd_head_launch).
+static int head_loss_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch, int max_width,
+                            int step, float* scratch, int with_reduce, hipStream_t stream) {
   if (n_active <= 0) return 0;
   const int rec = ((max_width + 7) / 8) * 8 + 8;
   const int max_chunks = (max_batch + HL_ROWS - 1) / HL_ROWS;
@@ -253,9 +239,20 @@ extern "C" int mt_head_loss_launch(const MtHeadSlot* slots, const int32_t* ids, 
     hipLaunchKernelGGL(mt_head_loss_kernel<4>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
                        mt_step_base_tls);
   else return -2;
-  hipLaunchKernelGGL(mt_head_reduce_kernel, dim3(n_active), block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
-                     mt_step_base_tls);
+  if (with_reduce)
+    hipLaunchKernelGGL(mt_head_reduce_kernel, dim3(n_active), block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
+                       mt_step_base_tls);
   return (int)hipGetLastError();
+}
+
+extern "C" int mt_head_loss_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch,
+                                   int max_width, int step, float* scratch, hipStream_t stream) {
+  return head_loss_launch(slots, ids, n_active, max_batch, max_width, step, scratch, 1, stream);
+}
+
+extern "C" int mt_head_loss_partials_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch,
+                                            int max_width, int step, float* scratch, hipStream_t stream) {
+  return head_loss_launch(slots, ids, n_active, max_batch, max_width, step, scratch, 0, stream);
 }
 
 extern "C" int mt_head_eval_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_width,

@@ -1,0 +1,67 @@
+// Bodies of the two small per-step kernels that also run as extra workgroups inside a neighbouring launch
+// (gfx950).  A training step of a small pack is a chain of dependent launches whose cost is mostly the launch
+// boundaries; work that only has to finish "before the optimiser" (the head-gradient reduction) or "before the next
+// forward" (the next step's mini-batch gather) rides along in a launch that is there anyway, chosen by block index.
+#pragma once
+#include "mt_common.h"
+
+#define HL_ROWS 32       // rows per workgroup of the head/loss kernel = rows per partial record
+
+struct MtHeadReduceArgs {      // by-value kernel argument of the launch that carries the head reduction
+  const MtHeadSlot* slots;
+  const int32_t* ids;
+  const float* scratch;
+  int32_t n_slots, max_chunks, rec;
+};
+
+// Mini-batch gather, workgroup (bx, by) of a grid (ceil(max_batch / rows_per_block), active slots), 256 threads.
+__device__ __forceinline__ void mt_gather_body(const MtGatherSlot* __restrict__ slots, const int32_t* __restrict__ ids,
+                                               const float* __restrict__ X, const float* __restrict__ Y, uint32_t n_rows,
+                                               int F, int Fpad, int hb, int step, int bx, int by) {
+  const MtGatherSlot s = slots[ids[by]];
+  if (step >= s.active_steps) return;
+  const int cpr = Fpad >> 3;                 // 16-byte output chunks per row
+  const int rows_per_block = 256 / cpr;
+  const int tid = threadIdx.x;
+  const int r = tid / cpr, c = tid - r * cpr;
+  if (r >= rows_per_block) return;
+  const int i = bx * rows_per_block + r;
+  if (i >= s.B) return;
+  const uint32_t pos = (uint32_t)step * (uint32_t)s.B + (uint32_t)i;
+  const uint32_t src = mt_permute(pos, n_rows, s.key, hb);
+  const float* xr = X + (size_t)src * F;
+  float v[8];
+  const int f0 = c * 8;
+  if ((F & 3) == 0 && f0 + 8 <= F) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xr + f0);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(xr + f0 + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (f0 + e < F) ? xr[f0 + e] : 0.f;
+  }
+  u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(s.X0) + (size_t)i * Fpad + f0) = o;
+  if (c == 0) s.y[i] = Y[src];
+}
+
+// Adds the partial records {gw[0..W), gb, loss} that the head/loss kernel wrote for slot ids[bx], in chunk order.
+__device__ __forceinline__ void mt_head_reduce_body(const MtHeadSlot* __restrict__ slots, const int32_t* __restrict__ ids,
+                                                    int step, const float* __restrict__ scratch, int max_chunks, int rec,
+                                                    int bx) {
+  const int slot = ids[bx];
+  const MtHeadSlot s = slots[slot];
+  if (step >= s.active_steps) return;
+  const int nchunk = (s.B + HL_ROWS - 1) / HL_ROWS;
+  const float* base = scratch + (size_t)slot * max_chunks * rec;
+  for (int k = threadIdx.x; k < s.W + 2; k += 256) {
+    const int col = (k < s.W) ? k : rec - 2 + (k - s.W);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < nchunk; ++c) acc += base[(size_t)c * rec + col];     // independent loads, ordered adds
+    if (k < s.W) s.gw[k] = acc;
+    else if (k == s.W) s.gb[0] = acc;
+    else s.loss_acc[0] += acc;
+  }
+}

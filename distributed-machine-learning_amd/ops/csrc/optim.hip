@@ -10,7 +10,7 @@
 // Global-norm clipping: mt_sqnorm_kernel writes one partial sum of squares per (slot, block); each
 // optimiser block re-adds its slot's partials in index order (a fixed order, so bitwise reproducible)
 // and scales gradients by min(1, clip / (norm + 1e-6)).
-#include "mt_common.h"
+#include "mt_bodies.h"
 
 #define OPT_THREADS 256
 #define OPT_PER_BLOCK 2048   // 8 elements per thread
@@ -53,20 +53,16 @@ __device__ __forceinline__ float lr_factor(int t, int warmup, int total) {
 }
 
 template <bool G_BF16>   // G_BF16: gradients are bf16 (data-parallel trials all-reduce bf16 gradient buckets)
-__global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict__ P, const float* __restrict__ G,
-                                                               float* __restrict__ M, float* __restrict__ V,
-                                                               uint16_t* __restrict__ Pb, size_t slot_stride,
-                                                               const MtOptSlot* __restrict__ hp,
-                                                               const int32_t* __restrict__ ids,
-                                                               const float* __restrict__ partials, int max_blocks,
-                                                               int step_imm, int gsplits, size_t gsplit_stride,
-                                                               const int* __restrict__ step_base) {
-  const int step = mt_step(step_imm, step_base);
-  const int slot = ids[blockIdx.y];
+__device__ __forceinline__ void optim_body(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M,
+                                           float* __restrict__ V, uint16_t* __restrict__ Pb, size_t slot_stride,
+                                           const MtOptSlot* __restrict__ hp, const int32_t* __restrict__ ids,
+                                           const float* __restrict__ partials, int max_blocks, int step, int gsplits,
+                                           size_t gsplit_stride, int bx, int by) {
+  const int slot = ids[by];
   const MtOptSlot h = hp[slot];
   if (step >= h.active_steps) return;
-  const int base = blockIdx.x * OPT_PER_BLOCK + threadIdx.x * 8;
-  if (blockIdx.x * OPT_PER_BLOCK >= h.n_params) return;
+  const int base = bx * OPT_PER_BLOCK + threadIdx.x * 8;
+  if (bx * OPT_PER_BLOCK >= h.n_params) return;
 
   float gscale = 1.f;
   if (h.clip > 0.f && partials != nullptr) {
@@ -166,6 +162,73 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict
       Pb[off + e] = (uint16_t)f32_to_bf16_bits(p[e]);
     }
   }
+}
+
+template <bool G_BF16>
+__global__ __launch_bounds__(OPT_THREADS) void mt_optim_kernel(float* __restrict__ P, const float* __restrict__ G,
+                                                               float* __restrict__ M, float* __restrict__ V,
+                                                               uint16_t* __restrict__ Pb, size_t slot_stride,
+                                                               const MtOptSlot* __restrict__ hp,
+                                                               const int32_t* __restrict__ ids,
+                                                               const float* __restrict__ partials, int max_blocks,
+                                                               int step_imm, int gsplits, size_t gsplit_stride,
+                                                               const int* __restrict__ step_base) {
+  optim_body<G_BF16>(P, G, M, V, Pb, slot_stride, hp, ids, partials, max_blocks, mt_step(step_imm, step_base), gsplits,
+                     gsplit_stride, blockIdx.x, blockIdx.y);
+}
+
+// Optimiser of step t and mini-batch gather of step t + 1 in one launch: the gather only needs step t's forward and
+// weight-gradient kernels to be done with the input buffers (they are: stream order), so its workgroups ride behind the
+// optimiser's in the grid's x dimension.
+struct MtGatherArgs {
+  const MtGatherSlot* slots;
+  const float* X;
+  const float* Y;
+  uint32_t n_rows;
+  int32_t F, Fpad, hb, blocks;      // blocks: gather workgroups per slot (0 = no gather in this launch)
+};
+
+__global__ __launch_bounds__(OPT_THREADS) void mt_optim_gather_kernel(float* __restrict__ P, const float* __restrict__ G,
+                                                                      float* __restrict__ M, float* __restrict__ V,
+                                                                      uint16_t* __restrict__ Pb, size_t slot_stride,
+                                                                      const MtOptSlot* __restrict__ hp,
+                                                                      const int32_t* __restrict__ ids,
+                                                                      const float* __restrict__ partials, int max_blocks,
+                                                                      int step_imm, int gsplits, size_t gsplit_stride,
+                                                                      const int* __restrict__ step_base, int nb_opt,
+                                                                      MtGatherArgs ga) {
+  const int step = mt_step(step_imm, step_base);
+  if ((int)blockIdx.x < nb_opt)
+    optim_body<false>(P, G, M, V, Pb, slot_stride, hp, ids, partials, max_blocks, step, gsplits, gsplit_stride, blockIdx.x,
+                      blockIdx.y);
+  else
+    mt_gather_body(ga.slots, ids, ga.X, ga.Y, ga.n_rows, ga.F, ga.Fpad, ga.hb, step + 1, (int)blockIdx.x - nb_opt,
+                   blockIdx.y);
+}
+
+extern "C" int mt_optim_gather_launch(float* P, const float* G, float* M, float* V, void* Pb, size_t slot_stride,
+                                      const MtOptSlot* hp, const int32_t* ids, int n_active, int max_params,
+                                      float* partials, int max_blocks, int use_clip, int step, int gsplits,
+                                      size_t gsplit_stride, const MtGatherSlot* gslots, const float* X, const float* Y,
+                                      uint32_t n_rows, int F, int Fpad, int hb, int max_batch, hipStream_t stream) {
+  if (gsplits < 1) return -6;
+  if (n_active <= 0 || max_params <= 0) return 0;
+  if (slot_stride % 8 != 0) return -2;
+  if (Fpad % 8 != 0 || Fpad / 8 > 256 || Fpad < F) return -2;
+  const int nb = (max_params + OPT_PER_BLOCK - 1) / OPT_PER_BLOCK;
+  if (nb > max_blocks) return -4;
+  const int rows_per_block = 256 / (Fpad / 8);
+  MtGatherArgs ga = {gslots, X, Y, n_rows, F, Fpad, hb, (max_batch + rows_per_block - 1) / rows_per_block};
+  dim3 block(OPT_THREADS);
+  if (use_clip) {
+    if (partials == nullptr) return -3;
+    hipLaunchKernelGGL(mt_sqnorm_kernel, dim3(nb, n_active), block, 0, stream, G, slot_stride, hp, ids, partials, max_blocks,
+                       step, gsplits, gsplit_stride, mt_step_base_tls);
+  }
+  hipLaunchKernelGGL(mt_optim_gather_kernel, dim3(nb + ga.blocks, n_active), block, 0, stream, P, G, M, V,
+                     reinterpret_cast<uint16_t*>(Pb), slot_stride, hp, ids, use_clip ? partials : nullptr, max_blocks, step,
+                     gsplits, gsplit_stride, mt_step_base_tls, nb, ga);
+  return (int)hipGetLastError();
 }
 
 extern "C" int mt_optim_launch(float* P, const float* G, float* M, float* V, void* Pb, size_t slot_stride,

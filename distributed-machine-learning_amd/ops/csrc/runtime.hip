@@ -8,7 +8,7 @@
 //   gather -> L x forward GEMM(+bias+ReLU) -> head+loss+dH (+ its reduce) -> for l = L-1..0 { wgrad(+dbias) and
 //   dgrad(+ReLU mask) of layer l in ONE launch } -> [grad sq-norm partials] -> fused per-trial optimiser
 //   (+bf16 shadow refresh), i.e. 2L + 4 (+1) launches regardless of how many trials share the GPU.
-#include "mt_common.h"
+#include "mt_bodies.h"
 
 #define MT_MAX_LAYERS 8
 
@@ -27,6 +27,15 @@ int mt_head_eval_launch(const MtHeadSlot* slots, const int32_t* ids, int n_activ
 int mt_optim_launch(float* P, const float* G, float* M, float* V, void* Pb, size_t slot_stride, const MtOptSlot* hp,
                     const int32_t* ids, int n_active, int max_params, float* partials, int max_blocks, int use_clip,
                     int step, int gsplits, size_t gsplit_stride, hipStream_t stream);
+int mt_gemm_bwd_head_launch(const MtGemmGroup* wgroups, const MtTile* wtiles, int n_wtiles, const MtGemmGroup* dgroups,
+                            const MtTile* dtiles, int n_dtiles, int step, int ksplits, size_t split_stride, int nstage,
+                            MtHeadReduceArgs hr, hipStream_t stream);
+int mt_head_loss_partials_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch, int max_width,
+                                 int step, float* scratch, hipStream_t stream);
+int mt_optim_gather_launch(float* P, const float* G, float* M, float* V, void* Pb, size_t slot_stride, const MtOptSlot* hp,
+                           const int32_t* ids, int n_active, int max_params, float* partials, int max_blocks, int use_clip,
+                           int step, int gsplits, size_t gsplit_stride, const MtGatherSlot* gslots, const float* X,
+                           const float* Y, uint32_t n_rows, int F, int Fpad, int hb, int max_batch, hipStream_t stream);
 }
 
 struct MtMlpPlan {
@@ -74,30 +83,44 @@ thread_local const int* mt_step_base_tls = nullptr;
     if (_e != 0) return _e;  \
   } while (0)
 
-static int mlp_enqueue_steps(const MtMlpPlan* p, int step0, int nsteps, hipStream_t stream) {
+static int mlp_enqueue_steps(const MtMlpPlan* p, int step0, int nsteps, hipStream_t stream, bool first_gather) {
   if (p->n_hidden < 1 || p->n_hidden > MT_MAX_LAYERS) return -10;
   const int L = p->n_hidden;
-  for (int step = step0; step < step0 + nsteps; ++step) {
+  // The mini-batch of a step is gathered by the optimiser launch of the step before it; whoever starts a run of
+  // steps (first_gather) gathers the first one.  The head kernel leaves partial records that the last layer's backward
+  // launch adds up (a 256-tile launch cannot carry them, so then the head reduces on its own).
+  const bool head_rides = !p->bwd_big[L - 1];
+  const MtHeadReduceArgs hr = {p->head, p->active_ids, p->head_scratch, p->n_active,
+                               (p->max_batch + HL_ROWS - 1) / HL_ROWS, ((p->max_width + 7) / 8) * 8 + 8};
+  const MtHeadReduceArgs no_hr = {nullptr, nullptr, nullptr, 0, 0, 0};
+  if (first_gather)
     MT_TRY(mt_gather_launch(p->gather, p->active_ids, p->n_active, p->max_batch, p->X, p->Y, p->n_rows, p->F,
-                            p->Fpad, p->hb, step, stream));
+                            p->Fpad, p->hb, step0, stream));
+  for (int step = step0; step < step0 + nsteps; ++step) {
     for (int l = 0; l < L; ++l)
       MT_TRY(mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], step, MT_GEMM_FLAG_RELU, 0, 0,
                             1, 0, p->fwd_big[l] ? 256 : 0, stream));
-    MT_TRY(mt_head_loss_launch(p->head, p->active_ids, p->n_active, p->max_batch, p->max_width, step,
-                               p->head_scratch, stream));
+    if (head_rides)
+      MT_TRY(mt_head_loss_partials_launch(p->head, p->active_ids, p->n_active, p->max_batch, p->max_width, step,
+                                          p->head_scratch, stream));
+    else
+      MT_TRY(mt_head_loss_launch(p->head, p->active_ids, p->n_active, p->max_batch, p->max_width, step,
+                                 p->head_scratch, stream));
     for (int l = L - 1; l >= 0; --l)     // layer 0 has no input gradient: its dgrad tile list is empty
-      MT_TRY(mt_gemm_bwd_launch(p->wgrad_groups[l], p->wgrad_tiles[l], p->wgrad_ntiles[l], p->dgrad_groups[l],
-                                p->dgrad_tiles[l], l > 0 ? p->dgrad_ntiles[l] : 0, step, p->ksplits,
-                                p->gsplit_stride, p->bwd_big[l] ? 256 : 0, stream));
-    MT_TRY(mt_optim_launch(p->P, p->G, p->M, p->V, p->Pb, p->slot_stride, p->opt, p->active_ids, p->n_active,
-                           p->max_params, p->partials, p->max_blocks, p->use_clip, step, p->ksplits,
-                           p->gsplit_stride, stream));
+      MT_TRY(mt_gemm_bwd_head_launch(p->wgrad_groups[l], p->wgrad_tiles[l], p->wgrad_ntiles[l], p->dgrad_groups[l],
+                                     p->dgrad_tiles[l], l > 0 ? p->dgrad_ntiles[l] : 0, step, p->ksplits,
+                                     p->gsplit_stride, p->bwd_big[l] ? 256 : 0,
+                                     (l == L - 1 && head_rides) ? hr : no_hr, stream));
+    MT_TRY(mt_optim_gather_launch(p->P, p->G, p->M, p->V, p->Pb, p->slot_stride, p->opt, p->active_ids, p->n_active,
+                                  p->max_params, p->partials, p->max_blocks, p->use_clip, step, p->ksplits,
+                                  p->gsplit_stride, p->gather, p->X, p->Y, p->n_rows, p->F, p->Fpad, p->hb,
+                                  p->max_batch, stream));
   }
   return 0;
 }
 
 extern "C" int mt_mlp_train_steps(const MtMlpPlan* p, int step0, int nsteps, hipStream_t stream) {
-  return mlp_enqueue_steps(p, step0, nsteps, stream);
+  return mlp_enqueue_steps(p, step0, nsteps, stream, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -123,7 +146,7 @@ extern "C" void* mt_mlp_graph_create(const MtMlpPlan* p, int nsteps, int* counte
   if (nsteps < 1 || counter == nullptr || stream == nullptr) { *err = -11; return nullptr; }
   if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { *err = -12; return nullptr; }
   mt_step_base_tls = counter;
-  int rc = mlp_enqueue_steps(p, 0, nsteps, stream);
+  int rc = mlp_enqueue_steps(p, 0, nsteps, stream, false);     // the caller gathers step 0 of the epoch (mt_mlp_gather_at)
   mt_step_base_tls = nullptr;
   if (rc == 0) {
     hipLaunchKernelGGL(mt_counter_add_kernel, dim3(1), dim3(64), 0, stream, counter, nsteps);
@@ -162,11 +185,20 @@ extern "C" void mt_mlp_graph_destroy(void* handle) {
   delete g;
 }
 
+// Gather the mini-batch of step *counter (the first step of an epoch that is then driven by graph replays).
+extern "C" int mt_mlp_gather_at(const MtMlpPlan* p, int* counter, hipStream_t stream) {
+  mt_step_base_tls = counter;
+  const int rc = mt_gather_launch(p->gather, p->active_ids, p->n_active, p->max_batch, p->X, p->Y, p->n_rows, p->F, p->Fpad,
+                                  p->hb, 0, stream);
+  mt_step_base_tls = nullptr;
+  return rc;
+}
+
 // Direct launches of steps [*counter, *counter + nsteps) (the remainder of an epoch that is not a whole block).
 extern "C" int mt_mlp_train_steps_at(const MtMlpPlan* p, int* counter, int nsteps, hipStream_t stream) {
   if (nsteps <= 0) return 0;
   mt_step_base_tls = counter;
-  const int rc = mlp_enqueue_steps(p, 0, nsteps, stream);
+  const int rc = mlp_enqueue_steps(p, 0, nsteps, stream, false);
   mt_step_base_tls = nullptr;
   if (rc != 0) return rc;
   hipLaunchKernelGGL(mt_counter_add_kernel, dim3(1), dim3(64), 0, stream, counter, nsteps);

@@ -193,6 +193,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_mlp_graph_destroy.restype = None
     lib.mt_mlp_train_steps_at.argtypes = [C.POINTER(MlpPlan), c_void_p, C.c_int, c_void_p]
     lib.mt_mlp_train_steps_at.restype = C.c_int
+    lib.mt_mlp_gather_at.argtypes = [C.POINTER(MlpPlan), c_void_p, c_void_p]
+    lib.mt_mlp_gather_at.restype = C.c_int
     for fn in (lib.mt_gemm_launch, lib.mt_gather_launch, lib.mt_head_loss_launch, lib.mt_head_eval_launch,
                lib.mt_optim_launch, lib.mt_mlp_train_steps, lib.mt_mlp_eval):
         fn.restype = C.c_int

@@ -508,6 +508,9 @@ class HipPackEngine(PackEngine):
             pairs = list(zip(self._chains, self._streams))
             for _, st in pairs:
                 st.wait_stream(main)           # tables, counters and zeroed loss accumulators were issued on `main`
+            for ch, st in pairs:           # step 0's mini-batch; every later one is gathered by the step before it
+                L.check(self.lib.mt_mlp_gather_at(C.byref(ch.plan), ch.counter.data_ptr(), st.cuda_stream),
+                        "mt_mlp_gather_at")
             blocks = [ch.steps // GRAPH_STEPS for ch in self._chains]
             for b in range(max(blocks)):       # interleaved so that no chain gets a head start
                 for (ch, st), nb in zip(pairs, blocks):
