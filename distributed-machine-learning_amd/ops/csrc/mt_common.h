@@ -100,7 +100,9 @@ struct MtOptSlot {
   int32_t n_params;      // live elements of this slot's slab
   int32_t active_steps;
   int32_t step_base;     // optimiser steps taken before this epoch
-  int32_t pad[3];
+  int32_t first_end;     // elements [0, first_end) are layer 0's weights and bias (a multiple of 8) ...
+  int32_t first_splits;  // ... whose gradient is spread over this many slabs (0: same as the rest of the slot)
+  int32_t pad;
 };
 
 // Feistel permutation shared with packed/permutation.py (bit-identical).

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_sqnorm_kernel(const float* __r
   const MtOptSlot h = hp[slot];
   float acc = 0.f;
   const int base = blockIdx.x * OPT_PER_BLOCK + threadIdx.x * 8;
+  if (h.first_splits > 0 && base < h.first_end) gsplits = h.first_splits;
   if (step < h.active_steps && h.clip > 0.f && base < h.n_params) {
     const float* g = G + (size_t)slot * slot_stride + base;
     const int n = (h.n_params - base) < 8 ? (h.n_params - base) : 8;
@@ -73,6 +74,8 @@ __device__ __forceinline__ void optim_body(float* __restrict__ P, const float* _
     gscale = c < 1.f ? c : 1.f;
   }
   if (base >= h.n_params) return;
+  // layer 0 (tiny contraction tiles, few of them) may split its weight gradient further than the other layers
+  if (h.first_splits > 0 && base < h.first_end) gsplits = h.first_splits;
 
   const int t = h.step_base + step;                 // optimiser steps already taken
   const float lr = h.lr * lr_factor(t, h.warmup, h.total);

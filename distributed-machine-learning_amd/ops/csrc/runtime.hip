@@ -71,6 +71,8 @@ struct MtMlpPlan {
   int32_t max_blocks;
   int32_t ksplits;        // wgrad contraction splits; G holds that many slabs of gsplit_stride floats
   size_t gsplit_stride;
+  int32_t ksplits0;       // contraction splits of layer 0's wgrad (its tile list is built with this count)
+  int32_t pad0;
   int32_t fwd_big[MT_MAX_LAYERS];   // 1: this layer's forward tile list holds 256x256 tiles
   int32_t bwd_big[MT_MAX_LAYERS];   // 1: this layer's wgrad and dgrad tile lists hold 256x256 tiles
 };
@@ -108,8 +110,8 @@ static int mlp_enqueue_steps(const MtMlpPlan* p, int step0, int nsteps, hipStrea
                                  p->head_scratch, stream));
     for (int l = L - 1; l >= 0; --l)     // layer 0 has no input gradient: its dgrad tile list is empty
       MT_TRY(mt_gemm_bwd_head_launch(p->wgrad_groups[l], p->wgrad_tiles[l], p->wgrad_ntiles[l], p->dgrad_groups[l],
-                                     p->dgrad_tiles[l], l > 0 ? p->dgrad_ntiles[l] : 0, step, p->ksplits,
-                                     p->gsplit_stride, p->bwd_big[l] ? 256 : 0,
+                                     p->dgrad_tiles[l], l > 0 ? p->dgrad_ntiles[l] : 0, step,
+                                     l == 0 ? p->ksplits0 : p->ksplits, p->gsplit_stride, p->bwd_big[l] ? 256 : 0,
                                      (l == L - 1 && head_rides) ? hr : no_hr, stream));
     MT_TRY(mt_optim_gather_launch(p->P, p->G, p->M, p->V, p->Pb, p->slot_stride, p->opt, p->active_ids, p->n_active,
                                   p->max_params, p->partials, p->max_blocks, p->use_clip, step, p->ksplits,

@@ -46,7 +46,8 @@ class OptSlot(C.Structure):
     _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("wd", c_float),
                 ("momentum", c_float), ("clip", c_float),
                 ("opt_type", c_int32), ("warmup", c_int32), ("total", c_int32), ("n_params", c_int32),
-                ("active_steps", c_int32), ("step_base", c_int32), ("pad", c_int32 * 3)]
+                ("active_steps", c_int32), ("step_base", c_int32), ("first_end", c_int32),
+                ("first_splits", c_int32), ("pad", c_int32)]
 
 
 class MlpPlan(C.Structure):
@@ -62,7 +63,7 @@ class MlpPlan(C.Structure):
                 ("head", c_void_p), ("P", c_void_p), ("G", c_void_p), ("M", c_void_p), ("V", c_void_p),
                 ("Pb", c_void_p), ("slot_stride", c_size_t), ("opt", c_void_p), ("partials", c_void_p),
                 ("active_ids", c_void_p), ("head_scratch", c_void_p), ("max_blocks", c_int32), ("ksplits", c_int32),
-                ("gsplit_stride", c_size_t),
+                ("gsplit_stride", c_size_t), ("ksplits0", c_int32), ("pad0", c_int32),
                 ("fwd_big", c_int32 * MT_MAX_LAYERS), ("bwd_big", c_int32 * MT_MAX_LAYERS)]
 
 
@@ -95,7 +96,7 @@ HEAD_DTYPE = np.dtype([("H", "<u8"), ("dH", "<u8"), ("w", "<u8"), ("b", "<u8"), 
 OPT_DTYPE = np.dtype([("lr", "<f4"), ("beta1", "<f4"), ("beta2", "<f4"), ("eps", "<f4"), ("wd", "<f4"),
                       ("momentum", "<f4"), ("clip", "<f4"), ("opt_type", "<i4"), ("warmup", "<i4"),
                       ("total", "<i4"), ("n_params", "<i4"), ("active_steps", "<i4"), ("step_base", "<i4"),
-                      ("pad", "<i4", (3,))], align=True)
+                      ("first_end", "<i4"), ("first_splits", "<i4"), ("pad", "<i4")], align=True)
 
 _lib: Optional[C.CDLL] = None
 

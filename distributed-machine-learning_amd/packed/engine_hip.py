@@ -307,26 +307,30 @@ class HipPackEngine(PackEngine):
     def _act_ptr(self, buf: torch.Tensor, slot: int, elem_bytes: int = 2) -> int:
         return buf.data_ptr() + slot * self.act_stride * elem_bytes
 
-    def _choose_ksplits(self, ids: Optional[List[int]] = None) -> int:
-        """Split the wgrad contraction when the pack is too small to give every CU a weight-gradient tile."""
+    def _choose_ksplits(self, ids: Optional[List[int]] = None) -> Tuple[int, int]:
+        """(splits for layers >= 1, splits for layer 0) of the wgrad contraction: a launch with too few weight-gradient
+        tiles to give every CU one splits the batch dimension instead."""
         per_layer: Dict[int, int] = {}
         for slot in (ids if ids is not None else sorted(self.slots)):
-            s = self.slots[slot]
-            lay = s.layout
+            lay = self.slots[slot].layout
             for l, h in enumerate(lay.hidden):
                 per_layer[l] = per_layer.get(l, 0) + ((h + TILE - 1) // TILE) * ((lay.in_dims[l] + TILE - 1) // TILE)
-        busiest = max(per_layer.values())
-        # measured on 512-wide layers: 4 splits win 1.4x at 128 tiles, nothing at 256, and every split
-        # costs the optimiser one more slab to read
-        if busiest <= 128:
-            return MAX_KSPLITS
-        return 2 if busiest <= 192 else 1
+
+        def rule(tiles: int) -> int:
+            # measured on 512-wide layers: 4 splits win 1.4x at 128 tiles, nothing at 256, and every split
+            # costs the optimiser one more slab to read
+            if tiles <= 128:
+                return MAX_KSPLITS
+            return 2 if tiles <= 192 else 1
+
+        rest = rule(max([v for l, v in per_layer.items() if l > 0] or [per_layer[0]]))
+        return rest, max(rest, rule(per_layer[0]))
 
     def _build_gemm_tables(self, eval_mode: bool, ids: List[int], tag: str) -> Dict[str, Any]:
         members = [(slot, self.slots[slot]) for slot in ids]
         Lmax = max(len(s.spec.hidden_sizes) for _, s in members)
-        ksplits = 1 if eval_mode else self._choose_ksplits(ids)
-        self._ksplits = ksplits
+        ksplits, ksplits0 = (1, 1) if eval_mode else self._choose_ksplits(ids)
+        self._ksplits, self._ksplits0 = ksplits, ksplits0
         T = self.capacity
         out: Dict[str, Any] = {"n_hidden": Lmax}
         p_base, pb_base, g_base = self.P.data_ptr(), self.Pb.data_ptr(), self.G.data_ptr()
@@ -371,14 +375,14 @@ class HipPackEngine(PackEngine):
 
             # 256-tiles halve the bytes staged per flop; they pay once a launch still has enough of them to fill the chip
             big_f = BIG_MIN_TILES > 0 and count(fl, BIG_TILE) >= BIG_MIN_TILES
-            big_b = (BIG_MIN_TILES > 0 and (not eval_mode) and ksplits == 1
+            big_b = (BIG_MIN_TILES > 0 and (not eval_mode) and ksplits0 == 1
                      and count(dl, BIG_TILE) + count(wl, BIG_TILE) >= BIG_MIN_TILES)
             out[f"big_fwd{l}"], out[f"big_bwd{l}"] = int(big_f), int(big_b)
             ft = balanced_tiles(tiled(fl, BIG_TILE if big_f else TILE))
             out[f"fwd{l}"] = (self._upload(f"{tag}fwd_g{l}", fwd), self._upload(f"{tag}fwd_t{l}", ft), len(ft))
             if not eval_mode:
                 edge = BIG_TILE if big_b else TILE
-                dt, wt = balanced_tiles(tiled(dl, edge)), balanced_tiles(tiled(wl, edge), ksplits)
+                dt, wt = balanced_tiles(tiled(dl, edge)), balanced_tiles(tiled(wl, edge), ksplits0 if l == 0 else ksplits)
                 out[f"dgrad{l}"] = (self._upload(f"{tag}dg_g{l}", dg), self._upload(f"{tag}dg_t{l}", dt), len(dt))
                 out[f"wgrad{l}"] = (self._upload(f"{tag}wg_g{l}", wg), self._upload(f"{tag}wg_t{l}", wt), len(wt))
         return out
@@ -397,6 +401,7 @@ class HipPackEngine(PackEngine):
         plan.head_scratch = (scratch if scratch is not None else self.head_scratch).data_ptr()
         plan.max_blocks = self.max_blocks
         plan.ksplits, plan.gsplit_stride = self._ksplits, self.capacity * self.stride
+        plan.ksplits0 = self._ksplits0
         plan.max_batch = max(s.spec.batch_size for _, s in members)
         plan.max_width = max(max(s.spec.hidden_sizes) for _, s in members)
         plan.max_params = max(s.layout.total for _, s in members)
@@ -445,7 +450,9 @@ class HipPackEngine(PackEngine):
                          round_keys(self.seed, s.trial_index, s.epoch), b, steps)
             opt[slot] = (sp.learning_rate, sp.beta1, sp.beta2, sp.eps, sp.weight_decay, sp.momentum,
                          sp.gradient_clipping, OPT_CODES[sp.optimizer], sp.warmup_steps, sp.total_steps,
-                         s.layout.total, steps, s.step, (0, 0, 0))
+                         s.layout.total, steps, s.step,
+                         s.layout.b_off[0] + ceil8(s.layout.hidden[0]),           # end of layer 0's weights + bias
+                         plan.ksplits0 if plan.ksplits0 != plan.ksplits else 0, 0)
         plan.gather = self._upload(tag + "gather", gat)
         plan.opt = self._upload(tag + "opt", opt)
         return max_steps

@@ -169,7 +169,7 @@ class DPTrainer:
                 hp = np.zeros(1, dtype=self.L.OPT_DTYPE)
                 hp[0] = (sp.learning_rate, sp.beta1, sp.beta2, sp.eps, sp.weight_decay, sp.momentum, 0.0,
                          OPT_CODES[sp.optimizer], sp.warmup_steps, sp.total_steps, self.model.numel, 1 << 30, 0,
-                         (0, 0, 0))
+                         0, 0, 0)
                 self._hp_t = torch.from_numpy(hp.view(np.uint8).reshape(-1).copy()).to(self.device)
             stream = torch.cuda.current_stream(self.device).cuda_stream
             self.L.check(self.lib.mt_optim_launch_bf16g(

@@ -111,3 +111,31 @@ def test_concurrent_chains_match_single_stream():
         a, b = out[1][0][-1][slot], out[4][0][-1][slot]
         assert a["validation_mse"] == pytest.approx(b["validation_mse"], rel=2e-3), slot
         assert a["train_loss"] == pytest.approx(b["train_loss"], rel=2e-3), slot
+
+
+def test_layer0_splits_its_weight_gradient_further_than_wide_layers():
+    """12 trials of [512, 512]: the 512x512 layer has enough tiles for one pass, layer 0 (20 features) does not, so the
+    two use different split counts and the optimiser must add the right number of slabs per region."""
+    from mitune.packed import PackedTrainable, TorchPackEngine
+    from mitune.packed.engine_hip import HipPackEngine
+    train, val = _data(n=4000, seed=6)
+    tr = PackedTrainable(train=train, val=val, max_epochs=1, val_chunk=512,
+                         model_kwargs={"max_width": 512, "max_layers": 2, "max_batch": 512})
+    cfgs = [(i, {"hidden_sizes": [512, 512], "batch_size": 256, "learning_rate": 1e-3 * (1 + i % 3), "optimizer": "adamw",
+                 "gradient_clipping": 1.0 if i % 2 else 0.0}) for i in range(12)]
+    eng = HipPackEngine(tr, device="cuda", capacity=12, seed=1)
+    for slot, (idx, cfg) in enumerate(cfgs):
+        eng.load(slot, idx, cfg)
+    eng.train_epoch()
+    got = eng.evaluate()
+    plan = eng._chains[0].plan
+    assert (plan.ksplits, plan.ksplits0) == (2, 4)
+    ref = TorchPackEngine(tr, device="cuda", capacity=12, seed=1)
+    for slot, (idx, cfg) in enumerate(cfgs):
+        ref.load(slot, idx, cfg)
+    ref.train_epoch()
+    want = ref.evaluate()
+    var_y = float(val[1].var())
+    for slot in range(12):
+        assert got[slot]["validation_mse"] == pytest.approx(want[slot]["validation_mse"], rel=0.08, abs=0.02 * var_y), slot
+        assert got[slot]["train_loss"] == pytest.approx(want[slot]["train_loss"], rel=0.08, abs=0.02 * var_y), slot

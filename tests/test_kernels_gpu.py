@@ -248,7 +248,7 @@ def test_fused_optimizer_matches_torch(lib, name, code, clip, gsplits):
         p0 = torch.randn(n, device="cuda", generator=g)
         P[s * stride:s * stride + n] = p0
         lr, wd, mom = 1e-2 * (s + 1), 1e-2, 0.9
-        hp[s] = (lr, 0.9, 0.999, 1e-8, wd, mom, clip, code, 0, 0, n, 100, 0, (0, 0, 0))
+        hp[s] = (lr, 0.9, 0.999, 1e-8, wd, mom, clip, code, 0, 0, n, 100, 0, 0, 0, 0)
         pr = p0.clone().requires_grad_(True)
         refs.append((pr, build_optimizer(name, [pr], lr, wd, mom)))
     nb = (max(sizes) + 2047) // 2048
