@@ -35,7 +35,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch  # noqa: E402
 
 # trials/hour of the same search executed as sequential single-trial PyTorch-eager training on the
-# reference's CPU path (configuration 2).
+# reference's CPU path: measured with bench/baseline_cpu_eager.py (12 configurations x one epoch on 40k rows,
+# 8 threads, extrapolated to the search's 640 trial-epochs on the 1M x 64 table).
 BASELINE_TRIALS_PER_HOUR = 303.6
 
 
