@@ -191,9 +191,18 @@ class GraphedTrainer:
             f.G.zero_(); self.pos.zero_(); self.running.zero_()
         cur.synchronize()                      # stream-level only: a device-wide wait would disturb other threads
         g = torch.cuda.CUDAGraph()
+        # Raw capture_begin / capture_end on the warm-up stream: the torch.cuda.graph context would first synchronise the
+        # device, run the Python garbage collector and empty the allocator cache -- tens of milliseconds per trial that a
+        # search over hundreds of sub-second trials pays again and again (and every trial after it re-mallocs).
         with _CAPTURE_LOCK:
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self._cursor_step()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                g.capture_begin(capture_error_mode="thread_local")
+                try:
+                    self._cursor_step()
+                finally:
+                    g.capture_end()
+            cur.wait_stream(side)
         self.graph = g
 
     # ------------------------------------------------------------------ epochs
