@@ -1,5 +1,6 @@
 """GPU tests: small fused Transformer-path kernels, the device-state flat optimiser and graph-replayed training."""
 import math
+import os
 
 import pytest
 import torch
@@ -328,3 +329,31 @@ def test_split_k_linear_matches_reference(M, in_f, out_f):
     assert torch.allclose(got[2], ref_dw, rtol=1e-3, atol=1e-3 * ref_dw.abs().max().item())
     assert torch.allclose(got[3], ref_db, rtol=1e-3, atol=1e-3 * ref_db.abs().max().item())
     assert torch.allclose(got[1], ref_dx, rtol=2e-2, atol=2e-2 * ref_dx.abs().max().item())
+
+
+# ------------------------------------------------------------------ one process per trial on the GPU
+def _gpu_trial(config, data=None):
+    import torch as _t
+    from mitune import tune as _tune
+    X, y = data
+    dev = _t.device("cuda:0")             # the trial's own GPU is always device 0 of its process
+    w = _t.zeros(X.shape[1], device=dev, requires_grad=True)
+    opt = _t.optim.SGD([w], lr=config["lr"])
+    Xd, yd = X.to(dev), y.to(dev)
+    for _ in range(3):
+        loss = ((Xd @ w - yd) ** 2).mean()
+        opt.zero_grad(); loss.backward(); opt.step()
+        _tune.report(loss=float(loss), visible=os.environ.get("HIP_VISIBLE_DEVICES", ""))
+
+
+def test_process_executor_pins_a_gpu_per_trial(tmp_path):
+    from mitune import tune
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(256, 4, generator=g)
+    y = X @ torch.tensor([1.0, -2.0, 0.5, 0.0])
+    an = tune.run(tune.with_parameters(_gpu_trial, data=(X, y)), config={"lr": tune.grid_search([0.05, 0.1])},
+                  resources_per_trial={"cpu": 1, "gpu": 1}, executor="process", local_dir=str(tmp_path), verbose=0,
+                  metric="loss", mode="min")
+    assert [t.status for t in an.trials] == ["TERMINATED", "TERMINATED"]
+    assert all(t.training_iteration == 3 and t.last_result["visible"] == "0" for t in an.trials)
+    assert an.best_result["loss"] < an.trials[0].results[0]["loss"]
