@@ -51,13 +51,20 @@ def is_current() -> bool:
 def build(force: bool = False, verbose: bool = True, extra_flags: List[str] | None = None) -> str:
     if not force and is_current():
         return LIB
+    tmp = f"{LIB}.tmp.{os.getpid()}"          # built aside and renamed: a concurrent reader never maps a half-written file
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-o", LIB] + (extra_flags or []) + sources()
+           "-Wno-unused-result", "-o", tmp] + (extra_flags or []) + sources()
     if verbose:
-        print("[mitune] " + " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
-    with open(STAMP, "w") as f:
+        print("[mitune] " + " ".join(cmd).replace(tmp, LIB), flush=True)
+    try:
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    with open(STAMP + ".tmp", "w") as f:
         f.write(_digest())
+    os.replace(STAMP + ".tmp", STAMP)
     return LIB
 
 

@@ -115,6 +115,12 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if _lib is not None:
         return _lib
     path = lib_path()
+    if build_if_missing and not _build.is_current() and os.environ.get("LOCAL_RANK", "0") != "0":
+        # one process per GPU: local rank 0 rebuilds a stale library, the others wait for it instead of racing hipcc
+        import time
+        deadline = time.time() + 600
+        while not _build.is_current() and time.time() < deadline:
+            time.sleep(0.5)
     if build_if_missing and not _build.is_current():
         try:
             _build.build(verbose=False)
