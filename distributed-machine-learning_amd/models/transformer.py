@@ -35,7 +35,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops.attention import short_attention
+from ..ops.attention import self_attention
 from ..ops.elementwise import depthwise_conv1d, dropout, pe_add_dropout
 from ..ops.head_mlp import head_mlp
 from ..ops.layernorm import residual_layer_norm
@@ -84,16 +84,6 @@ class DepthwiseSeparableConv(nn.Module):
         return F.linear(y, self.project.weight.squeeze(-1), self.project.bias)
 
 
-def _split_heads(t: torch.Tensor, h: int) -> torch.Tensor:       # [B, S, h*dh] -> [B, h, S, dh]
-    b, s, d = t.shape
-    return t.view(b, s, h, d // h).transpose(1, 2)
-
-
-def _merge_heads(t: torch.Tensor) -> torch.Tensor:               # [B, h, S, dh] -> [B, S, h*dh]
-    b, h, s, dh = t.shape
-    return t.transpose(1, 2).reshape(b, s, h * dh)
-
-
 class SelfAttention(nn.Module):
     """Multi-head softmax self-attention; ``key_dim_scaling`` shrinks the query/key width per head."""
 
@@ -117,11 +107,10 @@ class SelfAttention(nn.Module):
     def forward(self, query: torch.Tensor, key: Optional[torch.Tensor] = None, value: Optional[torch.Tensor] = None
                 ) -> Tuple[torch.Tensor, None]:
         x = query                                  # self-attention: key/value arguments are accepted, not used
-        q, k = linear(x, self.qk_proj.weight, self.qk_proj.bias).chunk(2, dim=-1)
+        qk = linear(x, self.qk_proj.weight, self.qk_proj.bias)           # [B, S, 2*h*dk]: queries then keys, head-major
         v = self._mix(linear(x, self.v_proj.weight, self.v_proj.bias))
-        o = short_attention(_split_heads(q, self.h), _split_heads(k, self.h), _split_heads(v, self.h),
-                            kind=self.kind, dropout_p=self.p if self.training else 0.0)
-        return linear(_merge_heads(o), self.out_proj.weight, self.out_proj.bias), None
+        o = self_attention(qk, v, self.h, kind=self.kind, dropout_p=self.p if self.training else 0.0)
+        return linear(o, self.out_proj.weight, self.out_proj.bias), None
 
 
 class LinearAttention(SelfAttention):

@@ -63,3 +63,26 @@ def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kind: str
         if available():
             return FusedShortAttention.apply(q, k, v, kind, keep, dropout_p)
     return attention_reference(q, k, v, kind, keep, dropout_p)
+
+
+def self_attention(qk: torch.Tensor, v: torch.Tensor, num_heads: int, kind: str = "softmax",
+                   dropout_p: float = 0.0) -> torch.Tensor:
+    """Multi-head self-attention on projection outputs: ``qk`` [B, S, 2*h*dk] (all queries, then all keys, head-major),
+    ``v`` [B, S, h*dv]; returns [B, S, h*dv].  On a GPU the fused kernels read these tensors in place (no head
+    split/merge copies, no casts); elsewhere the heads are split and ``attention_reference`` runs."""
+    B, S, w2 = qk.shape
+    h = num_heads
+    dk, dv = w2 // (2 * h), v.shape[-1] // h
+    keep = None
+    if dropout_p > 0.0:
+        from .elementwise import keep_mask
+        keep = keep_mask((B, h, S, S), dropout_p, qk.device)
+    if (qk.is_cuda and qk.dtype in (torch.float32, torch.bfloat16) and S <= MAX_SEQ and dk <= MAX_HEAD_DIM
+            and dv <= MAX_HEAD_DIM and dk % 8 == 0 and dv % 8 == 0):
+        from .attention_hip import FusedSelfAttention, available
+        if available():
+            return FusedSelfAttention.apply(qk, v, h, kind, keep, dropout_p)
+    q, k = qk.chunk(2, dim=-1)
+    split = lambda t, d: t.reshape(B, S, h, d).transpose(1, 2)          # noqa: E731
+    o = attention_reference(split(q, dk), split(k, dk), split(v, dv), kind, keep, dropout_p)
+    return o.transpose(1, 2).reshape(B, S, h * dv)

@@ -57,3 +57,51 @@ class FusedShortAttention(torch.autograd.Function):
                                       _KIND[kind], torch.cuda.current_stream(qb.device).cuda_stream),
                 "mt_attn_bwd_launch")
         return dq.to(qd), dk_.to(kd), dv_.to(vd), None, None, None
+
+
+class FusedSelfAttention(torch.autograd.Function):
+    """Attention straight on projection outputs: ``qk`` [B, S, 2*h*dk] (queries then keys, head-major), ``v`` [B, S, h*dv]
+    -> [B, S, h*dv].  f32 or bf16; no head split / merge copies, no dtype casts: the kernels read the strided operands
+    in place and write the gradient of ``qk`` as one tensor."""
+
+    @staticmethod
+    def forward(ctx, qk, v, h: int, kind: str, keep: Optional[torch.Tensor], dropout_p: float):
+        so = L.load()
+        if v.dtype != qk.dtype:
+            v = v.to(qk.dtype)
+        qk, v = qk.contiguous(), v.contiguous()
+        B, S, w2 = qk.shape
+        dk, dv = w2 // (2 * h), v.shape[-1] // h
+        f32 = 1 if qk.dtype == torch.float32 else 0
+        es = qk.element_size()
+        keep_u8 = keep.to(torch.uint8).contiguous() if keep is not None else None
+        out = torch.empty(B, S, h * dv, device=qk.device, dtype=qk.dtype)
+        stat = torch.empty(B * h, S, device=qk.device, dtype=torch.float32)
+        scale = 1.0 / math.sqrt(dk)
+        keep_scale = 1.0 / (1.0 - dropout_p) if keep is not None else 1.0
+        L.check(so.mt_attn_fwd_strided_launch(qk.data_ptr(), qk.data_ptr() + h * dk * es, v.data_ptr(),
+                                              keep_u8.data_ptr() if keep_u8 is not None else None, out.data_ptr(),
+                                              stat.data_ptr(), B * h, S, dk, dv, scale, keep_scale, _KIND[kind], h,
+                                              2 * h * dk, h * dv, h * dv, f32,
+                                              torch.cuda.current_stream(qk.device).cuda_stream), "mt_attn_fwd_strided_launch")
+        ctx.save_for_backward(qk, v, stat, keep_u8 if keep_u8 is not None else torch.empty(0, device=qk.device))
+        ctx.meta = (h, kind, scale, keep_scale, keep is not None, f32)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        so = L.load()
+        qk, v, stat, keep_u8 = ctx.saved_tensors
+        h, kind, scale, keep_scale, has_keep, f32 = ctx.meta
+        B, S, w2 = qk.shape
+        dk, dv = w2 // (2 * h), v.shape[-1] // h
+        es = qk.element_size()
+        do = grad_out.to(qk.dtype).contiguous()
+        dqk = torch.empty(B, S, w2, device=qk.device, dtype=torch.float32)
+        dv_ = torch.empty(B, S, h * dv, device=qk.device, dtype=torch.float32)
+        L.check(so.mt_attn_bwd_strided_launch(qk.data_ptr(), qk.data_ptr() + h * dk * es, v.data_ptr(), do.data_ptr(),
+                                              keep_u8.data_ptr() if has_keep else None, stat.data_ptr(), dqk.data_ptr(),
+                                              dqk.data_ptr() + h * dk * 4, dv_.data_ptr(), B * h, S, dk, dv, scale,
+                                              keep_scale, _KIND[kind], h, 2 * h * dk, h * dv, h * dv, f32,
+                                              torch.cuda.current_stream(qk.device).cuda_stream), "mt_attn_bwd_strided_launch")
+        return dqk.to(qk.dtype), dv_.to(v.dtype), None, None, None, None

@@ -34,16 +34,31 @@ __device__ __forceinline__ int img_off(int row, int chunk, int cpr) {
   return row * cpr * 16 + ((chunk ^ swz) << 4);
 }
 
-// global [rows][cols] bf16 (row stride ld elements) -> zero-padded LDS image [rows_pad][PCHQ * 8]
-template <int PCHQ>
-__device__ __forceinline__ void stage_image(uint8_t* lds, const uint16_t* __restrict__ src, int rows, int cols, int ld,
+// global [rows][cols] (row stride ld elements; bf16, or f32 converted on the way in) -> zero-padded LDS image
+// [rows_pad][PCHQ * 8] bf16
+template <int PCHQ, bool F32>
+__device__ __forceinline__ void stage_image(uint8_t* lds, const void* __restrict__ src_, int rows, int cols, long ld,
                                             int rows_pad, int tid) {
   for (int q = tid; q < rows_pad * PCHQ; q += AT_THREADS) {
     const int r = q / PCHQ, c = q % PCHQ;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (r < rows && c * 8 < cols) v = *reinterpret_cast<const u32x4*>(src + (size_t)r * ld + c * 8);
+    if (r < rows && c * 8 < cols) {
+      if constexpr (F32) {
+        const float* src = reinterpret_cast<const float*>(src_) + (size_t)r * ld + c * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+        v = u32x4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+      } else {
+        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(src_) + (size_t)r * ld + c * 8);
+      }
+    }
     *reinterpret_cast<u32x4*>(lds + img_off(r, c, PCHQ)) = v;
   }
+}
+
+// Where problem bh = (b, head) of a [B, S, H * d] operand with row stride ld starts: element offset.
+__device__ __forceinline__ size_t at_base(int bh, int H, int S, long ld, int d) {
+  const int b = bh / H, hh = bh - b * H;
+  return (size_t)b * S * ld + (size_t)hh * d;
 }
 
 // rows = M or N index (16 of them from row0), contraction contiguous: one ds_read_b128
@@ -98,23 +113,28 @@ __device__ __forceinline__ void scores_T(f32x4 (&acc)[NKB], const uint8_t* ldsK,
   }
 }
 
-template <int NKB, int PCHQ>   // NKB = padded sequence length / 16 (2, 4, 6 or 8); PCHQ = 16-byte chunks per image row
-__global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const uint16_t* __restrict__ Q,
-                                                                 const uint16_t* __restrict__ K,
-                                                                 const uint16_t* __restrict__ V,
+// NKB = padded sequence length / 16 (2, 4, 6 or 8); PCHQ = 16-byte chunks per image row; F32: Q, K, V, O are f32
+// (converted while staging) instead of bf16.  Operands are [B, S, H * d] with row strides ldq (Q and K), ldv, ldo, so
+// the halves of a fused QK projection and a [B, S, d_model] value / output tensor are used in place; H = 1 with
+// ld = d is the plain contiguous [BH, S, d] form.
+template <int NKB, int PCHQ, bool F32>
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const void* __restrict__ Q_, const void* __restrict__ K_,
+                                                                 const void* __restrict__ V_,
                                                                  const uint8_t* __restrict__ keep,
-                                                                 uint16_t* __restrict__ O, float* __restrict__ stat,
+                                                                 void* __restrict__ O_, float* __restrict__ stat,
                                                                  int S, int dk, int dv, float scale, float keep_scale,
-                                                                 int kind) {
+                                                                 int kind, int H, long ldq, long ldv, long ldo) {
   constexpr int SP = NKB * 16;
   constexpr int IMG = SP * PCHQ * 16;
   __shared__ __attribute__((aligned(16))) uint8_t lds[3 * IMG];
   uint8_t *ldsQ = lds, *ldsK = lds + IMG, *ldsV = lds + 2 * IMG;
   const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, fr = lane & 15;
-  stage_image<PCHQ>(ldsQ, Q + (size_t)bh * S * dk, S, dk, dk, SP, tid);
-  stage_image<PCHQ>(ldsK, K + (size_t)bh * S * dk, S, dk, dk, SP, tid);
-  stage_image<PCHQ>(ldsV, V + (size_t)bh * S * dv, S, dv, dv, SP, tid);
+  constexpr int ES = F32 ? 4 : 2;       // bytes per operand element
+  const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
+  stage_image<PCHQ, F32>(ldsQ, reinterpret_cast<const uint8_t*>(Q_) + qoff * ES, S, dk, ldq, SP, tid);
+  stage_image<PCHQ, F32>(ldsK, reinterpret_cast<const uint8_t*>(K_) + qoff * ES, S, dk, ldq, SP, tid);
+  stage_image<PCHQ, F32>(ldsV, reinterpret_cast<const uint8_t*>(V_) + voff * ES, S, dv, ldv, SP, tid);
   __syncthreads();
   const int dsteps = (dk + 31) / 32, nvb = (dv + 15) / 16;
 
@@ -190,22 +210,24 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const uint16_t*
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int qrow = qb * 16 + g * 4 + j;
-        if (qrow < S && n < dv) O[((size_t)bh * S + qrow) * dv + n] = (uint16_t)f32_to_bf16_bits(o[j]);
+        if (qrow < S && n < dv) {
+          const size_t at = ooff + (size_t)qrow * ldo + n;
+          if constexpr (F32) reinterpret_cast<float*>(O_)[at] = o[j];
+          else reinterpret_cast<uint16_t*>(O_)[at] = (uint16_t)f32_to_bf16_bits(o[j]);
+        }
       }
     }
   }
 }
 
-template <int NKB, int PCHQ>
-__global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const uint16_t* __restrict__ Q,
-                                                                 const uint16_t* __restrict__ K,
-                                                                 const uint16_t* __restrict__ V,
-                                                                 const uint16_t* __restrict__ dO,
+template <int NKB, int PCHQ, bool F32>     // dQ, dK, dV are f32 and laid out like Q, K, V (same row strides)
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const void* __restrict__ Q_, const void* __restrict__ K_,
+                                                                 const void* __restrict__ V_, const void* __restrict__ dO_,
                                                                  const uint8_t* __restrict__ keep,
                                                                  const float* __restrict__ stat, float* __restrict__ dQ,
                                                                  float* __restrict__ dK, float* __restrict__ dV, int S,
                                                                  int dk, int dv, float scale, float keep_scale,
-                                                                 int kind) {
+                                                                 int kind, int H, long ldq, long ldv, long ldo) {
   constexpr int SP = NKB * 16;
   constexpr int PCH = (SP <= 64) ? 8 : 16;        // chunks per row of the [key][query] images
   constexpr int PT_BYTES = SP * PCH * 16;
@@ -215,10 +237,12 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const uint16_t*
   uint8_t *ldsPT = lds + 4 * IMG, *ldsST = ldsPT + PT_BYTES;
   const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, fr = lane & 15;
-  stage_image<PCHQ>(ldsQ, Q + (size_t)bh * S * dk, S, dk, dk, SP, tid);
-  stage_image<PCHQ>(ldsK, K + (size_t)bh * S * dk, S, dk, dk, SP, tid);
-  stage_image<PCHQ>(ldsV, V + (size_t)bh * S * dv, S, dv, dv, SP, tid);
-  stage_image<PCHQ>(ldsdO, dO + (size_t)bh * S * dv, S, dv, dv, SP, tid);
+  constexpr int ES = F32 ? 4 : 2;
+  const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
+  stage_image<PCHQ, F32>(ldsQ, reinterpret_cast<const uint8_t*>(Q_) + qoff * ES, S, dk, ldq, SP, tid);
+  stage_image<PCHQ, F32>(ldsK, reinterpret_cast<const uint8_t*>(K_) + qoff * ES, S, dk, ldq, SP, tid);
+  stage_image<PCHQ, F32>(ldsV, reinterpret_cast<const uint8_t*>(V_) + voff * ES, S, dv, ldv, SP, tid);
+  stage_image<PCHQ, F32>(ldsdO, reinterpret_cast<const uint8_t*>(dO_) + ooff * ES, S, dv, ldo, SP, tid);
   __syncthreads();
   const int dsteps = (dk + 31) / 32, vsteps = (dv + 31) / 32, nkd = (dk + 15) / 16, nvb = (dv + 15) / 16;
 
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const uint16_t*
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int d = db * 16 + g * 4 + j;
-          if (d < dk) dQ[((size_t)bh * S + query) * dk + d] = a[j];
+          if (d < dk) dQ[qoff + (size_t)query * ldq + d] = a[j];
         }
       }
     }
@@ -309,7 +333,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const uint16_t*
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int key = kb * 16 + g * 4 + j;
-        if (key < S && n < dv) dV[((size_t)bh * S + key) * dv + n] = a[j];
+        if (key < S && n < dv) dV[voff + (size_t)key * ldv + n] = a[j];
       }
     }
     for (int db = 0; db < nkd; ++db) {       // dK[key][d] = sum_query dS^T[key][query] Q[query][d]
@@ -324,7 +348,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const uint16_t*
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int key = kb * 16 + g * 4 + j;
-        if (key < S && d < dk) dK[((size_t)bh * S + key) * dk + d] = a[j];
+        if (key < S && d < dk) dK[qoff + (size_t)key * ldq + d] = a[j];
       }
     }
   }
@@ -332,16 +356,28 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const uint16_t*
 
 static int nkb_for(int S) { return ((S + 31) / 32) * 2; }   // pad the sequence to a multiple of 32
 
-extern "C" int mt_attn_fwd_launch(const void* Q, const void* K, const void* V, const void* keep, void* O, float* stat,
-                                  int BH, int S, int dk, int dv, float scale, float keep_scale, int kind,
-                                  hipStream_t stream) {
+// Strided form.  Q, K: [B, S, H * dk] with row stride ldq elements (the two halves of a fused QK projection pass the
+// same ldq and pointers dk * H apart); V: row stride ldv; O (and dO): row stride ldo.  f32 != 0: operands and output
+// are f32, otherwise bf16.  All strides and head dims must keep 16-byte alignment of every 8-element chunk.
+static int at_check(int BH, int S, int dk, int dv, int H, long ldq, long ldv, long ldo, int f32) {
+  if (S < 1 || S > 128 || dk > 64 || dv > 64 || (dk & 7) || (dv & 7) || H < 1 || BH % H != 0) return -2;
+  const int al = f32 ? 4 : 8;       // elements per 16 bytes
+  if (ldq % al || ldv % al || ldo % al || ldq < (long)H * dk || ldv < (long)H * dv || ldo < (long)H * dv) return -2;
+  return 0;
+}
+
+extern "C" int mt_attn_fwd_strided_launch(const void* Q, const void* K, const void* V, const void* keep, void* O,
+                                          float* stat, int BH, int S, int dk, int dv, float scale, float keep_scale,
+                                          int kind, int H, long ldq, long ldv, long ldo, int f32, hipStream_t stream) {
   if (BH <= 0) return 0;
-  if (S < 1 || S > 128 || dk > 64 || dv > 64 || (dk & 7) || (dv & 7)) return -2;
+  const int rc = at_check(BH, S, dk, dv, H, ldq, ldv, ldo, f32);
+  if (rc) return rc;
   dim3 grid(BH), block(AT_THREADS);
   const bool narrow = dk <= 32 && dv <= 32;
-#define AT_FWD1(N, P)                                                                                          \
-  hipLaunchKernelGGL((mt_attn_fwd_kernel<N, P>), grid, block, 0, stream, (const uint16_t*)Q, (const uint16_t*)K, \
-                     (const uint16_t*)V, (const uint8_t*)keep, (uint16_t*)O, stat, S, dk, dv, scale, keep_scale, kind)
+#define AT_FWD2(N, P, F)                                                                                        \
+  hipLaunchKernelGGL((mt_attn_fwd_kernel<N, P, F>), grid, block, 0, stream, Q, K, V, (const uint8_t*)keep, O, stat, S, dk, \
+                     dv, scale, keep_scale, kind, H, ldq, ldv, ldo)
+#define AT_FWD1(N, P) do { if (f32) AT_FWD2(N, P, true); else AT_FWD2(N, P, false); } while (0)
 #define AT_FWD(N) do { if (narrow) AT_FWD1(N, 4); else AT_FWD1(N, 8); } while (0)
   switch (nkb_for(S)) {
     case 2: AT_FWD(2); break;
@@ -352,20 +388,23 @@ extern "C" int mt_attn_fwd_launch(const void* Q, const void* K, const void* V, c
   }
 #undef AT_FWD
 #undef AT_FWD1
+#undef AT_FWD2
   return (int)hipGetLastError();
 }
 
-extern "C" int mt_attn_bwd_launch(const void* Q, const void* K, const void* V, const void* dO, const void* keep,
-                                  const float* stat, float* dQ, float* dK, float* dV, int BH, int S, int dk, int dv,
-                                  float scale, float keep_scale, int kind, hipStream_t stream) {
+extern "C" int mt_attn_bwd_strided_launch(const void* Q, const void* K, const void* V, const void* dO, const void* keep,
+                                          const float* stat, float* dQ, float* dK, float* dV, int BH, int S, int dk,
+                                          int dv, float scale, float keep_scale, int kind, int H, long ldq, long ldv,
+                                          long ldo, int f32, hipStream_t stream) {
   if (BH <= 0) return 0;
-  if (S < 1 || S > 128 || dk > 64 || dv > 64 || (dk & 7) || (dv & 7)) return -2;
+  const int rc = at_check(BH, S, dk, dv, H, ldq, ldv, ldo, f32);
+  if (rc) return rc;
   dim3 grid(BH), block(AT_THREADS);
   const bool narrow = dk <= 32 && dv <= 32;
-#define AT_BWD1(N, P)                                                                                          \
-  hipLaunchKernelGGL((mt_attn_bwd_kernel<N, P>), grid, block, 0, stream, (const uint16_t*)Q, (const uint16_t*)K, \
-                     (const uint16_t*)V, (const uint16_t*)dO, (const uint8_t*)keep, stat, dQ, dK, dV, S, dk, dv, \
-                     scale, keep_scale, kind)
+#define AT_BWD2(N, P, F)                                                                                        \
+  hipLaunchKernelGGL((mt_attn_bwd_kernel<N, P, F>), grid, block, 0, stream, Q, K, V, dO, (const uint8_t*)keep, stat, dQ, \
+                     dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo)
+#define AT_BWD1(N, P) do { if (f32) AT_BWD2(N, P, true); else AT_BWD2(N, P, false); } while (0)
 #define AT_BWD(N) do { if (narrow) AT_BWD1(N, 4); else AT_BWD1(N, 8); } while (0)
   switch (nkb_for(S)) {
     case 2: AT_BWD(2); break;
@@ -375,5 +414,21 @@ extern "C" int mt_attn_bwd_launch(const void* Q, const void* K, const void* V, c
     default: return -3;
   }
 #undef AT_BWD
+#undef AT_BWD1
+#undef AT_BWD2
   return (int)hipGetLastError();
+}
+
+// Contiguous [BH, S, d] bf16 operands (one head per "batch" entry).
+extern "C" int mt_attn_fwd_launch(const void* Q, const void* K, const void* V, const void* keep, void* O, float* stat,
+                                  int BH, int S, int dk, int dv, float scale, float keep_scale, int kind,
+                                  hipStream_t stream) {
+  return mt_attn_fwd_strided_launch(Q, K, V, keep, O, stat, BH, S, dk, dv, scale, keep_scale, kind, 1, dk, dv, dv, 0, stream);
+}
+
+extern "C" int mt_attn_bwd_launch(const void* Q, const void* K, const void* V, const void* dO, const void* keep,
+                                  const float* stat, float* dQ, float* dK, float* dV, int BH, int S, int dk, int dv,
+                                  float scale, float keep_scale, int kind, hipStream_t stream) {
+  return mt_attn_bwd_strided_launch(Q, K, V, dO, keep, stat, dQ, dK, dV, BH, S, dk, dv, scale, keep_scale, kind, 1, dk, dv,
+                                    dv, 0, stream);
 }

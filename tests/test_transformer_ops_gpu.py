@@ -93,3 +93,31 @@ def test_transformer_models_run_on_the_fused_kernels():
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mg.parameters())
     s = SimpleTransformerModel(10, 32, 4, 2, 0.1).cuda()
     s(torch.randn(4, 50, 10, device="cuda")).sum().backward()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["softmax", "relu"])
+@pytest.mark.parametrize("B,S,h,dk,dv,drop", [(4, 50, 4, 16, 16, 0.0), (3, 65, 8, 24, 24, 0.2), (2, 96, 2, 64, 32, 0.1),
+                                              (5, 17, 2, 8, 40, 0.0)])
+def test_strided_self_attention_on_projection_outputs(B, S, h, dk, dv, drop, kind, dtype):
+    """The kernels read Q and K in place from one [B, S, 2*h*dk] tensor and V / O as [B, S, h*dv]."""
+    from mitune.ops.attention import attention_reference
+    from mitune.ops.attention_hip import FusedSelfAttention
+    g = torch.Generator(device="cuda").manual_seed(3)
+    qk = torch.randn(B, S, 2 * h * dk, device="cuda", generator=g).to(dtype).requires_grad_()
+    v = torch.randn(B, S, h * dv, device="cuda", generator=g).to(dtype).requires_grad_()
+    keep = (torch.rand(B, h, S, S, device="cuda", generator=g) >= drop).to(torch.uint8) if drop > 0 else None
+    do = torch.randn(B, S, h * dv, device="cuda", generator=g).to(dtype)
+    out = FusedSelfAttention.apply(qk, v, h, kind, keep, drop)
+    out.backward(do)
+    got = (out.float().detach(), qk.grad.float().clone(), v.grad.float().clone())
+    # reference on the bf16-rounded operands the kernel multiplies, in f32
+    qr = qk.detach().bfloat16().float().requires_grad_()
+    vr = v.detach().bfloat16().float().requires_grad_()
+    q, k = qr.chunk(2, dim=-1)
+    sp = lambda t, d: t.reshape(B, S, h, d).transpose(1, 2)          # noqa: E731
+    ref = attention_reference(sp(q, dk), sp(k, dk), sp(vr, dv), kind, keep, drop).transpose(1, 2).reshape(B, S, h * dv)
+    ref.backward(do.bfloat16().float())
+    tol = 3e-2 if dtype == torch.bfloat16 else 2e-2
+    for a, r, name in zip(got, (ref.detach(), qr.grad, vr.grad), ("out", "dqk", "dv")):
+        assert torch.allclose(a, r, rtol=tol, atol=tol * max(1.0, r.abs().max().item())), name
