@@ -73,15 +73,19 @@ def self_attention(qk: torch.Tensor, v: torch.Tensor, num_heads: int, kind: str 
     B, S, w2 = qk.shape
     h = num_heads
     dk, dv = w2 // (2 * h), v.shape[-1] // h
-    keep = None
-    if dropout_p > 0.0:
-        from .elementwise import keep_mask
-        keep = keep_mask((B, h, S, S), dropout_p, qk.device)
     if (qk.is_cuda and qk.dtype in (torch.float32, torch.bfloat16) and S <= MAX_SEQ and dk <= MAX_HEAD_DIM
             and dv <= MAX_HEAD_DIM and dk % 8 == 0 and dv % 8 == 0):
         from .attention_hip import FusedSelfAttention, available
         if available():
-            return FusedSelfAttention.apply(qk, v, h, kind, keep, dropout_p)
+            seed = None
+            if dropout_p > 0.0:           # no [B, h, S, S] mask tensor: the kernels hash (seed, element index)
+                from .rng import next_seed
+                seed = next_seed(qk.device)
+            return FusedSelfAttention.apply(qk, v, h, kind, None, dropout_p, seed)
+    keep = None
+    if dropout_p > 0.0:
+        from .elementwise import keep_mask
+        keep = keep_mask((B, h, S, S), dropout_p, qk.device)
     q, k = qk.chunk(2, dim=-1)
     split = lambda t, d: t.reshape(B, S, h, d).transpose(1, 2)          # noqa: E731
     o = attention_reference(split(q, dk), split(k, dk), split(v, dv), kind, keep, dropout_p)

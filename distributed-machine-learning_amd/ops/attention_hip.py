@@ -65,7 +65,8 @@ class FusedSelfAttention(torch.autograd.Function):
     in place and write the gradient of ``qk`` as one tensor."""
 
     @staticmethod
-    def forward(ctx, qk, v, h: int, kind: str, keep: Optional[torch.Tensor], dropout_p: float):
+    def forward(ctx, qk, v, h: int, kind: str, keep: Optional[torch.Tensor], dropout_p: float,
+                seed: Optional[torch.Tensor] = None):
         so = L.load()
         if v.dtype != qk.dtype:
             v = v.to(qk.dtype)
@@ -78,14 +79,18 @@ class FusedSelfAttention(torch.autograd.Function):
         out = torch.empty(B, S, h * dv, device=qk.device, dtype=qk.dtype)
         stat = torch.empty(B * h, S, device=qk.device, dtype=torch.float32)
         scale = 1.0 / math.sqrt(dk)
-        keep_scale = 1.0 / (1.0 - dropout_p) if keep is not None else 1.0
+        drops = keep is not None or (seed is not None and dropout_p > 0.0)
+        keep_scale = 1.0 / (1.0 - dropout_p) if drops else 1.0
+        seed = seed if (keep is None and drops) else None       # attention dropout drawn inside the kernel
         L.check(so.mt_attn_fwd_strided_launch(qk.data_ptr(), qk.data_ptr() + h * dk * es, v.data_ptr(),
                                               keep_u8.data_ptr() if keep_u8 is not None else None, out.data_ptr(),
                                               stat.data_ptr(), B * h, S, dk, dv, scale, keep_scale, _KIND[kind], h,
                                               2 * h * dk, h * dv, h * dv, f32,
+                                              seed.data_ptr() if seed is not None else None, float(dropout_p),
                                               torch.cuda.current_stream(qk.device).cuda_stream), "mt_attn_fwd_strided_launch")
         ctx.save_for_backward(qk, v, stat, keep_u8 if keep_u8 is not None else torch.empty(0, device=qk.device))
         ctx.meta = (h, kind, scale, keep_scale, keep is not None, f32)
+        ctx.seed, ctx.p = seed, float(dropout_p)
         return out
 
     @staticmethod
@@ -103,5 +108,6 @@ class FusedSelfAttention(torch.autograd.Function):
                                               keep_u8.data_ptr() if has_keep else None, stat.data_ptr(), dqk.data_ptr(),
                                               dqk.data_ptr() + h * dk * 4, dv_.data_ptr(), B * h, S, dk, dv, scale,
                                               keep_scale, _KIND[kind], h, 2 * h * dk, h * dv, h * dv, f32,
+                                              ctx.seed.data_ptr() if ctx.seed is not None else None, ctx.p,
                                               torch.cuda.current_stream(qk.device).cuda_stream), "mt_attn_bwd_strided_launch")
-        return dqk.to(qk.dtype), dv_.to(v.dtype), None, None, None, None
+        return dqk.to(qk.dtype), dv_.to(v.dtype), None, None, None, None, None

@@ -123,7 +123,12 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const void* __r
                                                                  const uint8_t* __restrict__ keep,
                                                                  void* __restrict__ O_, float* __restrict__ stat,
                                                                  int S, int dk, int dv, float scale, float keep_scale,
-                                                                 int kind, int H, long ldq, long ldv, long ldo) {
+                                                                 int kind, int H, long ldq, long ldv, long ldo,
+                                                                 const int64_t* __restrict__ seed, uint32_t thresh) {
+  // attention dropout: a stored [BH, S, S] byte mask if `keep` is given, else drawn here from the device seed
+  const bool masked = keep != nullptr || seed != nullptr;
+  uint32_t seed_lo = 0u, seed_hi = 0u;
+  if (seed != nullptr) { const uint64_t sv = (uint64_t)seed[0]; seed_lo = (uint32_t)sv; seed_hi = (uint32_t)(sv >> 32); }
   constexpr int SP = NKB * 16;
   constexpr int IMG = SP * PCHQ * 16;
   __shared__ __attribute__((aligned(16))) uint8_t lds[3 * IMG];
@@ -183,18 +188,24 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const void* __r
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       uint32_t kw = 0x01010101u;
-      if (keep != nullptr && query < S) {
+      if (masked && query < S) {
         const int key0 = kb * 16 + g * 4;
-        const uint8_t* kp = keep + ((size_t)bh * S + query) * S + key0;
+        const size_t at = ((size_t)bh * S + query) * S + key0;        // element index in the [BH, S, S] mask
         kw = 0u;
+        if (keep != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (key0 + j < S) kw |= (uint32_t)kp[j] << (8 * j);
+          for (int j = 0; j < 4; ++j)
+            if (key0 + j < S) kw |= (uint32_t)keep[at + j] << (8 * j);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (key0 + j < S) kw |= (mt_rng_hash(seed_lo, seed_hi, (uint32_t)(at + j)) >= thresh ? 1u : 0u) << (8 * j);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float mk = ((kw >> (8 * j)) & 0xFFu) ? keep_scale : 0.f;
-        acc[kb][j] *= norm * (keep != nullptr ? mk : 1.f);
+        acc[kb][j] *= norm * (masked ? mk : 1.f);
       }
     }
     // O = P . V with P straight from the accumulators
@@ -227,7 +238,12 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const void* __r
                                                                  const float* __restrict__ stat, float* __restrict__ dQ,
                                                                  float* __restrict__ dK, float* __restrict__ dV, int S,
                                                                  int dk, int dv, float scale, float keep_scale,
-                                                                 int kind, int H, long ldq, long ldv, long ldo) {
+                                                                 int kind, int H, long ldq, long ldv, long ldo,
+                                                                 const int64_t* __restrict__ seed, uint32_t thresh) {
+  // attention dropout: a stored [BH, S, S] byte mask if `keep` is given, else drawn here from the device seed
+  const bool masked = keep != nullptr || seed != nullptr;
+  uint32_t seed_lo = 0u, seed_hi = 0u;
+  if (seed != nullptr) { const uint64_t sv = (uint64_t)seed[0]; seed_lo = (uint32_t)sv; seed_hi = (uint32_t)(sv >> 32); }
   constexpr int SP = NKB * 16;
   constexpr int PCH = (SP <= 64) ? 8 : 16;        // chunks per row of the [key][query] images
   constexpr int PT_BYTES = SP * PCH * 16;
@@ -259,13 +275,19 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const void* __r
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       uint32_t kw = 0x01010101u;
-      if (keep != nullptr && query < S) {
+      if (masked && query < S) {
         const int key0 = kb * 16 + g * 4;
-        const uint8_t* kp = keep + ((size_t)bh * S + query) * S + key0;
+        const size_t at = ((size_t)bh * S + query) * S + key0;        // element index in the [BH, S, S] mask
         kw = 0u;
+        if (keep != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (key0 + j < S) kw |= (uint32_t)kp[j] << (8 * j);
+          for (int j = 0; j < 4; ++j)
+            if (key0 + j < S) kw |= (uint32_t)keep[at + j] << (8 * j);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (key0 + j < S) kw |= (mt_rng_hash(seed_lo, seed_hi, (uint32_t)(at + j)) >= thresh ? 1u : 0u) << (8 * j);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -274,7 +296,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const void* __r
         float pv;
         if (kind == 0) pv = (key < S && query < S) ? __expf(s - st) : 0.f;
         else { pv = fmaxf(s, 0.f) * inv_z; if (s > 0.f) relu_pos |= 1u << (kb * 4 + j); }
-        const float mk = (keep != nullptr) ? (((kw >> (8 * j)) & 0xFFu) ? keep_scale : 0.f) : 1.f;
+        const float mk = masked ? (((kw >> (8 * j)) & 0xFFu) ? keep_scale : 0.f) : 1.f;
         const float dpe = dp[kb][j] * mk;      // gradient w.r.t. the un-dropped probability
         delta += dpe * pv;
         p[kb][j] = pv;
@@ -368,15 +390,18 @@ static int at_check(int BH, int S, int dk, int dv, int H, long ldq, long ldv, lo
 
 extern "C" int mt_attn_fwd_strided_launch(const void* Q, const void* K, const void* V, const void* keep, void* O,
                                           float* stat, int BH, int S, int dk, int dv, float scale, float keep_scale,
-                                          int kind, int H, long ldq, long ldv, long ldo, int f32, hipStream_t stream) {
+                                          int kind, int H, long ldq, long ldv, long ldo, int f32, const int64_t* seed,
+                                          float p, hipStream_t stream) {
   if (BH <= 0) return 0;
   const int rc = at_check(BH, S, dk, dv, H, ldq, ldv, ldo, f32);
   if (rc) return rc;
+  const uint32_t thresh = (seed != nullptr && p > 0.f) ? (uint32_t)((double)p * 4294967296.0) : 0u;
+  if (thresh == 0u) seed = nullptr;
   dim3 grid(BH), block(AT_THREADS);
   const bool narrow = dk <= 32 && dv <= 32;
 #define AT_FWD2(N, P, F)                                                                                        \
   hipLaunchKernelGGL((mt_attn_fwd_kernel<N, P, F>), grid, block, 0, stream, Q, K, V, (const uint8_t*)keep, O, stat, S, dk, \
-                     dv, scale, keep_scale, kind, H, ldq, ldv, ldo)
+                     dv, scale, keep_scale, kind, H, ldq, ldv, ldo, seed, thresh)
 #define AT_FWD1(N, P) do { if (f32) AT_FWD2(N, P, true); else AT_FWD2(N, P, false); } while (0)
 #define AT_FWD(N) do { if (narrow) AT_FWD1(N, 4); else AT_FWD1(N, 8); } while (0)
   switch (nkb_for(S)) {
@@ -395,15 +420,17 @@ extern "C" int mt_attn_fwd_strided_launch(const void* Q, const void* K, const vo
 extern "C" int mt_attn_bwd_strided_launch(const void* Q, const void* K, const void* V, const void* dO, const void* keep,
                                           const float* stat, float* dQ, float* dK, float* dV, int BH, int S, int dk,
                                           int dv, float scale, float keep_scale, int kind, int H, long ldq, long ldv,
-                                          long ldo, int f32, hipStream_t stream) {
+                                          long ldo, int f32, const int64_t* seed, float p, hipStream_t stream) {
   if (BH <= 0) return 0;
   const int rc = at_check(BH, S, dk, dv, H, ldq, ldv, ldo, f32);
   if (rc) return rc;
+  const uint32_t thresh = (seed != nullptr && p > 0.f) ? (uint32_t)((double)p * 4294967296.0) : 0u;
+  if (thresh == 0u) seed = nullptr;
   dim3 grid(BH), block(AT_THREADS);
   const bool narrow = dk <= 32 && dv <= 32;
 #define AT_BWD2(N, P, F)                                                                                        \
   hipLaunchKernelGGL((mt_attn_bwd_kernel<N, P, F>), grid, block, 0, stream, Q, K, V, dO, (const uint8_t*)keep, stat, dQ, \
-                     dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo)
+                     dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo, seed, thresh)
 #define AT_BWD1(N, P) do { if (f32) AT_BWD2(N, P, true); else AT_BWD2(N, P, false); } while (0)
 #define AT_BWD(N) do { if (narrow) AT_BWD1(N, 4); else AT_BWD1(N, 8); } while (0)
   switch (nkb_for(S)) {
@@ -423,12 +450,13 @@ extern "C" int mt_attn_bwd_strided_launch(const void* Q, const void* K, const vo
 extern "C" int mt_attn_fwd_launch(const void* Q, const void* K, const void* V, const void* keep, void* O, float* stat,
                                   int BH, int S, int dk, int dv, float scale, float keep_scale, int kind,
                                   hipStream_t stream) {
-  return mt_attn_fwd_strided_launch(Q, K, V, keep, O, stat, BH, S, dk, dv, scale, keep_scale, kind, 1, dk, dv, dv, 0, stream);
+  return mt_attn_fwd_strided_launch(Q, K, V, keep, O, stat, BH, S, dk, dv, scale, keep_scale, kind, 1, dk, dv, dv, 0,
+                                    nullptr, 0.f, stream);
 }
 
 extern "C" int mt_attn_bwd_launch(const void* Q, const void* K, const void* V, const void* dO, const void* keep,
                                   const float* stat, float* dQ, float* dK, float* dV, int BH, int S, int dk, int dv,
                                   float scale, float keep_scale, int kind, hipStream_t stream) {
   return mt_attn_bwd_strided_launch(Q, K, V, dO, keep, stat, dQ, dK, dV, BH, S, dk, dv, scale, keep_scale, kind, 1, dk, dv,
-                                    dv, 0, stream);
+                                    dv, 0, nullptr, 0.f, stream);
 }

@@ -10,9 +10,7 @@
 //   mt_dropout_launch       y = keep ? x / (1 - p) : 0 for f32 or bf16 data; the same call with dy gives dx
 #include "mt_common.h"
 
-__device__ __forceinline__ uint32_t dr_hash(uint32_t s0, uint32_t s1, uint32_t i) {
-  return mt_mix32(i * 0x9E3779B9u + s0) ^ mt_mix32((i >> 5) + s1 * 0x85EBCA6Bu + 0x27D4EB2Fu);
-}
+#define dr_hash mt_rng_hash       // the same hash the fused kernels use for their in-kernel masks
 
 __global__ __launch_bounds__(256) void mt_keep_mask_kernel(uint8_t* __restrict__ out, long n, const int64_t* __restrict__ seed,
                                                            uint32_t thresh) {

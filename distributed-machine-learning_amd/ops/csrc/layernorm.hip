@@ -18,7 +18,8 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_fwd_kernel(const float* __re
                                                                const float* __restrict__ w, const float* __restrict__ b,
                                                                float* __restrict__ y, float* __restrict__ z,
                                                                float* __restrict__ stats, int M, int d, float eps,
-                                                               float keep_scale) {
+                                                               float keep_scale, const int64_t* __restrict__ seed,
+                                                               uint32_t thresh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= M) return;
@@ -33,8 +34,8 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_fwd_kernel(const float* __re
     if (c < nv) {
       f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + 4 * c);
       const f32x4 rv = *reinterpret_cast<const f32x4*>(res + base + 4 * c);
-      if (keep != nullptr) {
-        const uint32_t kw = *reinterpret_cast<const uint32_t*>(keep + base + 4 * c);
+      if (keep != nullptr || seed != nullptr) {
+        const uint32_t kw = mt_keep_word4(keep, seed, thresh, base + 4 * c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) xv[e] *= ((kw >> (8 * e)) & 0xFFu) ? keep_scale : 0.f;
       }
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_fwd_small_kernel(const float
                                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                                      float* __restrict__ y, float* __restrict__ z,
                                                                      float* __restrict__ stats, int M, int d, float eps,
-                                                                     float keep_scale) {
+                                                                     float keep_scale, const int64_t* __restrict__ seed,
+                                                                     uint32_t thresh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = (blockIdx.x * 4 + wave) * LN_SMALL_ROWS;
   if (row0 >= M) return;
@@ -91,8 +93,8 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_fwd_small_kernel(const float
     const size_t off = (size_t)(row0 + i < M ? row0 + i : row0) * d + c4;
     f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
     const f32x4 rv = *reinterpret_cast<const f32x4*>(res + off);
-    if (keep != nullptr) {        // uniform
-      const uint32_t kw = *reinterpret_cast<const uint32_t*>(keep + off);
+    if (keep != nullptr || seed != nullptr) {        // uniform
+      const uint32_t kw = mt_keep_word4(keep, seed, thresh, off);
 #pragma unroll
       for (int e = 0; e < 4; ++e) xv[e] *= ((kw >> (8 * e)) & 0xFFu) ? keep_scale : 0.f;
     }
@@ -134,7 +136,8 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_kernel(const float* __re
                                                                const uint8_t* __restrict__ keep,
                                                                const float* __restrict__ w, float* __restrict__ dx,
                                                                float* __restrict__ dres, float* __restrict__ dwb_part,
-                                                               int M, int d, float keep_scale) {
+                                                               int M, int d, float keep_scale,
+                                                               const int64_t* __restrict__ seed, uint32_t thresh) {
   __shared__ float red[4][2 * 2048 / 4];     // per wave: dw then db for one float4 column group at a time
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = d >> 2;
@@ -179,8 +182,8 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) dz[e] = rstd * (g[t][e] - s1 - xh[t][e] * s2);
         dxv = dz;
-        if (keep != nullptr) {
-          const uint32_t kw = *reinterpret_cast<const uint32_t*>(keep + base + 4 * c);
+        if (keep != nullptr || seed != nullptr) {
+          const uint32_t kw = mt_keep_word4(keep, seed, thresh, base + 4 * c);
 #pragma unroll
           for (int e = 0; e < 4; ++e) dxv[e] *= ((kw >> (8 * e)) & 0xFFu) ? keep_scale : 0.f;
         }
@@ -218,24 +221,29 @@ extern "C" int mt_ln_bwd_blocks(int M) { return (M + 4 * LN_ROWS_PER_WAVE - 1) /
 
 extern "C" int mt_ln_fwd_launch(const float* x, const float* res, const void* keep, const float* w, const float* b,
                                 float* y, float* z, float* stats, int M, int d, float eps, float keep_scale,
-                                hipStream_t stream) {
+                                const int64_t* seed, float p, hipStream_t stream) {
+  // dropout mask: `keep` (uint8 per element) if given, else drawn in the kernel from `seed` with drop probability p
+  const uint32_t thresh = (seed != nullptr && p > 0.f) ? (uint32_t)((double)p * 4294967296.0) : 0u;
+  if (thresh == 0u) seed = nullptr;
   if (M <= 0) return 0;
   if (d > 2048 || (d & 3)) return -2;
   if (d <= 256)
     hipLaunchKernelGGL(mt_ln_fwd_small_kernel, dim3((M + 4 * LN_SMALL_ROWS - 1) / (4 * LN_SMALL_ROWS)), dim3(LN_THREADS), 0,
-                       stream, x, res, (const uint8_t*)keep, w, b, y, z, stats, M, d, eps, keep_scale);
+                       stream, x, res, (const uint8_t*)keep, w, b, y, z, stats, M, d, eps, keep_scale, seed, thresh);
   else
     hipLaunchKernelGGL(mt_ln_fwd_kernel, dim3((M + 3) / 4), dim3(LN_THREADS), 0, stream, x, res, (const uint8_t*)keep, w,
-                       b, y, z, stats, M, d, eps, keep_scale);
+                       b, y, z, stats, M, d, eps, keep_scale, seed, thresh);
   return (int)hipGetLastError();
 }
 
 extern "C" int mt_ln_bwd_launch(const float* dy, const float* z, const float* stats, const void* keep, const float* w,
                                 float* dx, float* dres, float* dwb_part, int M, int d, float keep_scale,
-                                hipStream_t stream) {
+                                const int64_t* seed, float p, hipStream_t stream) {
+  const uint32_t thresh = (seed != nullptr && p > 0.f) ? (uint32_t)((double)p * 4294967296.0) : 0u;
+  if (thresh == 0u) seed = nullptr;
   if (M <= 0) return 0;
   if (d > 2048 || (d & 3)) return -2;
   hipLaunchKernelGGL(mt_ln_bwd_kernel, dim3(mt_ln_bwd_blocks(M)), dim3(LN_THREADS), 0, stream, dy, z, stats,
-                     (const uint8_t*)keep, w, dx, dres, dwb_part, M, d, keep_scale);
+                     (const uint8_t*)keep, w, dx, dres, dwb_part, M, d, keep_scale, seed, thresh);
   return (int)hipGetLastError();
 }

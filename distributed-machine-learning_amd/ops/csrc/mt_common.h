@@ -111,6 +111,25 @@ __device__ __forceinline__ uint32_t mt_mix32(uint32_t x) {
   x = (x ^ (x >> 13)) * 0xC2B2AE35u;
   return x ^ (x >> 16);
 }
+
+// Counter-based dropout: element i of a tensor is kept iff mt_rng_hash(seed, i) >= p * 2^32.  The 64-bit seed lives in
+// device memory (ops/rng.py), so captured graphs draw fresh masks per replay and a backward pass recomputes the
+// forward's mask instead of reading a stored one.
+__device__ __forceinline__ uint32_t mt_rng_hash(uint32_t s0, uint32_t s1, uint32_t i) {
+  return mt_mix32(i * 0x9E3779B9u + s0) ^ mt_mix32((i >> 5) + s1 * 0x85EBCA6Bu + 0x27D4EB2Fu);
+}
+// Keep flags (one byte each, 0 or 1) of elements i .. i+3, from a stored mask if there is one, else from the seed.
+__device__ __forceinline__ uint32_t mt_keep_word4(const uint8_t* __restrict__ keep, const int64_t* __restrict__ seed,
+                                                  uint32_t thresh, size_t i) {
+  if (keep != nullptr) return *reinterpret_cast<const uint32_t*>(keep + i);
+  if (seed == nullptr) return 0x01010101u;
+  const uint64_t s = (uint64_t)seed[0];
+  const uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+  uint32_t w = 0u;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w |= (mt_rng_hash(s0, s1, (uint32_t)(i + e)) >= thresh ? 1u : 0u) << (8 * e);
+  return w;
+}
 __device__ __forceinline__ uint32_t mt_feistel(uint32_t x, const uint32_t* key, int hb) {
   const uint32_t mask = (1u << hb) - 1u;
   uint32_t left = (x >> hb) & mask, right = x & mask;

@@ -24,12 +24,17 @@ def residual_layer_norm_reference(x: torch.Tensor, residual: torch.Tensor, weigh
 
 def residual_layer_norm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
                         eps: float = 1e-5, dropout_p: float = 0.0) -> torch.Tensor:
+    fused = x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 2048 and x.shape[-1] % 4 == 0
+    if fused:
+        from .layernorm_hip import FusedResidualLayerNorm, available
+        if available():
+            seed = None
+            if dropout_p > 0.0:           # the mask is drawn inside the kernel from a device-resident seed
+                from .rng import next_seed
+                seed = next_seed(x.device)
+            return FusedResidualLayerNorm.apply(x, residual, weight, bias, eps, None, dropout_p, seed)
     keep = None
     if dropout_p > 0.0:
         from .elementwise import keep_mask
         keep = keep_mask(x.shape, dropout_p, x.device)
-    if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 2048 and x.shape[-1] % 4 == 0:
-        from .layernorm_hip import FusedResidualLayerNorm, available
-        if available():
-            return FusedResidualLayerNorm.apply(x, residual, weight, bias, eps, keep, dropout_p)
     return residual_layer_norm_reference(x, residual, weight, bias, eps, keep, dropout_p)

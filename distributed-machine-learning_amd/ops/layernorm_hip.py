@@ -17,7 +17,10 @@ def available() -> bool:
 
 class FusedResidualLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, eps: float, keep: Optional[torch.Tensor], dropout_p: float):
+    def forward(ctx, x, residual, weight, bias, eps: float, keep: Optional[torch.Tensor], dropout_p: float,
+                seed: Optional[torch.Tensor] = None):
+        """Dropout on ``x``: a stored 0/1 ``keep`` mask, or (``seed`` [1] int64 on the device) a mask drawn inside the
+        kernel and re-drawn from the same seed in backward; neither: no dropout."""
         so = L.load()
         d = x.shape[-1]
         xf, rf = x.contiguous().view(-1, d), residual.contiguous().view(-1, d)
@@ -25,14 +28,18 @@ class FusedResidualLayerNorm(torch.autograd.Function):
         keep_u8 = keep.to(torch.uint8).contiguous() if keep is not None else None
         y, z = torch.empty_like(xf), torch.empty_like(xf)
         stats = torch.empty(M, 2, device=x.device, dtype=torch.float32)
-        keep_scale = 1.0 / (1.0 - dropout_p) if keep is not None else 1.0
+        drops = keep is not None or (seed is not None and dropout_p > 0.0)
+        keep_scale = 1.0 / (1.0 - dropout_p) if drops else 1.0
+        seed = seed if (keep is None and drops) else None
         w, b = weight.contiguous(), bias.contiguous()
         L.check(so.mt_ln_fwd_launch(xf.data_ptr(), rf.data_ptr(), keep_u8.data_ptr() if keep_u8 is not None else None,
                                     w.data_ptr(), b.data_ptr(), y.data_ptr(), z.data_ptr(), stats.data_ptr(), M, d,
-                                    float(eps), keep_scale, torch.cuda.current_stream(x.device).cuda_stream),
+                                    float(eps), keep_scale, seed.data_ptr() if seed is not None else None,
+                                    float(dropout_p), torch.cuda.current_stream(x.device).cuda_stream),
                 "mt_ln_fwd_launch")
         ctx.save_for_backward(z, stats, w, keep_u8 if keep_u8 is not None else torch.empty(0, device=x.device))
         ctx.meta = (keep is not None, keep_scale, x.shape)
+        ctx.seed, ctx.p = seed, float(dropout_p)
         return y.view(x.shape)
 
     @staticmethod
@@ -48,6 +55,7 @@ class FusedResidualLayerNorm(torch.autograd.Function):
         L.check(so.mt_ln_bwd_launch(dy.data_ptr(), z.data_ptr(), stats.data_ptr(),
                                     keep_u8.data_ptr() if has_keep else None, w.data_ptr(), dx.data_ptr(),
                                     dres.data_ptr(), part.data_ptr(), M, d, keep_scale,
+                                    ctx.seed.data_ptr() if ctx.seed is not None else None, ctx.p,
                                     torch.cuda.current_stream(z.device).cuda_stream), "mt_ln_bwd_launch")
         dwb = part.sum(0)
-        return dx.view(shape), dres.view(shape), dwb[0], dwb[1], None, None, None
+        return dx.view(shape), dres.view(shape), dwb[0], dwb[1], None, None, None, None

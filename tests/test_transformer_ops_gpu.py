@@ -121,3 +121,53 @@ def test_strided_self_attention_on_projection_outputs(B, S, h, dk, dv, drop, kin
     tol = 3e-2 if dtype == torch.bfloat16 else 2e-2
     for a, r, name in zip(got, (ref.detach(), qr.grad, vr.grad), ("out", "dqk", "dv")):
         assert torch.allclose(a, r, rtol=tol, atol=tol * max(1.0, r.abs().max().item())), name
+
+
+def test_in_kernel_dropout_masks_equal_the_materialised_mask():
+    """Seed-driven masks inside the attention and LayerNorm kernels are the masks ``keep_mask`` would write for the same
+    seed, in forward and in backward."""
+    from mitune.ops import lib as L
+    from mitune.ops.attention_hip import FusedSelfAttention
+    from mitune.ops.layernorm_hip import FusedResidualLayerNorm
+    so = L.load()
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    seed = torch.tensor([0x1234ABCD5678], dtype=torch.int64, device=dev)
+
+    def mask(shape, p):
+        out = torch.empty(shape, dtype=torch.uint8, device=dev)
+        L.check(so.mt_keep_mask_launch(out.data_ptr(), out.numel(), seed.data_ptr(), p, torch.cuda.current_stream().cuda_stream), "mask")
+        return out
+
+    B, S, h, dk, dv, p = 3, 50, 4, 16, 16, 0.25
+    for dtype in (torch.float32, torch.bfloat16):
+        qk = torch.randn(B, S, 2 * h * dk, device=dev, generator=g).to(dtype)
+        v = torch.randn(B, S, h * dv, device=dev, generator=g).to(dtype)
+        do = torch.randn(B, S, h * dv, device=dev, generator=g).to(dtype)
+        res = []
+        for use_seed in (True, False):
+            a, b = qk.clone().requires_grad_(), v.clone().requires_grad_()
+            keep = None if use_seed else mask((B, h, S, S), p)
+            out = FusedSelfAttention.apply(a, b, h, "softmax", keep, p, seed if use_seed else None)
+            out.backward(do)
+            res.append((out.detach(), a.grad, b.grad))
+        for x, y in zip(*res):
+            assert torch.equal(x, y)
+    x = torch.randn(4, 37, 192, device=dev, generator=g)
+    r = torch.randn(4, 37, 192, device=dev, generator=g)
+    w = torch.randn(192, device=dev, generator=g)
+    bias = torch.randn(192, device=dev, generator=g)
+    dy = torch.randn(4, 37, 192, device=dev, generator=g)
+    for d_cols in (192, 512):
+        xs, rs = (x, r) if d_cols == 192 else (torch.randn(3, 9, 512, device=dev, generator=g), torch.randn(3, 9, 512, device=dev, generator=g))
+        ws, bs = (w, bias) if d_cols == 192 else (torch.randn(512, device=dev, generator=g), torch.randn(512, device=dev, generator=g))
+        dys = dy if d_cols == 192 else torch.randn(3, 9, 512, device=dev, generator=g)
+        res = []
+        for use_seed in (True, False):
+            a, b = xs.clone().requires_grad_(), rs.clone().requires_grad_()
+            keep = None if use_seed else mask(xs.shape, 0.3)
+            y = FusedResidualLayerNorm.apply(a, b, ws, bs, 1e-5, keep, 0.3, seed if use_seed else None)
+            y.backward(dys)
+            res.append((y.detach(), a.grad, b.grad))
+        for x1, x2 in zip(*res):
+            assert torch.equal(x1, x2)
