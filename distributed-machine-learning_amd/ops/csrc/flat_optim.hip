@@ -115,6 +115,99 @@ __global__ void mt_flat_advance_kernel(MtFlatOpt* st) {
   if (threadIdx.x == 0 && blockIdx.x == 0) st->step = st->step + 1;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Scattered gradients.  With gradients pre-bound to views of a slab, autograd ADDS into them: one extra kernel per
+// parameter per step.  Left unbound, autograd hands each parameter the tensor its backward op produced -- inside a
+// captured graph always at the same address -- and these kernels read the gradients where they are, through a
+// table of segments (one per block of up to 2048 elements): {offset in the parameter slab, gradient pointer, count}.
+struct MtGradSeg {
+  long off;
+  const float* g;      // null: the parameter received no gradient this step (treated as zero)
+  int32_t cnt;
+  int32_t pad;
+};
+
+__global__ __launch_bounds__(FOPT_THREADS) void mt_flat_sqnorm_seg_kernel(const MtGradSeg* __restrict__ segs,
+                                                                          float* __restrict__ partials) {
+  const MtGradSeg sg = segs[blockIdx.x];
+  const int local = threadIdx.x * 8;
+  float acc = 0.f;
+  if (sg.g != nullptr)
+    for (int e = local; e < local + 8 && e < sg.cnt; ++e) acc += sg.g[e] * sg.g[e];
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(FOPT_THREADS) void mt_flat_optim_seg_kernel(float* __restrict__ P, float* __restrict__ M,
+                                                                         float* __restrict__ V,
+                                                                         const MtGradSeg* __restrict__ segs,
+                                                                         const MtFlatOpt* __restrict__ st,
+                                                                         const float* __restrict__ partials, int nb) {
+  const MtFlatOpt h = *st;
+  const MtGradSeg sg = segs[blockIdx.x];
+  float gscale = 1.f;
+  if (h.clip > 0.f && partials != nullptr) {
+    float tot = 0.f;
+    for (int i = 0; i < nb; ++i) tot += partials[i];
+    const float c = h.clip / (sqrtf(tot) + 1e-6f);
+    gscale = c < 1.f ? c : 1.f;
+  }
+  const int local = threadIdx.x * 8;
+  if (local >= sg.cnt) return;
+  const int cnt = (sg.cnt - local) < 8 ? (sg.cnt - local) : 8;
+  const int t = h.step;
+  const float lr = h.lr * flat_lr_factor(t, h.warmup, h.total);
+  const float bc1 = 1.f - powf(h.beta1, (float)(t + 1));
+  const float inv_bc2_sqrt = 1.f / sqrtf(1.f - powf(h.beta2, (float)(t + 1)));
+  const long base = sg.off + local;
+  for (int e = 0; e < cnt; ++e) {
+    float p = P[base + e], m = M[base + e], v = V[base + e];
+    float gg = (sg.g != nullptr ? sg.g[local + e] : 0.f) * gscale;
+    switch (h.opt_type) {
+      case 0:
+      case 1: {
+        if (h.opt_type == 0) gg += h.wd * p;
+        else p *= (1.f - lr * h.wd);
+        m = h.beta1 * m + (1.f - h.beta1) * gg;
+        v = h.beta2 * v + (1.f - h.beta2) * gg * gg;
+        p -= (lr / bc1) * (m / (sqrtf(v) * inv_bc2_sqrt + h.eps));
+      } break;
+      case 2: {
+        gg += h.wd * p;
+        m = (t == 0 || h.momentum <= 0.f) ? gg : h.momentum * m + gg;
+        p -= lr * m;
+      } break;
+      default: {
+        gg += h.wd * p;
+        v = 0.99f * v + 0.01f * gg * gg;
+        const float avg = sqrtf(v) + h.eps;
+        if (h.momentum > 0.f) { m = h.momentum * m + gg / avg; p -= lr * m; }
+        else p -= lr * gg / avg;
+      } break;
+    }
+    P[base + e] = p; M[base + e] = m; V[base + e] = v;
+  }
+}
+
+extern "C" int mt_grad_seg_sizeof() { return (int)sizeof(MtGradSeg); }
+
+// segs: n_segs device-resident MtGradSeg; partials: f32[n_segs] when use_clip.
+extern "C" int mt_flat_optim_seg_launch(float* P, float* M, float* V, const MtGradSeg* segs, int n_segs, MtFlatOpt* st,
+                                        float* partials, int use_clip, hipStream_t stream) {
+  if (n_segs <= 0) return 0;
+  if (use_clip) {
+    if (partials == nullptr) return -3;
+    hipLaunchKernelGGL(mt_flat_sqnorm_seg_kernel, dim3(n_segs), dim3(FOPT_THREADS), 0, stream, segs, partials);
+  }
+  hipLaunchKernelGGL(mt_flat_optim_seg_kernel, dim3(n_segs), dim3(FOPT_THREADS), 0, stream, P, M, V, segs, st,
+                     use_clip ? partials : nullptr, n_segs);
+  hipLaunchKernelGGL(mt_flat_advance_kernel, dim3(1), dim3(64), 0, stream, st);
+  return (int)hipGetLastError();
+}
+
 extern "C" int mt_flat_opt_sizeof() { return (int)sizeof(MtFlatOpt); }
 
 extern "C" int mt_flat_optim_blocks(long n) { return (int)((n + FOPT_PER_BLOCK - 1) / FOPT_PER_BLOCK); }

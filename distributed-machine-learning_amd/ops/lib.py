@@ -176,6 +176,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn.restype = C.c_int
     if lib.mt_flat_opt_sizeof() != C.sizeof(FlatOpt) or lib.mt_head_mlp_sizeof() != C.sizeof(HeadMlp):
         raise KernelLibraryError("FlatOpt / HeadMlp layout mismatch between lib.py and the library")
+    if lib.mt_grad_seg_sizeof() != 24:
+        raise KernelLibraryError("MtGradSeg is not 24 bytes")
+    lib.mt_flat_optim_seg_launch.argtypes = [c_void_p] * 4 + [C.c_int, c_void_p, c_void_p, C.c_int, c_void_p]
+    lib.mt_flat_optim_seg_launch.restype = C.c_int
     lib.mt_flat_optim_blocks.argtypes = [C.c_long]
     lib.mt_flat_optim_launch.argtypes = [c_void_p] * 4 + [C.c_long, c_void_p, c_void_p, C.c_int, C.c_int, c_void_p]
     lib.mt_posenc_fwd_launch.argtypes = [c_void_p] * 3 + [C.c_long, C.c_int, C.c_int, c_void_p, c_float, c_void_p]

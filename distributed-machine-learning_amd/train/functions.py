@@ -117,7 +117,7 @@ def _fit_graphed(model, config: Dict, data_loader, val_loader, epochs: int, crit
     train_t, val_t = _device_tensors(data_loader, device), _device_tensors(val_loader, device)
     if train_t is None or val_t is None:
         return False
-    flat = FlatParams(model)
+    flat = FlatParams(model, grad_slab=False)      # autograd's own gradient tensors, read in place by the optimiser
     opt = FlatOptimizer(flat, opt_name, lr, weight_decay, momentum, clip=clip, warmup=warmup, total=total)
     start = _resume(model, opt)
     opt.set_hyper(lr, weight_decay)           # PBT may have perturbed these since the checkpoint was taken

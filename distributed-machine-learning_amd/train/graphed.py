@@ -38,12 +38,19 @@ _CAPTURE_LOCK = threading.Lock()
 SHARED_GPU_THREADS = False
 
 _ALIGN = 8        # parameter offsets in the slab are multiples of 8 floats (32 bytes)
+_SEG = 2048       # elements per optimiser block / gradient-table segment
 
 
 class FlatParams:
-    """Re-homes a module's trainable parameters into one contiguous f32 slab (and gradients into another)."""
+    """Re-homes a module's trainable parameters into one contiguous f32 slab.
 
-    def __init__(self, model: torch.nn.Module):
+    ``grad_slab=True`` also binds every gradient to a view of a twin slab (autograd then accumulates in place, one add
+    kernel per parameter); ``grad_slab=False`` leaves gradients unbound, so autograd hands over the tensors its backward
+    ops produced and the optimiser reads them where they are (``FlatOptimizer`` keeps a table of their addresses).
+    """
+
+    def __init__(self, model: torch.nn.Module, grad_slab: bool = True):
+        self.grad_slab = grad_slab
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("model has no trainable parameters")
@@ -56,12 +63,13 @@ class FlatParams:
             n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.n, self.offsets = n, offs
         self.P = torch.zeros(n, device=dev)
-        self.G = torch.zeros(n, device=dev)
+        self.G = torch.zeros(n if grad_slab else 0, device=dev)
         with torch.no_grad():
             for p, o in zip(self.params, offs):
                 self.P[o:o + p.numel()].copy_(p.detach().reshape(-1))
                 p.data = self.P[o:o + p.numel()].view(p.shape)
-                p.grad = self.G[o:o + p.numel()].view(p.shape)     # autograd accumulates in place into the slab
+                # slab mode: autograd accumulates in place into the slab
+                p.grad = self.G[o:o + p.numel()].view(p.shape) if grad_slab else None
 
 
 class FlatOptimizer:
@@ -86,6 +94,22 @@ class FlatOptimizer:
         self._i32 = self.state.view(torch.int32)
         self.use_clip = clip > 0.0
         nb = int(self.so.mt_flat_optim_blocks(flat.n))
+        self._segs = None
+        if not flat.grad_slab:
+            # one segment per block of up to 2048 elements of a parameter: [slab offset, gradient address, count]
+            rows, owner, local = [], [], []
+            for i, (p, off) in enumerate(zip(flat.params, flat.offsets)):
+                for c in range(0, p.numel(), _SEG):
+                    rows.append([off + c, 0, min(_SEG, p.numel() - c)])
+                    owner.append(i)
+                    local.append(c * 4)
+            self._segs = torch.tensor(rows, dtype=torch.int64)
+            self._seg_owner = torch.tensor(owner, dtype=torch.int64)
+            self._seg_local = torch.tensor(local, dtype=torch.int64)
+            self._tables = {"eager": self._segs.to(dev), "graph": self._segs.to(dev)}
+            self._ptrs = {"eager": None, "graph": None}
+            self._deferred = None
+            nb = len(rows)
         self.partials = torch.zeros(max(nb, 1), device=dev)
 
     # field slots of the FlatOpt record (4-byte words)
@@ -97,8 +121,41 @@ class FlatOptimizer:
         if weight_decay is not None:
             self._f32[self._WD:self._WD + 1].fill_(float(weight_decay))
 
+    def _write_table(self, which: str, ptrs) -> None:
+        base = torch.tensor(ptrs, dtype=torch.int64)[self._seg_owner]
+        host = self._segs.clone()
+        host[:, 1] = torch.where(base != 0, base + self._seg_local, base)
+        self._tables[which].copy_(host)
+        self._ptrs[which] = ptrs
+
+    def finish_capture(self) -> None:
+        """Fill the captured step's gradient table (its addresses are only known once the capture has run)."""
+        if self._segs is not None and self._deferred is not None:
+            self._write_table("graph", self._deferred)
+            self._deferred = None
+
+    def _step_scattered(self) -> None:
+        f = self.flat
+        ptrs = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in f.params)
+        stream = torch.cuda.current_stream(f.P.device)
+        if torch.cuda.is_current_stream_capturing():
+            which, self._deferred = "graph", ptrs
+        else:
+            which = "eager"
+            if ptrs != self._ptrs["eager"]:
+                self._write_table("eager", ptrs)
+        table = self._tables[which]
+        self.L.check(self.so.mt_flat_optim_seg_launch(f.P.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), table.data_ptr(),
+                                                      table.shape[0], self.state.data_ptr(), self.partials.data_ptr(),
+                                                      1 if self.use_clip else 0, stream.cuda_stream),
+                     "mt_flat_optim_seg_launch")
+        for p in f.params:
+            p.grad = None            # the next backward hands over fresh tensors (same addresses under graph replay)
+
     def step(self) -> None:
         f = self.flat
+        if self._segs is not None:
+            return self._step_scattered()
         self.L.check(self.so.mt_flat_optim_launch(f.P.data_ptr(), f.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
                                                   f.n, self.state.data_ptr(), self.partials.data_ptr(),
                                                   1 if self.use_clip else 0, 1,
@@ -106,7 +163,11 @@ class FlatOptimizer:
                      "mt_flat_optim_launch")
 
     def zero_grad(self) -> None:      # the update kernel already zeroes the slab; this is for completeness
-        self.flat.G.zero_()
+        if self._segs is not None:
+            for p in self.flat.params:
+                p.grad = None
+        else:
+            self.flat.G.zero_()
 
     @property
     def steps_taken(self) -> int:
@@ -188,7 +249,7 @@ class GraphedTrainer:
         cur.wait_stream(side)
         with torch.no_grad():                  # undo the warm-up steps: training starts from the initial weights
             f.P.copy_(keep[0]); o.M.copy_(keep[1]); o.V.copy_(keep[2]); o.state.copy_(keep[3])
-            f.G.zero_(); self.pos.zero_(); self.running.zero_()
+            o.zero_grad(); self.pos.zero_(); self.running.zero_()
         cur.synchronize()                      # stream-level only: a device-wide wait would disturb other threads
         g = torch.cuda.CUDAGraph()
         # Raw capture_begin / capture_end on the warm-up stream: the torch.cuda.graph context would first synchronise the
@@ -203,6 +264,7 @@ class GraphedTrainer:
                 finally:
                     g.capture_end()
             cur.wait_stream(side)
+        o.finish_capture()
         self.graph = g
 
     # ------------------------------------------------------------------ epochs

@@ -98,14 +98,15 @@ def test_head_mlp_matches_reference(B, d, dims):
 # ------------------------------------------------------------------ flat optimiser vs torch.optim
 @pytest.mark.parametrize("name", ["adam", "adamw", "sgd", "rmsprop"])
 @pytest.mark.parametrize("clip", [0.0, 0.5])
-def test_flat_optimizer_matches_torch(name, clip):
+@pytest.mark.parametrize("grad_slab", [True, False])
+def test_flat_optimizer_matches_torch(name, clip, grad_slab):
     from mitune.train.graphed import FlatOptimizer, FlatParams
     from mitune.train.optim import build_optimizer
     torch.manual_seed(0)
     a = torch.nn.Sequential(torch.nn.Linear(13, 37), torch.nn.ReLU(), torch.nn.Linear(37, 3)).to(DEV)
     b = torch.nn.Sequential(torch.nn.Linear(13, 37), torch.nn.ReLU(), torch.nn.Linear(37, 3)).to(DEV)
     b.load_state_dict(a.state_dict())
-    flat = FlatParams(a)
+    flat = FlatParams(a, grad_slab=grad_slab)
     fo = FlatOptimizer(flat, name, lr=3e-3, weight_decay=1e-2, momentum=0.9, clip=clip)
     to = build_optimizer(name, b.parameters(), 3e-3, 1e-2, 0.9)
     for step in range(6):
@@ -118,7 +119,10 @@ def test_flat_optimizer_matches_torch(name, clip):
             torch.nn.utils.clip_grad_norm_(b.parameters(), clip)
         to.step()
     assert fo.steps_taken == 6
-    assert float(flat.G.abs().max()) == 0.0                    # the update zeroed the gradient slab
+    if grad_slab:
+        assert float(flat.G.abs().max()) == 0.0                # the update zeroed the gradient slab
+    else:
+        assert all(p.grad is None for p in a.parameters())     # gradients were read in place and released
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.allclose(pa, pb, rtol=2e-4, atol=2e-6)
 
@@ -127,7 +131,7 @@ def test_flat_optimizer_schedule_and_state_roundtrip():
     from mitune.models.mlp import lr_factor
     from mitune.train.graphed import FlatOptimizer, FlatParams
     m = torch.nn.Linear(4, 4, bias=False).to(DEV)
-    flat = FlatParams(m)
+    flat = FlatParams(m)          # slab mode: the test writes gradients straight into the slab view
     fo = FlatOptimizer(flat, "sgd", lr=0.1, momentum=0.0, warmup=3, total=10)
     w0 = m.weight.detach().clone()
     expect = w0.clone()
@@ -158,7 +162,7 @@ def test_graphed_training_matches_eager_stepping():
     for use_graph in (True, False):
         torch.manual_seed(0)
         model = SimpleTransformerModel(10, 32, 2, 1, dropout=0.0).to(DEV)
-        opt = FlatOptimizer(FlatParams(model), "adamw", lr=1e-3, weight_decay=1e-4)
+        opt = FlatOptimizer(FlatParams(model, grad_slab=False), "adamw", lr=1e-3, weight_decay=1e-4)
         tr = GraphedTrainer(model, torch.nn.MSELoss(), X, y, 32, opt, seed=3, use_graph=use_graph)
         assert tr.graphed == use_graph
         losses[use_graph] = [tr.train_epoch() for _ in range(3)]
@@ -175,7 +179,7 @@ def test_graphed_training_with_dropout_and_ragged_tail_learns():
     torch.manual_seed(1)
     model = TransformerModel(10, 2, 2, 32, 64, 0.1, attention_type="linear_attention",
                              depthwise_separable_conv=True).to(DEV)
-    opt = FlatOptimizer(FlatParams(model), "adam", lr=2e-3, clip=1.0, warmup=5, total=400)
+    opt = FlatOptimizer(FlatParams(model, grad_slab=False), "adam", lr=2e-3, clip=1.0, warmup=5, total=400)
     tr = GraphedTrainer(model, torch.nn.MSELoss(), X, y.unsqueeze(1), 32, opt, seed=0)
     assert tr.graphed
     first = tr.train_epoch()
