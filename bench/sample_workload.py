@@ -5,9 +5,11 @@ Same data shape ([1000, 50, 10] -> [1000], 80/20 split), model family, search sp
 5 epochs x 25 steps per trial as /root/reference/ray-tune-hpo-regression-sample.py:28-55,60-83,110,140-147
 (10 trials there, sequential CPU: 57.7 s = 624 trials/hour on an 8-vCPU box).  Differences, all on purpose:
 one report per epoch (so ASHA is live), a learnable target unless --noise-target, and on a GPU the
-graph-replayed training path.  ``--concurrent`` trials share the GPU (each on its own stream).
+graph-replayed training path.  ``--concurrent`` trials share the GPU (each on its own stream).  ``--packed K`` runs
+the search through the packed executor instead: K trials resident at a time, each with its own captured step,
+replayed round-robin over a few HIP streams by one host thread (``packed/engine_graph.py``).
 
-    python bench/sample_workload.py [--num-samples 10] [--concurrent 1] [--device cuda|cpu] [--no-asha]
+    python bench/sample_workload.py [--num-samples 10] [--concurrent 1] [--device cuda|cpu] [--no-asha] [--packed K]
 """
 import argparse
 import json
@@ -37,12 +39,27 @@ def main():
     ap.add_argument("--noise-target", action="store_true")
     ap.add_argument("--warm", type=int, default=1, help="untimed trials first (library load, allocator warm-up)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--packed", type=int, default=0, help="trial slots of the packed executor (0: one function trial at a time)")
+    ap.add_argument("--streams", type=int, default=4)
     args = ap.parse_args()
     tl, vl = create_dummy_data(learnable=not args.noise_target)
     space = dict(SAMPLE_SPACE, device=args.device, hip_graph=not args.no_graph)
     res = {"cpu": 1, "gpu": 1.0 / args.concurrent} if args.device == "cuda" else {"cpu": 1}
 
+    def packed_search(n, seed):
+        from mitune.packed import PackedTrainable
+        Xt, yt = tl.dataset.tensors
+        Xv, yv = vl.dataset.tensors
+        tr = PackedTrainable(model="simple_transformer", train=(Xt, yt), val=(Xv, yv), max_epochs=5, dtype="f32",
+                             capacity=args.packed, name="sample_packed",
+                             model_kwargs={"batch_size": 32, "optimizer": "adamw", "streams": args.streams})
+        sched = FIFOScheduler() if args.no_asha else ASHAScheduler(metric="validation_loss", mode="min", max_t=5)
+        return tune.run(tr, config=SAMPLE_SPACE, num_samples=n, scheduler=sched, local_dir=None, verbose=0, seed=seed,
+                        metric="validation_loss", mode="min", device=torch.device(args.device))
+
     def search(n, seed):
+        if args.packed:
+            return packed_search(n, seed)
         sched = FIFOScheduler() if args.no_asha else ASHAScheduler(metric="validation_loss", mode="min", max_t=5)
         return tune.run(tune.with_parameters(train_dummy_model, data_loader=tl, val_loader=vl, epochs=5), config=space,
                         num_samples=n, scheduler=sched, resources_per_trial=res, max_concurrent_trials=args.concurrent,
@@ -59,7 +76,7 @@ def main():
     el = time.perf_counter() - t0
     per = sorted(t.last_result.get("time_total_s", 0.0) for t in an.trials)
     print(json.dumps({"workload": "sample-transformer-search", "device": args.device, "trials": len(an.trials),
-                      "concurrent": args.concurrent, "asha": not args.no_asha, "graphed": not args.no_graph,
+                      "concurrent": args.concurrent, "packed_slots": args.packed, "streams": args.streams, "asha": not args.no_asha, "graphed": not args.no_graph,
                       "elapsed_s": el, "trials_per_hour": len(an.trials) / el * 3600.0,
                       "best_validation_loss": an.best_result["validation_loss"],
                       "trial_seconds_min_med_max": [per[0], per[len(per) // 2], per[-1]],

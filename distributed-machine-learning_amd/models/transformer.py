@@ -35,7 +35,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops.attention import self_attention
+from ..ops.attention import self_attention, self_attention_qkv
 from ..ops.elementwise import depthwise_conv1d, dropout, pe_add_dropout
 from ..ops.head_mlp import head_mlp
 from ..ops.layernorm import residual_layer_norm
@@ -96,10 +96,12 @@ class SelfAttention(nn.Module):
         self.h = num_heads
         self.dv = d_model // num_heads
         self.dk = max(1, int(round(self.dv * key_dim_scaling)))
-        self.qk_proj = nn.Linear(d_model, 2 * self.h * self.dk)
-        self.v_proj = nn.Linear(d_model, d_model)
+        # one projection for queries, keys and values: [all q | all k | all v], each block head-major
+        self.qkv_proj = nn.Linear(d_model, 2 * self.h * self.dk + d_model)
         self.out_proj = nn.Linear(d_model, d_model)
         self.p = dropout
+
+    mixes_values = False
 
     def _mix(self, v: torch.Tensor) -> torch.Tensor:
         return v
@@ -107,9 +109,13 @@ class SelfAttention(nn.Module):
     def forward(self, query: torch.Tensor, key: Optional[torch.Tensor] = None, value: Optional[torch.Tensor] = None
                 ) -> Tuple[torch.Tensor, None]:
         x = query                                  # self-attention: key/value arguments are accepted, not used
-        qk = linear(x, self.qk_proj.weight, self.qk_proj.bias)           # [B, S, 2*h*dk]: queries then keys, head-major
-        v = self._mix(linear(x, self.v_proj.weight, self.v_proj.bias))
-        o = self_attention(qk, v, self.h, kind=self.kind, dropout_p=self.p if self.training else 0.0)
+        qkv = linear(x, self.qkv_proj.weight, self.qkv_proj.bias)        # [B, S, 2*h*dk + d_model]
+        p = self.p if self.training else 0.0
+        if self.mixes_values:
+            qk, v = qkv.split([2 * self.h * self.dk, self.h * self.dv], dim=-1)
+            o = self_attention(qk, self._mix(v), self.h, kind=self.kind, dropout_p=p)
+        else:
+            o = self_attention_qkv(qkv, self.h, self.dk, kind=self.kind, dropout_p=p)
         return linear(o, self.out_proj.weight, self.out_proj.bias), None
 
 
@@ -124,6 +130,7 @@ class LinearAttention(SelfAttention):
         self.kernel_size = kernel_size
         self.local = (nn.Conv1d(d_model, d_model, kernel_size, padding=kernel_size // 2, groups=d_model)
                       if kernel_size and kernel_size > 1 else None)
+        self.mixes_values = self.local is not None
 
     def _mix(self, v: torch.Tensor) -> torch.Tensor:
         if self.local is None:
@@ -204,6 +211,25 @@ class TransformerModel(nn.Module):
         self.fc4 = nn.Linear(32, 16)
         self.fc5 = nn.Linear(16, 1)
 
+    @classmethod
+    def from_config(cls, config, input_size: int) -> "TransformerModel":
+        """Model of one trial of the full search space (/root/reference/ray-tune-hpo-regression.py:266-284); a head
+        count that does not divide ``d_model`` is lowered to the largest divisor among the sampled values."""
+        d_model = int(config["d_model"])
+        heads = int(config.get("num_heads", 4))
+        if d_model % heads:
+            heads = max(h for h in (1, 2, 4, 8, 16, 32) if d_model % h == 0 and h <= heads)
+        return cls(input_size=input_size, num_heads=heads,
+                   num_encoder_layers=int(config.get("num_encoder_layers", config.get("num_layers", 2))),
+                   d_model=d_model, dim_feedforward=int(config.get("dim_feedforward", 4 * d_model)),
+                   dropout=float(config.get("dropout", 0.1)), max_seq_length=int(config.get("max_seq_length", 512)),
+                   attention_type=config.get("attention_type", "scaled_dot_product"),
+                   attn_kernel_size=int(config.get("attn_kernel_size", 3)),
+                   depthwise_separable_conv=bool(config.get("depthwise_separable_conv", False)),
+                   key_dim_scaling=float(config.get("key_dim_scaling", 1.0)),
+                   shared_weights=bool(config.get("shared_weights", False)),
+                   stochastic_depth_rate=float(config.get("stochastic_depth_rate", 0.0)))
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = self.positional_encoding(self.input_projection(x))
         for i in range(self.num_encoder_layers):
@@ -242,6 +268,12 @@ class SimpleTransformerModel(nn.Module):
         self.transformer = nn.ModuleList(_PostNormLayer(d_model, num_heads, 4 * d_model, dropout)
                                          for _ in range(num_layers))
         self.fc = nn.Linear(d_model, 1)
+
+    @classmethod
+    def from_config(cls, config, input_size: int) -> "SimpleTransformerModel":
+        """Model of one trial of the sample search space (/root/reference/ray-tune-hpo-regression-sample.py:94-99)."""
+        return cls(input_size, int(config["d_model"]), int(config["num_heads"]), int(config["num_layers"]),
+                   float(config.get("dropout", 0.1)))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = self.input_projection(x)

@@ -65,6 +65,31 @@ def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kind: str
     return attention_reference(q, k, v, kind, keep, dropout_p)
 
 
+def _kernel_envelope(t: torch.Tensor, S: int, dk: int, dv: int) -> bool:
+    return (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and S <= MAX_SEQ and 0 < dk <= MAX_HEAD_DIM
+            and 0 < dv <= MAX_HEAD_DIM and dk % 8 == 0 and dv % 8 == 0)
+
+
+def self_attention_qkv(qkv: torch.Tensor, num_heads: int, dk: int, kind: str = "softmax",
+                       dropout_p: float = 0.0) -> torch.Tensor:
+    """Multi-head self-attention on ONE fused projection output ``qkv`` [B, S, 2*h*dk + h*dv]: all queries, all keys,
+    all values, each block head-major.  On a GPU the kernels read the three blocks in place and return one gradient
+    tensor for the projection; elsewhere the blocks are split and ``self_attention`` runs."""
+    B, S, W = qkv.shape
+    h = num_heads
+    dv = (W - 2 * h * dk) // h
+    if _kernel_envelope(qkv, S, dk, dv) and W % 8 == 0:
+        from .attention_hip import FusedQKVAttention, available
+        if available():
+            seed = None
+            if dropout_p > 0.0:
+                from .rng import next_seed
+                seed = next_seed(qkv.device)
+            return FusedQKVAttention.apply(qkv, h, dk, kind, dropout_p, seed)
+    qk, v = qkv.split([2 * h * dk, h * dv], dim=-1)
+    return self_attention(qk, v, h, kind, dropout_p)
+
+
 def self_attention(qk: torch.Tensor, v: torch.Tensor, num_heads: int, kind: str = "softmax",
                    dropout_p: float = 0.0) -> torch.Tensor:
     """Multi-head self-attention on projection outputs: ``qk`` [B, S, 2*h*dk] (all queries, then all keys, head-major),
@@ -73,8 +98,7 @@ def self_attention(qk: torch.Tensor, v: torch.Tensor, num_heads: int, kind: str 
     B, S, w2 = qk.shape
     h = num_heads
     dk, dv = w2 // (2 * h), v.shape[-1] // h
-    if (qk.is_cuda and qk.dtype in (torch.float32, torch.bfloat16) and S <= MAX_SEQ and dk <= MAX_HEAD_DIM
-            and dv <= MAX_HEAD_DIM and dk % 8 == 0 and dv % 8 == 0):
+    if _kernel_envelope(qk, S, dk, dv):
         from .attention_hip import FusedSelfAttention, available
         if available():
             seed = None

@@ -59,6 +59,54 @@ class FusedShortAttention(torch.autograd.Function):
         return dq.to(qd), dk_.to(kd), dv_.to(vd), None, None, None
 
 
+class FusedQKVAttention(torch.autograd.Function):
+    """Attention on ONE fused projection output ``qkv`` [B, S, 2*h*dk + h*dv] (all queries, all keys, all values, each
+    head-major) -> [B, S, h*dv].  The kernels read the three column blocks in place and the backward writes one
+    gradient tensor of the same layout, so the projection is a single GEMM in each direction."""
+
+    @staticmethod
+    def forward(ctx, qkv, h: int, dk: int, kind: str, dropout_p: float, seed: Optional[torch.Tensor] = None):
+        so = L.load()
+        qkv = qkv.contiguous()
+        B, S, W = qkv.shape
+        dv = (W - 2 * h * dk) // h
+        f32 = 1 if qkv.dtype == torch.float32 else 0
+        es = qkv.element_size()
+        out = torch.empty(B, S, h * dv, device=qkv.device, dtype=qkv.dtype)
+        stat = torch.empty(B * h, S, device=qkv.device, dtype=torch.float32)
+        scale = 1.0 / math.sqrt(dk)
+        drops = seed is not None and dropout_p > 0.0
+        keep_scale = 1.0 / (1.0 - dropout_p) if drops else 1.0
+        seed = seed if drops else None
+        base = qkv.data_ptr()
+        L.check(so.mt_attn_fwd_strided_launch(base, base + h * dk * es, base + 2 * h * dk * es, None, out.data_ptr(),
+                                              stat.data_ptr(), B * h, S, dk, dv, scale, keep_scale, _KIND[kind], h,
+                                              W, W, h * dv, f32, seed.data_ptr() if seed is not None else None,
+                                              float(dropout_p), torch.cuda.current_stream(qkv.device).cuda_stream),
+                "mt_attn_fwd_strided_launch")
+        ctx.save_for_backward(qkv, stat)
+        ctx.meta = (h, dk, dv, kind, scale, keep_scale, f32)
+        ctx.seed, ctx.p = seed, float(dropout_p)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        so = L.load()
+        qkv, stat = ctx.saved_tensors
+        h, dk, dv, kind, scale, keep_scale, f32 = ctx.meta
+        B, S, W = qkv.shape
+        es = qkv.element_size()
+        do = grad_out.to(qkv.dtype).contiguous()
+        dqkv = torch.empty(B, S, W, device=qkv.device, dtype=torch.float32)
+        base, g = qkv.data_ptr(), dqkv.data_ptr()
+        L.check(so.mt_attn_bwd_strided_launch(base, base + h * dk * es, base + 2 * h * dk * es, do.data_ptr(), None,
+                                              stat.data_ptr(), g, g + h * dk * 4, g + 2 * h * dk * 4, B * h, S, dk, dv,
+                                              scale, keep_scale, _KIND[kind], h, W, W, h * dv, f32,
+                                              ctx.seed.data_ptr() if ctx.seed is not None else None, ctx.p,
+                                              torch.cuda.current_stream(qkv.device).cuda_stream), "mt_attn_bwd_strided_launch")
+        return dqkv.to(qkv.dtype), None, None, None, None, None
+
+
 class FusedSelfAttention(torch.autograd.Function):
     """Attention straight on projection outputs: ``qk`` [B, S, 2*h*dk] (queries then keys, head-major), ``v`` [B, S, h*dv]
     -> [B, S, h*dv].  f32 or bf16; no head split / merge copies, no dtype casts: the kernels read the strided operands
@@ -70,7 +118,7 @@ class FusedSelfAttention(torch.autograd.Function):
         so = L.load()
         if v.dtype != qk.dtype:
             v = v.to(qk.dtype)
-        qk, v = qk.contiguous(), v.contiguous()
+        qk, v = qk.contiguous(), v.contiguous()      # a column slice of a fused projection is copied here
         B, S, w2 = qk.shape
         dk, dv = w2 // (2 * h), v.shape[-1] // h
         f32 = 1 if qk.dtype == torch.float32 else 0

@@ -1,41 +1,111 @@
 """Device-resident random state for dropout on the GPU.
 
-One int64 counter per device.  Every dropout site bumps it (an in-place add, stream-ordered and capturable in a
-hipGraph) and takes a snapshot as its seed; the kernels of ``csrc/dropout.hip`` / ``csrc/posenc.hip`` hash
-``(seed, element index)``.  Because the counter lives on the device and is advanced *by the captured work itself*,
-a replayed training step draws new masks every time, and nothing depends on the framework's generator (whose
-graph-registered Philox state misbehaved here once three or more captured graphs were alive).
+A ``Counter`` is an int64 on the device plus a table of the next ``TABLE`` seeds derived from it.  A dropout site
+takes the next table entry as its seed (a view: no launch); when the table is used up -- and at the start of every
+training step, see ``begin_step`` -- two small launches write a fresh table from the counter and advance the
+counter.  The kernels of ``csrc/dropout.hip`` / ``csrc/posenc.hip`` / attention / LayerNorm hash ``(seed, element
+index)``.  Because counter and table live on the device and are advanced *by the issued work itself*, the refill is
+capturable in a hipGraph: a replayed training step draws new masks every time, and nothing depends on the
+framework's generator (whose graph-registered Philox state misbehaved here once three or more captured graphs were
+alive).  A refill writes a *new* table tensor, so seeds saved for a backward pass stay valid.
 
-``seed_all(value)`` pins the counter, e.g. to a function of (experiment seed, trial, epoch), which makes a trial's
-masks independent of which other trials share the GPU.
+Every thread has a default counter per device.  A trainer that runs next to others (several trials' graphs replayed
+on different streams) owns a counter and makes it current with ``scope(counter)`` around every forward it issues --
+captured work then holds *that* counter's addresses, concurrent trials never race on a shared seed, and a trial's
+masks do not depend on what else shares the GPU.  ``seed_all(value)`` / ``Counter.seed(value)`` pin a counter,
+e.g. to a function of (experiment seed, trial, epoch).
+
+A region captured into a graph must start with ``begin_step()`` (``GraphedTrainer`` does): the refill is then part
+of the graph, and replays do not reuse the table of the capture.
 """
 from __future__ import annotations
 
-from typing import Dict
+import contextlib
+import threading
+from typing import Dict, Optional
 
 import torch
 
-_CTR: Dict[torch.device, torch.Tensor] = {}
-_STRIDE = 0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF       # odd: successive seeds differ in many bits
+TABLE = 32                                              # seeds per refill; a training step of the zoo draws 5..30
+_STRIDE = 0x9E3779B97F4A7C15                            # odd: successive seeds differ in many bits
+_tls = threading.local()
 
 
-def counter(device) -> torch.Tensor:
+def _i64(v: int) -> int:
+    v &= 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+class Counter:
+    __slots__ = ("ctr", "table", "idx", "_steps")
+
+    def __init__(self, device, value: int = 0x1234567):
+        self.ctr = torch.full((1,), _i64(value), dtype=torch.int64, device=device)
+        self._steps = torch.tensor([_i64((i + 1) * _STRIDE) for i in range(TABLE)], dtype=torch.int64, device=device)
+        self.table: Optional[torch.Tensor] = None
+        self.idx = TABLE
+
+    def seed(self, value: int) -> None:
+        """Pin the counter (stream-ordered); the next draw starts a fresh table."""
+        self.ctr.fill_(_i64(value))
+        self.idx = TABLE
+
+    def begin_step(self) -> None:
+        self.idx = TABLE
+
+    def next(self) -> torch.Tensor:
+        """Seed for one dropout site: a [1] int64 view that stays valid for the backward pass."""
+        if self.idx >= TABLE:
+            self.table = self.ctr + self._steps          # wraps modulo 2^64
+            self.ctr.add_(_i64(TABLE * _STRIDE))
+            self.idx = 0
+        s = self.table[self.idx:self.idx + 1]
+        self.idx += 1
+        return s
+
+
+def new_counter(device, value: int = 0x1234567) -> Counter:
+    return Counter(device, value)
+
+
+def counter(device) -> Counter:
+    cur: Optional[Counter] = getattr(_tls, "cur", None)
+    if cur is not None:
+        return cur
     device = torch.device(device)
     if device.index is None and device.type == "cuda":
         device = torch.device("cuda", torch.cuda.current_device())
-    t = _CTR.get(device)
-    if t is None:
-        t = torch.full((1,), 0x1234567, dtype=torch.int64, device=device)
-        _CTR[device] = t
-    return t
+    table: Optional[Dict[torch.device, Counter]] = getattr(_tls, "default", None)
+    if table is None:
+        table = _tls.default = {}
+    c = table.get(device)
+    if c is None:
+        main = threading.current_thread() is threading.main_thread()
+        c = table[device] = Counter(device, 0x1234567 if main else 0x1234567 + threading.get_ident() * 0x51ED27)
+    return c
+
+
+@contextlib.contextmanager
+def scope(ctr: Optional[Counter]):
+    """Make ``ctr`` the counter every dropout site of this thread uses (None: leave the current one in place)."""
+    if ctr is None:
+        yield
+        return
+    prev = getattr(_tls, "cur", None)
+    _tls.cur = ctr
+    try:
+        yield
+    finally:
+        _tls.cur = prev
 
 
 def seed_all(value: int, device="cuda") -> None:
-    counter(device).fill_(int(value) & 0x7FFFFFFFFFFFFFFF)
+    counter(device).seed(value)
+
+
+def begin_step(device="cuda") -> None:
+    counter(device).begin_step()
 
 
 def next_seed(device) -> torch.Tensor:
-    """Advance the device counter and return a snapshot [1] int64 that stays valid for a backward pass."""
-    c = counter(device)
-    c.add_(_STRIDE)            # wraps modulo 2^64
-    return c.clone()
+    return counter(device).next()

@@ -29,6 +29,9 @@ from ..train.losses import MAPE_EPS, get_criterion
 from ..train.optim import build_optimizer
 
 
+MODEL_FAMILIES = ("mlp", "ft_transformer", "transformer", "simple_transformer")
+
+
 class PackEngine:
     """Interface; slots are integers in ``[0, capacity)``."""
 
@@ -74,8 +77,8 @@ class TorchPackEngine(PackEngine):
 
     def __init__(self, trainable: PackedTrainable, device: str = "cpu", capacity: Optional[int] = None,
                  seed: int = 0):
-        if not (trainable.model in ("mlp", "ft_transformer") or callable(trainable.model)):
-            raise ValueError("model must be 'mlp', 'ft_transformer' or a factory fn(config, in_features) -> nn.Module")
+        if not (trainable.model in MODEL_FAMILIES or callable(trainable.model)):
+            raise ValueError(f"model must be one of {MODEL_FAMILIES} or a factory fn(config, in_features) -> nn.Module")
         self.t = trainable
         self.device = torch.device(device)
         self.capacity = int(capacity or trainable.capacity or 64)
@@ -96,6 +99,10 @@ class TorchPackEngine(PackEngine):
     def occupied(self) -> List[int]:
         return sorted(self.slots)
 
+    def _spec(self, config: Dict) -> MLPTrialSpec:
+        """Optimiser/batch/loss settings of a trial; ``model_kwargs`` supplies what the search space leaves fixed."""
+        return MLPTrialSpec.from_config({**self.t.model_kwargs, **config}, self.t.in_features)
+
     def _build(self, spec: MLPTrialSpec, config: Dict, trial_index: int = 0):
         if self.t.model == "mlp":
             model = MLPRegressor(spec.in_features, spec.hidden_sizes)
@@ -103,9 +110,16 @@ class TorchPackEngine(PackEngine):
             # weights drawn from the trial's own stream, so a trial's start does not depend on its slot
             with torch.random.fork_rng(devices=[]):
                 torch.manual_seed((self.seed * 1_000_003 + int(trial_index)) * 16 + 7)
+                merged = {**self.t.model_kwargs, **config}
                 if self.t.model == "ft_transformer":
                     from ..models.ft_transformer import FTTransformer
-                    model = FTTransformer.from_config({**self.t.model_kwargs, **config}, spec.in_features)
+                    model = FTTransformer.from_config(merged, spec.in_features)
+                elif self.t.model == "transformer":         # the reference's full sequence regressor
+                    from ..models.transformer import TransformerModel
+                    model = TransformerModel.from_config(merged, spec.in_features)
+                elif self.t.model == "simple_transformer":  # the reference's sample model
+                    from ..models.transformer import SimpleTransformerModel
+                    model = SimpleTransformerModel.from_config(merged, spec.in_features)
                 else:
                     model = self.t.model(config, spec.in_features)
         model = model.to(self.device)
@@ -116,7 +130,7 @@ class TorchPackEngine(PackEngine):
     def load(self, slot, trial_index, config, state=None):
         if slot in self.slots:
             raise RuntimeError(f"slot {slot} is occupied")
-        spec = MLPTrialSpec.from_config(config, self.t.in_features)
+        spec = self._spec(config)
         s = _Slot()
         s.trial_index, s.spec, s.config = int(trial_index), spec, dict(config)
         s.model, s.opt = self._build(spec, config, trial_index)
@@ -183,7 +197,7 @@ class TorchPackEngine(PackEngine):
             s.opt.zero_grad(set_to_none=True)
             with self._autocast():
                 out = s.model(self.Xtr[idx])
-            loss = crit(out.float(), self.ytr[idx])
+            loss = crit(out.float().reshape(idx.shape[0]), self.ytr[idx])
             loss.backward()
             if s.spec.gradient_clipping > 0:
                 torch.nn.utils.clip_grad_norm_(s.model.parameters(), s.spec.gradient_clipping)
@@ -213,7 +227,7 @@ class TorchPackEngine(PackEngine):
                 x, y = self.Xva[c0:c0 + self.t.val_chunk], self.yva[c0:c0 + self.t.val_chunk]
                 with self._autocast():
                     o = s.model(x)
-                o = o.float()
+                o = o.float().reshape(y.shape)
                 se += ((o - y) ** 2).sum().double()
                 ape += ((o - y).abs() / (y.abs() + MAPE_EPS)).sum().double()
                 ls += elementwise_loss(crit, o, y).sum().double()

@@ -8,12 +8,26 @@ live in one flat slab, the optimiser is the fused device-state kernel, and a slo
 captured once and replayed for every batch of every epoch (``train/graphed.py``).  Row order stays the keyed
 Feistel permutation of ``(seed, trial_index, epoch)``, so a trial's data order does not depend on its slot or GPU.
 
+Slots do not wait for each other: one host thread issues the slots' graph replays round-robin over a few HIP
+streams, so the small kernels of several trials are in flight at once (measured on one MI355X with the sample
+Transformer, 25 steps x 4 trials: 65 ms replayed back to back on one stream, 21 ms on four streams; more hardware
+queues than the runtime's default four made it slower, not faster).  Every slot owns its dropout counter, its
+cursor and its loss accumulator, so the interleaving changes no trial's numbers.  Validation of all slots is
+issued the same way and read back with one synchronisation.
+
+Concurrent issue is confined to the regime it was built for and verified in: f32 models whose step touches at most
+``SMALL_STEP_ROWS`` token rows (launch-latency-bound kernels of a few workgroups each).  Packs outside it -- bf16
+autocast, or long token dimensions whose library GEMMs fill the chip on their own -- are issued on one stream, slot
+after slot: there overlap has nothing to win, and three FT-Transformer slots (bf16, 66 560 token rows per step)
+issued over several streams never completed on the test machine.
+
 PBT exploits inside a pack are slab-to-slab copies (weights + both moment slabs + step counter); the captured graph
 of the receiving slot stays valid because it only holds pointers.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+import os
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
@@ -23,7 +37,10 @@ from .permutation import permute, round_keys
 from ..models.mlp import MLPTrialSpec, init_mlp_state
 from ..ops import rng
 from ..train.graphed import FlatOptimizer, FlatParams, GraphedTrainer
-from ..train.losses import get_criterion
+from ..train.losses import MAPE_EPS, elementwise_loss, get_criterion
+
+DEFAULT_STREAMS = 4      # the HIP runtime's default number of hardware queues per process
+SMALL_STEP_ROWS = 4096   # batch x tokens up to which slots are issued concurrently
 
 
 class GraphPackEngine(TorchPackEngine):
@@ -34,12 +51,14 @@ class GraphPackEngine(TorchPackEngine):
         if self.device.type != "cuda":
             raise ValueError("GraphPackEngine needs a GPU; use engine='torch' on the CPU")
         self._trainers: Dict[int, GraphedTrainer] = {}
+        n = int(trainable.model_kwargs.get("streams", os.environ.get("MITUNE_GRAPH_STREAMS", DEFAULT_STREAMS)))
+        self._streams: List[torch.cuda.Stream] = [torch.cuda.Stream(self.device) for _ in range(max(1, min(n, 32)))]
 
     # ------------------------------------------------------------------ slot management
     def load(self, slot, trial_index, config, state=None):
         if slot in self.slots:
             raise RuntimeError(f"slot {slot} is occupied")
-        spec = MLPTrialSpec.from_config(config, self.t.in_features)
+        spec = self._spec(config)
         s = _Slot()
         s.trial_index, s.spec, s.config = int(trial_index), spec, dict(config)
         model, _ = self._build(spec, config, trial_index)
@@ -76,7 +95,7 @@ class GraphPackEngine(TorchPackEngine):
 
     def clone(self, src, dst, config):
         a, b = self.slots[src], self.slots[dst]
-        if a.opt.flat.n != b.opt.flat.n or a.opt.name != MLPTrialSpec.from_config(config, self.t.in_features).optimizer:
+        if a.opt.flat.n != b.opt.flat.n or a.opt.name != self._spec(config).optimizer:
             return super().clone(src, dst, config)       # shapes differ: go through a state_dict
         with torch.no_grad():
             b.opt.flat.P.copy_(a.opt.flat.P)
@@ -85,7 +104,7 @@ class GraphPackEngine(TorchPackEngine):
             b.opt._i32[b.opt._STEP:b.opt._STEP + 1].copy_(a.opt._i32[a.opt._STEP:a.opt._STEP + 1])
             for (_, bb), (_, ab) in zip(b.model.named_buffers(), a.model.named_buffers()):
                 bb.copy_(ab)
-        b.spec, b.config = MLPTrialSpec.from_config(config, self.t.in_features), dict(config)
+        b.spec, b.config = self._spec(config), dict(config)
         b.epoch, b.step = a.epoch, a.step
         self._apply_hparams(b)
 
@@ -94,19 +113,92 @@ class GraphPackEngine(TorchPackEngine):
         s.opt.set_hyper(s.spec.learning_rate, s.spec.weight_decay)
 
     # ------------------------------------------------------------------ training
-    def _train_slot_epoch(self, s: _Slot, slot: Optional[int] = None) -> None:
-        tr = self._trainers[slot]
-        n = self.Xtr.shape[0]
-        steps = n // tr.B
-        keys = round_keys(self.seed, s.trial_index, s.epoch)
-        perm = permute(np.arange(steps * tr.B, dtype=np.uint32), n, keys).astype(np.int64)
-        tr.perm[:steps * tr.B].copy_(torch.from_numpy(perm))      # blocking: the host array dies with this frame
-        # dropout draws of this epoch depend on (seed, trial, epoch) only, never on the slot or on neighbours
-        rng.seed_all(((self.seed * 1_000_003 + s.trial_index) * 4099 + s.epoch) * 0x2545F491 + 77, self.device)
-        s.train_loss = tr.train_epoch()
-        s.step += steps
-        s.epoch += 1
+    def _slot_seed(self, s: _Slot) -> int:
+        # dropout draws of an epoch depend on (seed, trial, epoch) only, never on the slot or on neighbours
+        return ((self.seed * 1_000_003 + s.trial_index) * 4099 + s.epoch) * 0x2545F491 + 77
+
+    def _tokens_per_sample(self) -> int:
+        X = self.Xtr
+        return int(X.shape[1]) if X.dim() >= 2 else 1       # sequence length, or one token per tabular feature
+
+    def _issue_streams(self, order, samples_per_launch: int, bound: int = SMALL_STEP_ROWS) -> List[torch.cuda.Stream]:
+        """Streams the slots in ``order`` are spread over: several only in the small-kernel f32 regime."""
+        small = samples_per_launch * self._tokens_per_sample() <= bound
+        if self.amp or not small or len(self._streams) < 2 or len(order) < 2:
+            return [torch.cuda.current_stream(self.device)]
+        return self._streams
+
+    def _fan_out(self, streams):
+        cur = torch.cuda.current_stream(self.device)
+        for st in streams:
+            if st != cur:
+                st.wait_stream(cur)
+        return cur
+
+    @staticmethod
+    def _fan_in(cur, streams) -> None:
+        for st in streams:
+            if st != cur:
+                cur.wait_stream(st)
 
     def train_epoch(self):
-        for slot in self.occupied():
-            self._train_slot_epoch(self.slots[slot], slot)
+        order = self.occupied()
+        if not order:
+            return
+        n = self.Xtr.shape[0]
+        plan = []
+        for slot in order:
+            s, tr = self.slots[slot], self._trainers[slot]
+            steps = n // tr.B
+            keys = round_keys(self.seed, s.trial_index, s.epoch)
+            perm = permute(np.arange(steps * tr.B, dtype=np.uint32), n, keys).astype(np.int64)
+            tr.perm[:steps * tr.B].copy_(torch.from_numpy(perm))      # blocking: the host array dies with this frame
+            tr.seed(self._slot_seed(s))
+            plan.append((s, tr, tr.begin_epoch()))
+        streams = self._issue_streams(order, max(tr.B for _, tr, _ in plan))
+        cur = self._fan_out(streams)
+        ns = len(streams)
+        if ns == 1:                                   # slot after slot: a slot's working set stays in cache
+            for _, tr, batches in plan:
+                for i in range(batches):
+                    tr.step_once(i)
+        else:
+            for i in range(max(b for _, _, b in plan)):
+                for j, (_, tr, batches) in enumerate(plan):
+                    if i < batches:
+                        with torch.cuda.stream(streams[j % ns]):
+                            tr.step_once(i)
+        self._fan_in(cur, streams)
+        losses = torch.stack([tr.epoch_loss(b) for _, tr, b in plan]).tolist()        # one synchronisation
+        for (s, tr, batches), loss in zip(plan, losses):
+            s.train_loss = loss
+            s.step += batches
+            s.epoch += 1
+
+    @torch.no_grad()
+    def evaluate(self):
+        order = self.occupied()
+        if not order:
+            return {}
+        n = self.Xva.shape[0]
+        acc = torch.zeros(len(order), 3, device=self.device, dtype=torch.float64)      # loss, squared error, APE sums
+        streams = self._issue_streams(order, min(n, self.t.val_chunk), 4 * SMALL_STEP_ROWS)
+        cur = self._fan_out(streams)
+        ns = len(streams)
+        for j, slot in enumerate(order):
+            s = self.slots[slot]
+            s.model.eval()
+            with torch.cuda.stream(streams[j % ns]):
+                for c0 in range(0, n, self.t.val_chunk):
+                    x, y = self.Xva[c0:c0 + self.t.val_chunk], self.yva[c0:c0 + self.t.val_chunk]
+                    with self._autocast():
+                        o = s.model(x)
+                    o = o.float().reshape(y.shape)
+                    d = o - y
+                    acc[j] += torch.stack([elementwise_loss(s.spec.loss_function, o, y).sum(), (d * d).sum(),
+                                           (d.abs() / (y.abs() + MAPE_EPS)).sum()]).double()
+        self._fan_in(cur, streams)
+        rows = acc.tolist()                                                            # one synchronisation
+        return {slot: {"train_loss": self.slots[slot].train_loss, "validation_loss": r[0] / n,
+                       "validation_mse": r[1] / n, "validation_mape": 100.0 * r[2] / n}
+                for slot, r in zip(order, rows)}

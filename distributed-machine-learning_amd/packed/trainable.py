@@ -17,8 +17,8 @@ import torch
 
 @dataclass
 class PackedTrainable:
-    model: str = "mlp"                                   # "mlp" | "ft_transformer"
-    train: Tuple[torch.Tensor, torch.Tensor] = None      # (X [N, F], y [N])
+    model: str = "mlp"               # "mlp" | "ft_transformer" | "transformer" | "simple_transformer" | factory
+    train: Tuple[torch.Tensor, torch.Tensor] = None      # (X [N, F] or sequences [N, S, F], y [N])
     val: Tuple[torch.Tensor, torch.Tensor] = None
     max_epochs: int = 16                                 # a trial that is never stopped ends here
     engine: str = "auto"                                 # "auto" | "torch" | "hip" | "graph"
@@ -36,14 +36,16 @@ class PackedTrainable:
         if self.train is None or self.val is None:
             raise ValueError("PackedTrainable needs train=(X, y) and val=(X, y)")
         for X, y in (self.train, self.val):
-            if X.dim() != 2 or y.dim() != 1 or X.shape[0] != y.shape[0]:
-                raise ValueError("datasets must be X [N, F] float and y [N] float")
-        if self.train[0].shape[1] != self.val[0].shape[1]:
-            raise ValueError("train/val feature counts differ")
+            if X.dim() not in (2, 3) or y.dim() != 1 or X.shape[0] != y.shape[0]:
+                raise ValueError("datasets must be X [N, F] (or sequences [N, S, F]) float and y [N] float")
+        if self.train[0].shape[1:] != self.val[0].shape[1:]:
+            raise ValueError("train/val feature shapes differ")
+        if self.model == "mlp" and self.train[0].dim() != 2:
+            raise ValueError("the MLP family trains on tabular X [N, F]")
 
     @property
     def in_features(self) -> int:
-        return int(self.train[0].shape[1])
+        return int(self.train[0].shape[-1])
 
     @property
     def __name__(self) -> str:      # so experiment directories read "<name>_<date>"

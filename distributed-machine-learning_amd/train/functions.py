@@ -163,8 +163,7 @@ def _rebatch(loader, batch_size: Optional[int], shuffle: bool):
 def train_dummy_model(config: Dict, data_loader, val_loader, epochs: int = 5) -> None:
     """Sample workflow: small stock Transformer, AdamW + MSE, 5 epochs."""
     device = pick_device(config)
-    model = SimpleTransformerModel(_infer_input_size(data_loader), config["d_model"], config["num_heads"],
-                                   config["num_layers"], config.get("dropout", 0.1)).to(device)
+    model = SimpleTransformerModel.from_config(config, _infer_input_size(data_loader)).to(device)
     n_epochs = int(config.get("epochs", epochs))
     if device.type == "cuda" and _fit_graphed(model, config, data_loader, val_loader, n_epochs, torch.nn.MSELoss(), device,
                                               "adamw", config["learning_rate"], config.get("weight_decay", 0.0)):
@@ -180,21 +179,7 @@ def train_transformer_model(config: Dict, data_loader, val_loader, epochs: int =
     """Full workflow: configurable Transformer, 4 optimisers x 4 losses, warm-up/decay LR, gradient clipping."""
     device = pick_device(config)
     data_loader = _rebatch(data_loader, config.get("batch_size"), shuffle=True)
-    d_model = int(config["d_model"])
-    heads = int(config["num_heads"])
-    if d_model % heads:
-        heads = max(h for h in (1, 2, 4, 8, 16, 32) if d_model % h == 0 and h <= heads)
-    model = TransformerModel(
-        input_size=_infer_input_size(data_loader), num_heads=heads,
-        num_encoder_layers=int(config["num_encoder_layers"]), d_model=d_model,
-        dim_feedforward=int(config.get("dim_feedforward", 4 * d_model)), dropout=float(config.get("dropout", 0.1)),
-        max_seq_length=int(config.get("max_seq_length", 512)),
-        attention_type=config.get("attention_type", "scaled_dot_product"),
-        attn_kernel_size=int(config.get("attn_kernel_size", 3)),
-        depthwise_separable_conv=bool(config.get("depthwise_separable_conv", False)),
-        key_dim_scaling=float(config.get("key_dim_scaling", 1.0)),
-        shared_weights=bool(config.get("shared_weights", False)),
-        stochastic_depth_rate=float(config.get("stochastic_depth_rate", 0.0))).to(device)
+    model = TransformerModel.from_config(config, _infer_input_size(data_loader)).to(device)
     n_epochs = int(config.get("epochs", epochs))
     steps_per_epoch = max(1, len(data_loader))
     warm = int(config.get("warmup_steps", 0))

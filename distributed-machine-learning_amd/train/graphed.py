@@ -14,8 +14,9 @@ For models this small the GPU idles between launches.  Here:
 * forward + loss + backward + clip + update + cursor advance are captured ONCE into a hipGraph and replayed for
   every batch of every epoch (``GraphedTrainer``); the host reads one scalar per epoch.
 
-Dropout keeps drawing fresh masks under replay because every random op inside the step takes its seed/offset
-from the generator state that graph capture registers.
+Dropout keeps drawing fresh masks under replay because every random op inside the step takes its seed from a
+device-resident counter that the captured step itself advances (``ops/rng.py``); each trainer owns its counter, so
+several trainers may replay their graphs on different streams at once.
 """
 from __future__ import annotations
 
@@ -28,6 +29,7 @@ from typing import Callable, Dict, Optional
 import torch
 
 from .optim import OPT_CODES
+from ..ops import rng
 
 log = logging.getLogger("mitune")
 
@@ -208,6 +210,7 @@ class GraphedTrainer:
         self.ar = torch.arange(self.B, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int64, device=dev)
         self.running = torch.zeros((), device=dev)
+        self.rng = rng.new_counter(dev, 0x1234567 + int(seed)) if dev.type == "cuda" else None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.graphed = False
         if use_graph and not SHARED_GPU_THREADS and dev.type == "cuda" and self.N >= self.B:
@@ -224,12 +227,19 @@ class GraphedTrainer:
     def _step(self, rows: torch.Tensor) -> None:
         x = self.X.index_select(0, rows)
         y = self.Y.index_select(0, rows)
-        with self.forward_ctx():
-            out = self.model(x)
-        loss = self.criterion(out.float().reshape(y.shape), y)
-        loss.backward()
+        with rng.scope(self.rng):
+            rng.begin_step(x.device)          # the seed table is refilled inside the (captured) step
+            with self.forward_ctx():
+                out = self.model(x)
+            loss = self.criterion(out.float().reshape(y.shape), y)
+            loss.backward()
         self.opt.step()
         self.running += loss.detach()
+
+    def seed(self, value: int) -> None:
+        """Pin this trainer's dropout counter (stream-ordered)."""
+        if self.rng is not None:
+            self.rng.seed(value)
 
     def _cursor_step(self) -> None:
         self._step(self.perm.index_select(0, self.ar + self.pos))
@@ -237,7 +247,7 @@ class GraphedTrainer:
 
     def _capture(self) -> None:
         f, o = self.opt.flat, self.opt
-        keep = (f.P.clone(), o.M.clone(), o.V.clone(), o.state.clone())
+        keep = (f.P.clone(), o.M.clone(), o.V.clone(), o.state.clone(), None if self.rng is None else self.rng.ctr.clone())
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -250,6 +260,8 @@ class GraphedTrainer:
         with torch.no_grad():                  # undo the warm-up steps: training starts from the initial weights
             f.P.copy_(keep[0]); o.M.copy_(keep[1]); o.V.copy_(keep[2]); o.state.copy_(keep[3])
             o.zero_grad(); self.pos.zero_(); self.running.zero_()
+            if self.rng is not None:
+                self.rng.ctr.copy_(keep[4])
         cur.synchronize()                      # stream-level only: a device-wide wait would disturb other threads
         g = torch.cuda.CUDAGraph()
         # Raw capture_begin / capture_end on the warm-up stream: the torch.cuda.graph context would first synchronise the
@@ -268,24 +280,35 @@ class GraphedTrainer:
         self.graph = g
 
     # ------------------------------------------------------------------ epochs
-    def train_epoch(self) -> float:
+    def begin_epoch(self) -> int:
+        """Shuffle, rewind the cursor; returns how many ``step_once`` calls make up the epoch."""
         self.model.train()
         if self.shuffle:
             self.perm.copy_(torch.randperm(self.N, device=self.perm.device, generator=self.gen))
         self.pos.zero_()
         self.running.zero_()
         n_full = self.N // self.B
-        if self.graph is not None:
-            for _ in range(n_full):
-                self.graph.replay()
-        else:
-            for _ in range(n_full):
-                self._cursor_step()
-        batches = n_full
-        if self.N % self.B and not self.drop_last:
+        return n_full + (1 if self.N % self.B and not self.drop_last else 0)
+
+    def step_once(self, i: int) -> None:
+        """Step ``i`` of the epoch on the current stream: a graph replay, or the eager ragged last batch."""
+        n_full = self.N // self.B
+        if i >= n_full:
             self._step(self.perm[n_full * self.B:])
-            batches += 1
-        return float(self.running) / max(batches, 1)
+        elif self.graph is not None:
+            self.graph.replay()
+        else:
+            self._cursor_step()
+
+    def epoch_loss(self, batches: int) -> torch.Tensor:
+        """Mean batch loss of the epoch as a device scalar (no synchronisation)."""
+        return self.running / max(batches, 1)
+
+    def train_epoch(self) -> float:
+        batches = self.begin_epoch()
+        for i in range(batches):
+            self.step_once(i)
+        return float(self.epoch_loss(batches))
 
     @torch.no_grad()
     def evaluate(self, Xv: torch.Tensor, Yv: torch.Tensor, chunk: int = 4096, mape_eps: float = 1e-8) -> Dict[str, float]:

@@ -310,6 +310,75 @@ def test_many_graphs_with_dropout_and_eager_work_between_epochs_stay_finite():
         assert all(math.isfinite(v["validation_mse"]) and math.isfinite(v["train_loss"]) for v in ev.values())
 
 
+def _sequence_pack(streams, n_slots=5, epochs=2):
+    from mitune.data import create_dummy_data
+    from mitune.packed import PackedTrainable
+    from mitune.packed.engine_graph import GraphPackEngine
+    tl, vl = create_dummy_data(num_samples=400, seq_len=20, input_size=6)
+    tr = PackedTrainable(model="simple_transformer", train=tuple(tl.dataset.tensors), val=tuple(vl.dataset.tensors),
+                         max_epochs=epochs, engine="graph", dtype="f32", capacity=n_slots,
+                         model_kwargs={"batch_size": 32, "optimizer": "adamw", "streams": streams})
+    eng = GraphPackEngine(tr, DEV, n_slots, seed=3)
+    shapes = [(32, 2, 1), (64, 4, 2), (32, 4, 3), (64, 2, 1), (128, 4, 2)]
+    for i in range(n_slots):
+        d, h, L = shapes[i % len(shapes)]
+        eng.load(i, i, {"d_model": d, "num_heads": h, "num_layers": L, "dropout": 0.2, "learning_rate": 1e-3,
+                        "weight_decay": 1e-4})
+    out = []
+    for _ in range(epochs):
+        eng.train_epoch()
+        out.append(eng.evaluate())
+    return eng, out
+
+
+def test_sequence_trials_issued_over_streams_equal_issue_on_one_stream():
+    """Slots of different shapes replayed round-robin over four streams end where the same slots end when they are
+    replayed one after the other: own dropout counter, cursor and loss accumulator per slot."""
+    eng4, multi = _sequence_pack(4)
+    assert len(eng4._issue_streams(eng4.occupied(), 32)) == 4
+    eng1, single = _sequence_pack(1)
+    assert len(eng1._issue_streams(eng1.occupied(), 32)) == 1
+    for a, b in zip(multi, single):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert math.isfinite(a[k]["validation_loss"])
+            assert a[k]["validation_loss"] == pytest.approx(b[k]["validation_loss"], rel=2e-3)
+            assert a[k]["train_loss"] == pytest.approx(b[k]["train_loss"], rel=2e-3)
+    assert multi[-1][0]["validation_loss"] < multi[0][0]["validation_loss"] * 1.5
+
+
+def test_bf16_or_long_token_packs_stay_on_one_stream():
+    from mitune.data import tabular_regression
+    from mitune.packed import PackedTrainable
+    from mitune.packed.engine_graph import GraphPackEngine
+    train, val = tabular_regression(4096, 64, seed=5, device=DEV)
+    tr = PackedTrainable(model="ft_transformer", train=train, val=val, max_epochs=1, engine="graph", dtype="bf16", capacity=2,
+                         model_kwargs={"d_token": 64, "n_blocks": 1, "n_heads": 4})
+    eng = GraphPackEngine(tr, DEV, 2, seed=0)
+    cur = torch.cuda.current_stream()
+    assert eng._issue_streams([0, 1], 32) == [cur]                     # bf16 autocast
+    eng.amp = False
+    assert eng._issue_streams([0, 1], 1024) == [cur]                   # 1024 x 64 token rows per step
+    assert len(eng._issue_streams([0, 1], 32)) == 4
+
+
+def test_packed_search_over_the_sample_space_on_gpu():
+    from mitune import tune
+    from mitune.data import create_dummy_data
+    from mitune.packed import PackedTrainable
+    from mitune.schedulers import ASHAScheduler
+    tl, vl = create_dummy_data(num_samples=400, seq_len=20, input_size=6)
+    tr = PackedTrainable(model="simple_transformer", train=tuple(tl.dataset.tensors), val=tuple(vl.dataset.tensors),
+                         max_epochs=3, dtype="f32", capacity=4, model_kwargs={"batch_size": 32, "optimizer": "adamw"})
+    an = tune.run(tr, config={"d_model": tune.choice([32, 64]), "num_heads": tune.choice([2, 4]),
+                              "num_layers": tune.choice([1, 2]), "dropout": tune.uniform(0.1, 0.3),
+                              "learning_rate": tune.loguniform(1e-4, 1e-2), "weight_decay": 1e-4},
+                  num_samples=6, scheduler=ASHAScheduler(metric="validation_loss", mode="min", max_t=3),
+                  local_dir=None, verbose=0, seed=1, metric="validation_loss", mode="min", device=torch.device(DEV))
+    assert len(an.trials) == 6 and an.stats["engine"] == "graph"
+    assert math.isfinite(an.best_result["validation_loss"])
+
+
 # ------------------------------------------------------------------ split-contraction weight gradient
 @pytest.mark.parametrize("M,in_f,out_f", [(66560, 192, 576), (8192, 256, 192), (5000, 72, 40)])
 def test_split_k_linear_matches_reference(M, in_f, out_f):

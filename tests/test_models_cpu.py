@@ -114,3 +114,54 @@ def test_dummy_data_and_glucose_pipeline():
     assert xb.shape[1:] == (96, 81) and yb.dim() == 1
     n = len(tr.dataset) + len(va.dataset)
     assert len(va.dataset) == int(np.ceil(0.3 * n))
+
+
+def test_packed_sequence_family_trains_on_cpu():
+    """The packed executor takes sequence data [N, S, F] and the sample Transformer family (Torch engine on the CPU)."""
+    import math
+    from mitune import tune
+    from mitune.data import create_dummy_data
+    from mitune.packed import PackedTrainable
+    tl, vl = create_dummy_data(num_samples=96, seq_len=8, input_size=5)
+    tr = PackedTrainable(model="simple_transformer", train=tuple(tl.dataset.tensors), val=tuple(vl.dataset.tensors),
+                         max_epochs=2, dtype="f32", capacity=2, model_kwargs={"batch_size": 16, "optimizer": "adamw"})
+    assert tr.in_features == 5
+    an = tune.run(tr, config={"d_model": tune.choice([16, 32]), "num_heads": 2, "num_layers": 1, "dropout": 0.1,
+                              "learning_rate": 1e-3}, num_samples=3, local_dir=None, verbose=0, seed=0,
+                  metric="validation_loss", mode="min", device=torch.device("cpu"))
+    assert len(an.trials) == 3 and all(t.training_iteration == 2 for t in an.trials)
+    assert math.isfinite(an.best_result["validation_loss"])
+    with pytest.raises(ValueError):
+        PackedTrainable(model="mlp", train=tuple(tl.dataset.tensors), val=tuple(vl.dataset.tensors))
+
+
+def test_rng_scope_switches_the_counter():
+    from mitune.ops import rng
+    mine = rng.new_counter("cpu", 5)
+    base = rng.counter("cpu")
+    before = int(base.ctr)
+    with rng.scope(mine):
+        assert rng.counter("cpu") is mine
+        a = rng.next_seed("cpu")
+        b = rng.next_seed("cpu")
+        with rng.scope(None):
+            assert rng.counter("cpu") is mine
+    assert rng.counter("cpu") is base and int(base.ctr) == before
+    assert int(a) == rng._i64(5 + rng._STRIDE) and int(b) == rng._i64(5 + 2 * rng._STRIDE)
+    assert a.data_ptr() + 8 == b.data_ptr()                       # neighbours of one table: no launch per draw
+    old = [int(rng.next_seed("cpu")) for _ in range(3)]
+    with rng.scope(mine):
+        for _ in range(rng.TABLE):                                # runs over the table end: refill continues the sequence
+            last = rng.next_seed("cpu")
+        assert int(a) == rng._i64(5 + rng._STRIDE) and int(last) == rng._i64(5 + (rng.TABLE + 2) * rng._STRIDE)  # the saved view still holds its seed
+        mine.seed(5)
+        assert int(rng.next_seed("cpu")) == int(a)                # pinned: reproducible
+    assert len(set(old)) == 3
+
+
+def test_model_from_config_lowers_indivisible_heads():
+    from mitune.models.transformer import SimpleTransformerModel, TransformerModel
+    m = TransformerModel.from_config({"d_model": 48, "num_heads": 32, "num_encoder_layers": 1}, 7)
+    assert m.layers[0].attention.h == 16
+    s = SimpleTransformerModel.from_config({"d_model": 32, "num_heads": 4, "num_layers": 2}, 7)
+    assert len(s.transformer) == 2

@@ -123,6 +123,31 @@ def test_strided_self_attention_on_projection_outputs(B, S, h, dk, dv, drop, kin
         assert torch.allclose(a, r, rtol=tol, atol=tol * max(1.0, r.abs().max().item())), name
 
 
+@pytest.mark.parametrize("B,S,h,dk,dv,dtype", [(3, 50, 4, 16, 16, torch.float32), (2, 65, 8, 24, 24, torch.bfloat16),
+                                                (2, 20, 2, 8, 16, torch.float32), (1, 128, 4, 32, 64, torch.bfloat16)])
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_fused_qkv_attention_equals_the_two_operand_form(B, S, h, dk, dv, dtype, p):
+    """One [B, S, 2*h*dk + h*dv] projection output read in place, one gradient tensor back: bitwise the values the
+    kernels give on separate contiguous qk / v tensors (which are checked against the f32 reference above)."""
+    from mitune.ops.attention_hip import FusedQKVAttention, FusedSelfAttention
+    g = torch.Generator(device="cuda").manual_seed(11)
+    W = 2 * h * dk + h * dv
+    qkv = torch.randn(B, S, W, device="cuda", generator=g).to(dtype)
+    do = torch.randn(B, S, h * dv, device="cuda", generator=g).to(dtype)
+    seed = torch.tensor([0x5DEECE66D], dtype=torch.int64, device="cuda") if p > 0 else None
+    a = qkv.clone().requires_grad_()
+    out = FusedQKVAttention.apply(a, h, dk, "softmax", p, seed)
+    out.backward(do)
+    qk = qkv[..., :2 * h * dk].clone().requires_grad_()
+    v = qkv[..., 2 * h * dk:].clone().requires_grad_()
+    ref = FusedSelfAttention.apply(qk, v, h, "softmax", None, p, seed)
+    ref.backward(do)
+    assert a.grad.shape == qkv.shape and a.grad.dtype == dtype
+    assert torch.equal(out, ref)
+    assert torch.equal(a.grad[..., :2 * h * dk], qk.grad)
+    assert torch.equal(a.grad[..., 2 * h * dk:], v.grad)
+
+
 def test_in_kernel_dropout_masks_equal_the_materialised_mask():
     """Seed-driven masks inside the attention and LayerNorm kernels are the masks ``keep_mask`` would write for the same
     seed, in forward and in backward."""
