@@ -1,6 +1,17 @@
-"""Dense layer whose weight gradient runs on the split-contraction MFMA kernel.
+"""Dense layers whose backward runs on hand-written MFMA kernels.
 
-``linear(x, weight, bias)`` is ``F.linear`` everywhere except in one place: on a GPU, under bf16 autocast, with a long
+``linear(x, weight, bias)`` is ``F.linear`` everywhere except in two places.
+
+Small f32 layers (no autocast; at most ``SMALL_MAX_ROWS`` rows and ``in x out <= SMALL_MAX_WEIGHTS`` -- every
+projection of the sequence-regression Transformers at batch 32 x 50 tokens): the backward's three library launches
+(input gradient, weight gradient, bias column sum) become ONE launch of ``mt_small_linear_bwd_launch``
+(``csrc/small_linear.hip``, exact-f32 matrix instructions, sixteen waves per 32x32 tile adding their accumulators
+through LDS in a fixed order; no workspace and no traffic between workgroups).  Measured per backward inside a
+replayed graph (library / fused, us): 800x64x256 61.3 / 10.1, 1600x10x32 20.7 / 15.3, 1600x64x256 29.6 / 15.7,
+1600x128x384 27.6 / 16.5, 1600x128x512 28.6 / 19.7, 3200x64x256 43.9 / 30.3; past the bound the library's larger
+LDS-staged tiles catch up (4800x256x768 76.5 / 74.5, 1600x256x1024 37.1 / 40.4) and keep the layer.
+
+On a GPU, under bf16 autocast, with a long
 token dimension (FT-Transformer and sequence-encoder layers see M = batch x tokens ~ 10^4..10^5 rows against a few
 hundred features), the backward's ``dW = dY^T X`` is a long skinny contraction for which the BLAS library picked a
 64x64 tile and no K split (87 TFLOP/s measured).  Here it goes to ``mt_wgrad_single_launch`` (``csrc/gemm.hip``):
@@ -16,6 +27,8 @@ import torch
 import torch.nn.functional as F
 
 MIN_ROWS = 4096        # below this the library GEMM is fine and the slab reduction is pure overhead
+SMALL_MAX_ROWS = 4096
+SMALL_MAX_WEIGHTS = 65536     # in x out, e.g. 128 x 512
 
 
 def _eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
@@ -28,10 +41,49 @@ def _eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return rows >= MIN_ROWS and out_f % 8 == 0 and in_f % 8 == 0 and out_f <= 128 * 255
 
 
+def _small_eligible(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
+    if not (x.is_cuda and torch.is_grad_enabled() and weight.requires_grad and not torch.is_autocast_enabled()):
+        return False
+    if x.dtype != torch.float32 or weight.dtype != torch.float32 or (bias is not None and bias.dtype != torch.float32):
+        return False
+    out_f, in_f = weight.shape
+    rows = x.numel() // max(in_f, 1)
+    return 0 < rows <= SMALL_MAX_ROWS and in_f * out_f <= SMALL_MAX_WEIGHTS
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     if _eligible(x, weight):
         return SplitKLinear.apply(x, weight, bias)
+    if _small_eligible(x, weight, bias):
+        return SmallLinear.apply(x, weight, bias)
     return F.linear(x, weight, bias)
+
+
+class SmallLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        so = L.load()
+        x, weight = ctx.saved_tensors
+        out_f, in_f = weight.shape
+        dyc = dy.reshape(-1, out_f).contiguous()
+        xc = x.reshape(-1, in_f).contiguous()
+        R = xc.shape[0]
+        dev = x.device
+        dx = torch.empty(R, in_f, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(out_f, in_f, device=dev, dtype=torch.float32)
+        db = torch.empty(out_f, device=dev, dtype=torch.float32) if ctx.has_bias else None
+        L.check(so.mt_small_linear_bwd_launch(xc.data_ptr(), weight.data_ptr(), dyc.data_ptr(),
+                                              dx.data_ptr() if dx is not None else None, dw.data_ptr(),
+                                              db.data_ptr() if db is not None else None, R, in_f, out_f, torch.cuda.current_stream(dev).cuda_stream),
+                "mt_small_linear_bwd_launch")
+        return (dx.reshape(x.shape) if dx is not None else None), dw, db
 
 
 class SplitKLinear(torch.autograd.Function):

@@ -196,3 +196,54 @@ def test_in_kernel_dropout_masks_equal_the_materialised_mask():
             res.append((y.detach(), a.grad, b.grad))
         for x1, x2 in zip(*res):
             assert torch.equal(x1, x2)
+
+
+# ------------------------------------------------------------------ fused small-linear backward
+@pytest.mark.parametrize("R,in_f,out_f", [(1600, 64, 256), (1600, 256, 64), (1600, 10, 64), (32, 64, 1), (37, 50, 33),
+                                          (1600, 128, 384), (3200, 32, 96), (800, 512, 128), (130, 36, 40)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_small_linear_backward_matches_f32_reference(R, in_f, out_f, bias):
+    """One launch gives dX, dW and db of a small f32 layer; compared with a float64 product of the same operands."""
+    from mitune.ops.linear import SmallLinear
+    linear = SmallLinear.apply                            # also past the size bound that ``linear`` applies
+    g = torch.Generator(device="cuda").manual_seed(R + in_f + out_f)
+    x = torch.randn(R // 4, 4, in_f, device="cuda", generator=g).requires_grad_() if R % 4 == 0 else \
+        torch.randn(R, in_f, device="cuda", generator=g).requires_grad_()
+    w = (torch.randn(out_f, in_f, device="cuda", generator=g) * in_f ** -0.5).requires_grad_()
+    b = torch.randn(out_f, device="cuda", generator=g).requires_grad_() if bias else None
+    y = linear(x, w, b)
+    assert "SmallLinear" in type(y.grad_fn).__name__
+    dy = torch.randn(y.shape, device="cuda", generator=g)
+    for rep in range(2):
+        x.grad = w.grad = None
+        if b is not None:
+            b.grad = None
+        linear(x, w, b).backward(dy)
+        x2, w2, dy2 = x.detach().double().reshape(R, in_f), w.detach().double(), dy.double().reshape(R, out_f)
+        assert torch.allclose(x.grad.double().reshape(R, in_f), dy2 @ w2, rtol=1e-4, atol=1e-4)
+        assert torch.allclose(w.grad.double(), dy2.t() @ x2, rtol=1e-4, atol=1e-3)
+        if b is not None:
+            assert torch.allclose(b.grad.double(), dy2.sum(0), rtol=1e-4, atol=1e-3)
+    first = w.grad.clone()
+    w.grad = None
+    linear(x, w, b).backward(dy)
+    assert torch.equal(w.grad, first)                     # ordered reduction: bitwise repeatable
+    xin = x.detach()                                      # an input that needs no gradient: no dX tiles are launched
+    w.grad = None
+    linear(xin, w, b).backward(dy)
+    assert torch.equal(w.grad, first)
+
+
+def test_small_linear_is_not_used_under_autocast_or_for_large_layers():
+    from mitune.ops.linear import linear
+    x = torch.randn(64, 32, device="cuda", requires_grad=True)
+    w = torch.randn(16, 32, device="cuda", requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert "SmallLinear" not in type(linear(x, w).grad_fn).__name__
+    xl = torch.randn(20000, 32, device="cuda", requires_grad=True)
+    assert "SmallLinear" not in type(linear(xl, w).grad_fn).__name__
+    wl = torch.randn(1024, 256, device="cuda", requires_grad=True)
+    assert "SmallLinear" not in type(linear(torch.randn(64, 256, device="cuda"), wl).grad_fn).__name__
+    assert "SmallLinear" in type(linear(x, w).grad_fn).__name__
+    with torch.no_grad():
+        assert linear(x, w).grad_fn is None
