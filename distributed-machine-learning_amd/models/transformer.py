@@ -36,7 +36,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops.attention import self_attention, self_attention_qkv
-from ..ops.elementwise import depthwise_conv1d, dropout, pe_add_dropout
+from ..ops.elementwise import depthwise_conv1d, pe_add_dropout, relu_dropout
 from ..ops.head_mlp import head_mlp
 from ..ops.layernorm import residual_layer_norm
 from ..ops.linear import linear
@@ -80,8 +80,8 @@ class DepthwiseSeparableConv(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:          # [B, S, d], channel-last throughout
         y = depthwise_conv1d(x, self.depthwise.weight, self.depthwise.bias)
-        y = F.relu(F.linear(y, self.pointwise.weight.squeeze(-1), self.pointwise.bias))     # k=1 conv == linear
-        return F.linear(y, self.project.weight.squeeze(-1), self.project.bias)
+        y = F.relu(linear(y, self.pointwise.weight.squeeze(-1), self.pointwise.bias))     # k=1 conv == linear
+        return linear(y, self.project.weight.squeeze(-1), self.project.bias)
 
 
 class SelfAttention(nn.Module):
@@ -180,7 +180,11 @@ class CustomEncoderLayer(nn.Module):
             a = a * m
         src = residual_layer_norm(a, src, self.norm1.weight, self.norm1.bias, self.norm1.eps,
                                   dropout_p=self.p if self.training else 0.0)
-        f = self.feedforward(src)
+        ff = self.feedforward
+        if isinstance(ff, nn.Sequential):          # same parameters, dense layers through the fused-backward path
+            f = linear(F.relu(linear(src, ff[0].weight, ff[0].bias)), ff[2].weight, ff[2].bias)
+        else:
+            f = ff(src)
         m = self._branch_scale(src, rate)
         if m is not None:
             f = f * m
@@ -231,7 +235,7 @@ class TransformerModel(nn.Module):
                    stochastic_depth_rate=float(config.get("stochastic_depth_rate", 0.0)))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.positional_encoding(self.input_projection(x))
+        x = self.positional_encoding(linear(x, self.input_projection.weight, self.input_projection.bias))
         for i in range(self.num_encoder_layers):
             layer = self.layers[0] if self.shared_weights else self.layers[i]
             x = layer(x, drop_path=self.drop_rates[i])
@@ -256,7 +260,7 @@ class _PostNormLayer(nn.Module):
         p = self.p if self.training else 0.0
         a, _ = self.self_attn(x)
         x = residual_layer_norm(a, x, self.norm1.weight, self.norm1.bias, self.norm1.eps, dropout_p=p)
-        f = linear(dropout(F.relu(linear(x, self.linear1.weight, self.linear1.bias)), p, self.training),
+        f = linear(relu_dropout(linear(x, self.linear1.weight, self.linear1.bias), p, self.training),
                    self.linear2.weight, self.linear2.bias)
         return residual_layer_norm(f, x, self.norm2.weight, self.norm2.bias, self.norm2.eps, dropout_p=p)
 
@@ -276,7 +280,7 @@ class SimpleTransformerModel(nn.Module):
                    float(config.get("dropout", 0.1)))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.input_projection(x)
+        x = linear(x, self.input_projection.weight, self.input_projection.bias)
         for layer in self.transformer:
             x = layer(x)
-        return self.fc(x[:, -1, :]).squeeze(-1)
+        return linear(x[:, -1, :], self.fc.weight, self.fc.bias).squeeze(-1)

@@ -8,6 +8,8 @@
 //
 //   mt_keep_mask_launch     uint8 mask [n] (1 = keep) for kernels that take a mask operand (attention, LayerNorm)
 //   mt_dropout_launch       y = keep ? x / (1 - p) : 0 for f32 or bf16 data; the same call with dy gives dx
+//   mt_relu_dropout_*       y = keep ? max(x, 0) / (1 - p) : 0 (the feed-forward block's activation + dropout in one
+//                           pass) and dx = (y != 0) ? dy / (1 - p) : 0: y itself records both the sign and the mask
 #include "mt_common.h"
 
 #define dr_hash mt_rng_hash       // the same hash the fused kernels use for their in-kernel masks
@@ -49,6 +51,31 @@ __global__ __launch_bounds__(256) void mt_dropout_kernel(const T* __restrict__ x
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void mt_relu_dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n,
+                                                                  const int64_t* __restrict__ seed, uint32_t thresh,
+                                                                  float scale) {
+  const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const uint64_t s = (uint64_t)seed[0];
+  const uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+  const int cnt = (n - i4) < 4 ? (int)(n - i4) : 4;
+  for (int e = 0; e < cnt; ++e) {
+    const float v = fmaxf(DrIO<T>::ld(x + i4 + e), 0.f);
+    DrIO<T>::st(y + i4 + e, dr_hash(s0, s1, (uint32_t)(i4 + e)) >= thresh ? v * scale : 0.f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mt_relu_dropout_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                                  T* __restrict__ dx, long n, float scale) {
+  const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const int cnt = (n - i4) < 4 ? (int)(n - i4) : 4;
+  for (int e = 0; e < cnt; ++e)
+    DrIO<T>::st(dx + i4 + e, DrIO<T>::ld(y + i4 + e) != 0.f ? DrIO<T>::ld(dy + i4 + e) * scale : 0.f);
+}
+
 static inline uint32_t dr_thresh(float p) { return (uint32_t)((double)p * 4294967296.0); }
 
 extern "C" int mt_keep_mask_launch(void* out, long n, const int64_t* seed, float p, hipStream_t stream) {
@@ -70,6 +97,38 @@ extern "C" int mt_dropout_launch(const void* x, void* y, long n, const int64_t* 
   else if (dtype == 1)
     hipLaunchKernelGGL(mt_dropout_kernel<uint16_t>, grid, block, 0, stream, (const uint16_t*)x, (uint16_t*)y, n, seed,
                        dr_thresh(p), scale);
+  else return -2;
+  return (int)hipGetLastError();
+}
+
+extern "C" int mt_relu_dropout_fwd_launch(const void* x, void* y, long n, const int64_t* seed, float p, int dtype,
+                                          hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (seed == nullptr || p < 0.f || p >= 1.f) return -2;
+  dim3 grid((unsigned)((n + 1023) / 1024)), block(256);
+  const float scale = 1.f / (1.f - p);
+  if (dtype == 0)
+    hipLaunchKernelGGL(mt_relu_dropout_fwd_kernel<float>, grid, block, 0, stream, (const float*)x, (float*)y, n, seed,
+                       dr_thresh(p), scale);
+  else if (dtype == 1)
+    hipLaunchKernelGGL(mt_relu_dropout_fwd_kernel<uint16_t>, grid, block, 0, stream, (const uint16_t*)x, (uint16_t*)y, n, seed,
+                       dr_thresh(p), scale);
+  else return -2;
+  return (int)hipGetLastError();
+}
+
+extern "C" int mt_relu_dropout_bwd_launch(const void* dy, const void* y, void* dx, long n, float p, int dtype,
+                                          hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (p < 0.f || p >= 1.f) return -2;
+  dim3 grid((unsigned)((n + 1023) / 1024)), block(256);
+  const float scale = 1.f / (1.f - p);
+  if (dtype == 0)
+    hipLaunchKernelGGL(mt_relu_dropout_bwd_kernel<float>, grid, block, 0, stream, (const float*)dy, (const float*)y, (float*)dx,
+                       n, scale);
+  else if (dtype == 1)
+    hipLaunchKernelGGL(mt_relu_dropout_bwd_kernel<uint16_t>, grid, block, 0, stream, (const uint16_t*)dy, (const uint16_t*)y,
+                       (uint16_t*)dx, n, scale);
   else return -2;
   return (int)hipGetLastError();
 }

@@ -217,6 +217,89 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_kernel(const float* __re
   }
 }
 
+// Narrow rows (d <= 256): the same regrouping as the narrow forward.  A wave takes LN_SMALL_ROWS rows per round with every
+// load issued before the first reduction and the two reductions of the rows interleaved, instead of eight rows one
+// after the other with two dependent reductions each; the weight/bias partials need one LDS exchange, not eight.
+// Rows per block and the layout of the per-block partials are those of mt_ln_bwd_kernel.
+__global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_small_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                     const float* __restrict__ stats,
+                                                                     const uint8_t* __restrict__ keep,
+                                                                     const float* __restrict__ w, float* __restrict__ dx,
+                                                                     float* __restrict__ dres, float* __restrict__ dwb_part,
+                                                                     int M, int d, float keep_scale,
+                                                                     const int64_t* __restrict__ seed, uint32_t thresh) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = d >> 2;
+  const bool col_ok = lane < nv;
+  const int c4 = col_ok ? 4 * lane : 0;
+  const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c4);
+  f32x4 dw = f32x4{0.f, 0.f, 0.f, 0.f}, db = dw;
+  const int row0 = (blockIdx.x * 4 + wave) * LN_ROWS_PER_WAVE;
+  const float inv_d = 1.f / (float)d;
+#pragma unroll
+  for (int it = 0; it < LN_ROWS_PER_WAVE; it += LN_SMALL_ROWS) {
+    if (row0 + it >= M) break;                                   // wave-uniform
+    f32x4 g[LN_SMALL_ROWS], xh[LN_SMALL_ROWS];
+    float s1[LN_SMALL_ROWS], s2[LN_SMALL_ROWS], rstd[LN_SMALL_ROWS];
+#pragma unroll
+    for (int i = 0; i < LN_SMALL_ROWS; ++i) {
+      const int row = row0 + it + i;
+      const bool ok = col_ok && row < M;
+      const int rc = row < M ? row : row0 + it;                  // clamped: loads never branch
+      const size_t off = (size_t)rc * d + c4;
+      const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + off);
+      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + off);
+      const float mean = stats[2 * (size_t)rc];
+      rstd[i] = stats[2 * (size_t)rc + 1];
+      s1[i] = 0.f; s2[i] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dye = ok ? dyv[e] : 0.f;
+        xh[i][e] = ok ? (zv[e] - mean) * rstd[i] : 0.f;
+        g[i][e] = dye * wv[e];
+        s1[i] += g[i][e];
+        s2[i] += g[i][e] * xh[i][e];
+        dw[e] += dye * xh[i][e];
+        db[e] += dye;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_SMALL_ROWS; ++i) s1[i] = wave_sum(s1[i]) * inv_d;
+#pragma unroll
+    for (int i = 0; i < LN_SMALL_ROWS; ++i) s2[i] = wave_sum(s2[i]) * inv_d;
+#pragma unroll
+    for (int i = 0; i < LN_SMALL_ROWS; ++i) {
+      const int row = row0 + it + i;
+      if (col_ok && row < M) {
+        const size_t off = (size_t)row * d + c4;
+        f32x4 dz, dxv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dz[e] = rstd[i] * (g[i][e] - s1[i] - xh[i][e] * s2[i]);
+        dxv = dz;
+        if (keep != nullptr || seed != nullptr) {
+          const uint32_t kw = mt_keep_word4(keep, seed, thresh, off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dxv[e] *= ((kw >> (8 * e)) & 0xFFu) ? keep_scale : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dres + off) = dz;
+        *reinterpret_cast<f32x4*>(dx + off) = dxv;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[wave][lane * 4 + e] = dw[e];
+    red[wave][256 + lane * 4 + e] = db[e];
+  }
+  __syncthreads();
+  float* out = dwb_part + (size_t)blockIdx.x * 2 * d;
+  for (int k = threadIdx.x; k < d; k += LN_THREADS) {            // d <= 256: one pass
+    out[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    out[d + k] = (red[0][256 + k] + red[1][256 + k]) + (red[2][256 + k] + red[3][256 + k]);
+  }
+}
+
 extern "C" int mt_ln_bwd_blocks(int M) { return (M + 4 * LN_ROWS_PER_WAVE - 1) / (4 * LN_ROWS_PER_WAVE); }
 
 extern "C" int mt_ln_fwd_launch(const float* x, const float* res, const void* keep, const float* w, const float* b,
@@ -243,7 +326,11 @@ extern "C" int mt_ln_bwd_launch(const float* dy, const float* z, const float* st
   if (thresh == 0u) seed = nullptr;
   if (M <= 0) return 0;
   if (d > 2048 || (d & 3)) return -2;
-  hipLaunchKernelGGL(mt_ln_bwd_kernel, dim3(mt_ln_bwd_blocks(M)), dim3(LN_THREADS), 0, stream, dy, z, stats,
-                     (const uint8_t*)keep, w, dx, dres, dwb_part, M, d, keep_scale, seed, thresh);
+  if (d <= 256)
+    hipLaunchKernelGGL(mt_ln_bwd_small_kernel, dim3(mt_ln_bwd_blocks(M)), dim3(LN_THREADS), 0, stream, dy, z, stats,
+                       (const uint8_t*)keep, w, dx, dres, dwb_part, M, d, keep_scale, seed, thresh);
+  else
+    hipLaunchKernelGGL(mt_ln_bwd_kernel, dim3(mt_ln_bwd_blocks(M)), dim3(LN_THREADS), 0, stream, dy, z, stats,
+                       (const uint8_t*)keep, w, dx, dres, dwb_part, M, d, keep_scale, seed, thresh);
   return (int)hipGetLastError();
 }

@@ -64,3 +64,12 @@ def dropout(x: torch.Tensor, p: float, training: bool = True) -> torch.Tensor:
         from .rng import next_seed
         return FusedDropout.apply(x, next_seed(x.device), float(p))
     return F.dropout(x, p, True)
+
+
+def relu_dropout(x: torch.Tensor, p: float, training: bool = True) -> torch.Tensor:
+    """``dropout(relu(x))``; one kernel per direction on a GPU when dropout is active."""
+    if training and p > 0.0 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+        from .elementwise_hip import FusedReluDropout
+        from .rng import next_seed
+        return FusedReluDropout.apply(x, next_seed(x.device), float(p))
+    return dropout(F.relu(x), p, training)

@@ -105,3 +105,28 @@ class FusedDropout(torch.autograd.Function):
         L.check(so.mt_dropout_launch(dyc.data_ptr(), dx.data_ptr(), dyc.numel(), ctx.seed.data_ptr(), ctx.p,
                                      0 if dy.dtype == torch.float32 else 1, _stream(dy)), "mt_dropout_launch(bwd)")
         return dx, None, None
+
+
+class FusedReluDropout(torch.autograd.Function):
+    """``dropout(relu(x))`` in one pass; the output is the only tensor kept for backward (non-zero = positive and kept)."""
+
+    @staticmethod
+    def forward(ctx, x, seed, p: float):
+        so = L.load()
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        L.check(so.mt_relu_dropout_fwd_launch(xc.data_ptr(), y.data_ptr(), xc.numel(), seed.data_ptr(), p,
+                                              0 if x.dtype == torch.float32 else 1, _stream(x)), "mt_relu_dropout_fwd_launch")
+        ctx.save_for_backward(y)
+        ctx.p = p
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        so = L.load()
+        (y,) = ctx.saved_tensors
+        dyc = dy.to(y.dtype).contiguous()
+        dx = torch.empty_like(dyc)
+        L.check(so.mt_relu_dropout_bwd_launch(dyc.data_ptr(), y.data_ptr(), dx.data_ptr(), dyc.numel(), ctx.p,
+                                              0 if y.dtype == torch.float32 else 1, _stream(dy)), "mt_relu_dropout_bwd_launch")
+        return dx, None, None

@@ -191,6 +191,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_keep_mask_launch.argtypes = [c_void_p, C.c_long, c_void_p, c_float, c_void_p]
     lib.mt_dropout_launch.argtypes = [c_void_p, c_void_p, C.c_long, c_void_p, c_float, C.c_int, c_void_p]
     lib.mt_keep_mask_launch.restype = lib.mt_dropout_launch.restype = C.c_int
+    lib.mt_relu_dropout_fwd_launch.argtypes = [c_void_p, c_void_p, C.c_long, c_void_p, c_float, C.c_int, c_void_p]
+    lib.mt_relu_dropout_bwd_launch.argtypes = [c_void_p, c_void_p, c_void_p, C.c_long, c_float, C.c_int, c_void_p]
+    lib.mt_relu_dropout_fwd_launch.restype = lib.mt_relu_dropout_bwd_launch.restype = C.c_int
     lib.mt_dwconv_chunks.argtypes = [C.c_long]
     lib.mt_dwconv_launch.argtypes = [c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]
     lib.mt_dwconv_wgrad_launch.argtypes = [c_void_p] * 3 + [C.c_long, C.c_int, C.c_int, C.c_int, c_void_p]

@@ -103,7 +103,7 @@ class TorchPackEngine(PackEngine):
         """Optimiser/batch/loss settings of a trial; ``model_kwargs`` supplies what the search space leaves fixed."""
         return MLPTrialSpec.from_config({**self.t.model_kwargs, **config}, self.t.in_features)
 
-    def _build(self, spec: MLPTrialSpec, config: Dict, trial_index: int = 0):
+    def _build(self, spec: MLPTrialSpec, config: Dict, trial_index: int = 0, with_optimizer: bool = True):
         if self.t.model == "mlp":
             model = MLPRegressor(spec.in_features, spec.hidden_sizes)
         else:
@@ -123,6 +123,8 @@ class TorchPackEngine(PackEngine):
                 else:
                     model = self.t.model(config, spec.in_features)
         model = model.to(self.device)
+        if not with_optimizer:
+            return model, None
         opt = build_optimizer(spec.optimizer, model.parameters(), spec.learning_rate, spec.weight_decay,
                               spec.momentum, spec.beta1, spec.beta2, spec.eps)
         return model, opt

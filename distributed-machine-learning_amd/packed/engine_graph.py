@@ -51,17 +51,18 @@ class GraphPackEngine(TorchPackEngine):
         if self.device.type != "cuda":
             raise ValueError("GraphPackEngine needs a GPU; use engine='torch' on the CPU")
         self._trainers: Dict[int, GraphedTrainer] = {}
+        self._prepared: Dict[int, tuple] = {}          # trial_index -> (config, slot record, trainer), not yet in a slot
+        self._pending_epoch = None
+        self.prepared_total = 0
         n = int(trainable.model_kwargs.get("streams", os.environ.get("MITUNE_GRAPH_STREAMS", DEFAULT_STREAMS)))
         self._streams: List[torch.cuda.Stream] = [torch.cuda.Stream(self.device) for _ in range(max(1, min(n, 32)))]
 
     # ------------------------------------------------------------------ slot management
-    def load(self, slot, trial_index, config, state=None):
-        if slot in self.slots:
-            raise RuntimeError(f"slot {slot} is occupied")
+    def _make(self, trial_index, config, state=None):
         spec = self._spec(config)
         s = _Slot()
         s.trial_index, s.spec, s.config = int(trial_index), spec, dict(config)
-        model, _ = self._build(spec, config, trial_index)
+        model, _ = self._build(spec, config, trial_index, with_optimizer=False)       # the fused flat optimiser below
         if state is None and self.t.model == "mlp":
             model.load_state_dict(init_mlp_state(spec, self.seed, trial_index))
         if state is not None and "model" in state:
@@ -79,10 +80,31 @@ class GraphPackEngine(TorchPackEngine):
                 except (ValueError, KeyError, TypeError):
                     pass       # another optimiser family or layout: fresh moments
             s.epoch, s.step = int(state.get("epoch", 0)), int(state.get("step", 0))
+        trainer = GraphedTrainer(model, get_criterion(spec.loss_function), self.Xtr, self.ytr, spec.batch_size, s.opt,
+                                 shuffle=False, drop_last=True, forward_ctx=self._autocast)
+        return s, trainer
+
+    def prepare(self, trial_index, config) -> bool:
+        """Build and capture a trial that has no slot yet (host work the executor overlaps with a running epoch);
+        ``load`` then only files it.  Returns False when the cache is full."""
+        if int(trial_index) in self._prepared:
+            return True         # already waiting for its slot
+        if len(self._prepared) >= self.capacity:
+            return False
+        self._prepared[int(trial_index)] = (dict(config),) + self._make(trial_index, config)
+        self.prepared_total += 1
+        return True
+
+    def load(self, slot, trial_index, config, state=None):
+        if slot in self.slots:
+            raise RuntimeError(f"slot {slot} is occupied")
+        ready = self._prepared.pop(int(trial_index), None)
+        if ready is not None and state is None and ready[0] == dict(config):
+            s, trainer = ready[1], ready[2]
+        else:
+            s, trainer = self._make(trial_index, config, state)
         self.slots[slot] = s
-        self._trainers[slot] = GraphedTrainer(model, get_criterion(spec.loss_function), self.Xtr, self.ytr,
-                                              spec.batch_size, s.opt, shuffle=False, drop_last=True,
-                                              forward_ctx=self._autocast)
+        self._trainers[slot] = trainer
 
     def evict(self, slot):
         self.slots.pop(slot, None)
@@ -142,7 +164,13 @@ class GraphPackEngine(TorchPackEngine):
                 cur.wait_stream(st)
 
     def train_epoch(self):
+        self.train_epoch_begin()
+        self.train_epoch_end()
+
+    def train_epoch_begin(self):
+        """Issue the epoch of every occupied slot; returns without waiting for the GPU."""
         order = self.occupied()
+        self._pending_epoch = None
         if not order:
             return
         n = self.Xtr.shape[0]
@@ -169,7 +197,15 @@ class GraphPackEngine(TorchPackEngine):
                         with torch.cuda.stream(streams[j % ns]):
                             tr.step_once(i)
         self._fan_in(cur, streams)
-        losses = torch.stack([tr.epoch_loss(b) for _, tr, b in plan]).tolist()        # one synchronisation
+        self._pending_epoch = (plan, torch.stack([tr.epoch_loss(b) for _, tr, b in plan]))
+
+    def train_epoch_end(self):
+        """Wait for the issued epoch and book its losses."""
+        if self._pending_epoch is None:
+            return
+        plan, stacked = self._pending_epoch
+        self._pending_epoch = None
+        losses = stacked.tolist()                                                    # one synchronisation
         for (s, tr, batches), loss in zip(plan, losses):
             s.train_loss = loss
             s.step += batches

@@ -75,6 +75,7 @@ class PackedExecutor(Executor):
         self._queued: List[Event] = []
         self._awaiting: Dict[str, Optional[str]] = {}          # trial_id -> decision (None = not yet)
         self._epoch_time = 0.0
+        self._gpu_epoch_s = 0.0            # duration of the last training epoch (issue to completion)
         self._n_undecided = 0
         self._hostname = socket.gethostname()
         self._diverged: set = set()
@@ -117,7 +118,13 @@ class PackedExecutor(Executor):
         if self._n_undecided > 0:
             return []      # the runner still owes decisions for the previous round
         t0 = time.time()
-        self.engine.train_epoch()
+        begin = getattr(self.engine, "train_epoch_begin", None)
+        if begin is not None and self.world == 1 and self.runner is not None and hasattr(self.engine, "prepare"):
+            begin()                                   # the GPU trains ...
+            self._prefetch(t0)                        # ... while the host builds and captures the trials that come next
+            self.engine.train_epoch_end()
+        else:
+            self.engine.train_epoch()
         t1 = time.time()
         local = self.engine.evaluate()
         t2 = time.time()
@@ -134,6 +141,8 @@ class PackedExecutor(Executor):
         self.stats["epochs"] += 1
         self.stats["slot_epochs"] += len(local)
         self.stats["train_s"] += t1 - t0
+        self._gpu_epoch_s = t1 - t0
+        self.stats["prepared_ahead"] = getattr(self.engine, "prepared_total", 0)
         self.stats["eval_s"] += t2 - t1
         self.stats["comm_s"] += t3 - t2
 
@@ -175,6 +184,21 @@ class PackedExecutor(Executor):
             self._n_undecided += 1
             events.append(Event("result", tr, result=result))
         return events
+
+    def _prefetch(self, t_issue: float) -> None:
+        """Prepare upcoming trials while the issued epoch runs: for as long as the previous epoch's GPU time suggests
+        the device stays busy, and never more than one pack's worth.  Only trials the runner can name in advance
+        without changing the search (already pending, or drawn from a searcher that does not look at results)."""
+        budget = 0.8 * self._gpu_epoch_s
+        if budget <= 0.0:
+            return
+        for tr in self.runner.lookahead(self.capacity):
+            if time.time() - t_issue >= budget:
+                break
+            if tr.restore_from is not None or tr.start_time is not None:
+                continue                              # resumes from a state: built when it gets its slot
+            if not self.engine.prepare(tr.index, tr.config):
+                break
 
     def resolve(self, trial: Trial, decision: str) -> None:
         if trial.trial_id in self._diverged:      # a NaN/inf slot is retired whatever the scheduler said

@@ -15,6 +15,7 @@ from ..tune import space as sp
 
 class Searcher:
     FINISHED = "FINISHED"
+    lookahead_safe = False       # True when suggestions do not depend on reported results
 
     def __init__(self, metric: Optional[str] = None, mode: Optional[str] = None):
         self.metric, self.mode = metric, mode
@@ -45,6 +46,8 @@ class Searcher:
 
 class BasicVariantGenerator(Searcher):
     """Random search with optional grid axes; deterministic for a given seed."""
+
+    lookahead_safe = True        # suggestions never depend on results: trials may be drawn ahead of their start
 
     def __init__(self, num_samples: int = 1, seed: Optional[int] = 0, points_to_evaluate: Optional[List[Dict]] = None):
         super().__init__()

@@ -252,10 +252,9 @@ class GraphedTrainer:
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         self.model.train()
-        with torch.cuda.stream(side):          # warm-up off the caller's stream (allocator, lazy init, autotune)
-            for _ in range(2):
-                self.pos.zero_()
-                self._cursor_step()
+        with torch.cuda.stream(side):          # warm-up off the caller's stream (allocator, lazy init, library workspaces)
+            self.pos.zero_()
+            self._cursor_step()
         cur.wait_stream(side)
         with torch.no_grad():                  # undo the warm-up steps: training starts from the initial weights
             f.P.copy_(keep[0]); o.M.copy_(keep[1]); o.V.copy_(keep[2]); o.state.copy_(keep[3])

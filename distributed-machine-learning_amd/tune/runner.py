@@ -88,6 +88,19 @@ class TrialRunner:
             q.popleft()
         return q[0] if q else None
 
+    def lookahead(self, n: int) -> List[Trial]:
+        """Up to ``n`` trials that will start next, in start order, without starting them: the pending queue, topped up
+        from the searcher when its suggestions do not depend on results (``lookahead_safe``).  Executors use it to
+        prepare trials while the device is busy."""
+        out = [t for t in self._pending_q if t.status == PENDING][:n]
+        if getattr(self.searcher, "lookahead_safe", False):
+            while len(out) < n:
+                t = self._next_from_searcher()
+                if t is None:
+                    break
+                out.append(t)
+        return out
+
     def get_trial(self, trial_id: str) -> Optional[Trial]:
         return self._by_id.get(trial_id)
 

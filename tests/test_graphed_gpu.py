@@ -280,6 +280,25 @@ def test_counter_dropout_forward_backward_share_the_mask(dtype):
     assert dropout(x, p, False) is x
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_relu_dropout_equals_dropout_of_relu(dtype):
+    from mitune.ops import rng
+    from mitune.ops.elementwise import dropout, relu_dropout
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(37, 50, 129, device=DEV, generator=g).to(dtype)
+    dy = torch.randn(37, 50, 129, device=DEV, generator=g).to(dtype)
+    a, b = x.clone().requires_grad_(), x.clone().requires_grad_()
+    rng.seed_all(23)
+    y = relu_dropout(a, 0.3, True)
+    assert "FusedReluDropout" in type(y.grad_fn).__name__
+    rng.seed_all(23)
+    ref = dropout(torch.relu(b), 0.3, True)
+    y.backward(dy)
+    ref.backward(dy)
+    assert torch.equal(y, ref) and torch.equal(a.grad, b.grad)
+    assert relu_dropout(x, 0.3, False).equal(torch.relu(x))
+
+
 def test_keep_mask_statistics():
     from mitune.ops.elementwise import keep_mask
     m = keep_mask((64, 8, 65, 65), 0.2, torch.device(DEV))
@@ -377,6 +396,33 @@ def test_packed_search_over_the_sample_space_on_gpu():
                   local_dir=None, verbose=0, seed=1, metric="validation_loss", mode="min", device=torch.device(DEV))
     assert len(an.trials) == 6 and an.stats["engine"] == "graph"
     assert math.isfinite(an.best_result["validation_loss"])
+
+
+def test_trials_prepared_during_a_running_epoch_end_like_trials_built_on_demand(monkeypatch):
+    from mitune import tune
+    from mitune.data import create_dummy_data
+    from mitune.packed import PackedTrainable
+    from mitune.search.searcher import BasicVariantGenerator
+    tl, vl = create_dummy_data(num_samples=400, seq_len=20, input_size=6)
+
+    def search():
+        tr = PackedTrainable(model="simple_transformer", train=tuple(tl.dataset.tensors), val=tuple(vl.dataset.tensors),
+                             max_epochs=2, dtype="f32", capacity=3, model_kwargs={"batch_size": 32, "optimizer": "adamw"})
+        an = tune.run(tr, config={"d_model": tune.choice([32, 64]), "num_heads": 2, "num_layers": tune.choice([1, 2]),
+                                  "dropout": 0.1, "learning_rate": tune.loguniform(1e-4, 1e-2)},
+                      num_samples=9, local_dir=None, verbose=0, seed=2, metric="validation_loss", mode="min",
+                      device=torch.device(DEV))
+        return an, {t.trial_id: (t.config["d_model"], t.last_result["validation_loss"]) for t in an.trials}
+
+    an_a, ahead = search()
+    assert an_a.stats["prepared_ahead"] > 0
+    monkeypatch.setattr(BasicVariantGenerator, "lookahead_safe", False)
+    an_b, on_demand = search()
+    assert an_b.stats["prepared_ahead"] == 0
+    assert ahead.keys() == on_demand.keys()
+    for k in ahead:
+        assert ahead[k][0] == on_demand[k][0]
+        assert ahead[k][1] == pytest.approx(on_demand[k][1], rel=2e-3)
 
 
 # ------------------------------------------------------------------ split-contraction weight gradient
