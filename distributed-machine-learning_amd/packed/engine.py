@@ -17,6 +17,7 @@ and read once per epoch instead of ``.item()`` per batch.
 """
 from __future__ import annotations
 
+import dataclasses
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -101,7 +102,17 @@ class TorchPackEngine(PackEngine):
 
     def _spec(self, config: Dict) -> MLPTrialSpec:
         """Optimiser/batch/loss settings of a trial; ``model_kwargs`` supplies what the search space leaves fixed."""
-        return MLPTrialSpec.from_config({**self.t.model_kwargs, **config}, self.t.in_features)
+        spec = MLPTrialSpec.from_config({**self.t.model_kwargs, **config}, self.t.in_features)
+        if self.t.model != "mlp" and (spec.warmup_steps or spec.total_steps):
+            # The full search space samples step counts sized for long runs; as in the function trainable
+            # (train/functions.py::train_transformer_model) the decay never ends before training does and the
+            # warm-up takes at most a quarter of it.
+            n = int(self.Xtr.shape[0])
+            planned = self.t.max_epochs * max(1, n // max(1, min(spec.batch_size, n)))
+            spec = dataclasses.replace(
+                spec, total_steps=max(spec.total_steps, planned) if spec.total_steps else 0,
+                warmup_steps=min(spec.warmup_steps, max(1, planned // 4)) if spec.warmup_steps else 0)
+        return spec
 
     def _build(self, spec: MLPTrialSpec, config: Dict, trial_index: int = 0, with_optimizer: bool = True):
         if self.t.model == "mlp":
