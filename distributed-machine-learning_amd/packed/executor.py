@@ -30,6 +30,11 @@ from ..tune.logger import dump_json
 from ..tune.session import CONTINUE, PAUSE, RESTART, STOP
 from ..tune.trial import Trial
 
+class RankLostError(RuntimeError):
+    """The per-epoch exchange between ranks failed: a peer process is gone or the fabric timed out.  The runner saves
+    the experiment state on the way out; restart every rank with ``resume=True``."""
+
+
 _REC = 6   # trial_index, epoch, train_loss, validation_loss, validation_mse, validation_mape
 
 
@@ -136,7 +141,11 @@ class PackedExecutor(Executor):
             rows_local[slot] = [float(tr.index), float(tr.training_iteration + 1), m["train_loss"], m["validation_loss"],
                                 m["validation_mse"], m["validation_mape"]]
         table = torch.tensor(rows_local, dtype=torch.float64)         # one conversion, not one per slot
-        gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
+        try:
+            gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
+        except Exception as e:          # noqa: BLE001 - RCCL / gloo raise backend-specific types
+            raise RankLostError(f"rank {self.rank} of {self.world}: metric exchange after epoch {self.stats['epochs'] + 1} "
+                                f"failed ({type(e).__name__}: {e})") from e
         t3 = time.time()
         self._epoch_time = t3 - t0
         self.stats["epochs"] += 1

@@ -112,6 +112,49 @@ def test_gloo_two_process_search_agrees(tmp_path):
     assert {k: v[:2] for k, v in a["res"].items()} == {k: list(v[:2]) for k, v in single.items()}
 
 
+def _rank_loss_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from mitune.packed import RankLostError
+    from mitune.packed.engine import TorchPackEngine
+    from mitune.parallel.comm import TorchDistComm
+
+    class DyingEngine(TorchPackEngine):
+        epochs_done = 0
+
+        def train_epoch(self):
+            if rank == 1 and self.epochs_done == 2:
+                os._exit(0)                       # the process vanishes mid-search, without any goodbye
+            super().train_epoch()
+            self.epochs_done += 1
+
+    comm = TorchDistComm(backend="gloo", rank=rank, world_size=world, timeout_s=30.0)
+    train, val = _data()
+    tr = PackedTrainable(train=train, val=val, max_epochs=6, engine="torch", capacity=3, name="rankloss")
+    ex = PackedExecutor(tr, comm=comm, device=torch.device("cpu"), capacity=3, seed=0, engine=DyingEngine(tr, "cpu", 3, 0))
+    try:
+        mitune.run(tr, config=SPACE, num_samples=6, executor=ex, seed=0, verbose=0,
+                   local_dir=os.path.join(out_dir, "exp") if rank == 0 else None, name="rankloss")
+        outcome = "finished"
+    except RankLostError as e:
+        outcome = "rank lost: " + str(e)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(outcome)
+    os._exit(0)                                   # no collective shutdown with a dead peer
+
+
+def test_a_vanished_rank_is_reported_and_the_state_is_left_resumable(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_loss_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    msg = (tmp_path / "rank0.txt").read_text()
+    assert msg.startswith("rank lost: rank 0 of 2: metric exchange after epoch 3"), msg
+    assert not (tmp_path / "rank1.txt").exists()
+    state = json.load(open(tmp_path / "exp" / "rankloss" / "experiment_state.json"))
+    done = [t for t in state["trials"] if t.get("training_iteration", t.get("last_result", {}).get("training_iteration", 0))]
+    assert len(state["trials"]) >= 6 and done
+
+
 # ----------------------------------------------------------------------------------------- data-parallel trials
 def _dp_data(n=512, f=12, seed=3):
     g = torch.Generator().manual_seed(seed)
