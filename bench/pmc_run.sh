@@ -1,15 +1,17 @@
 #!/bin/bash
 # Hardware-counter passes over bench/pmc_target.py, one rocprofv3 run per pass (counters never share a run with
 # system/runtime tracing; each pass stays inside the per-block counter limits).  Run from the repo root on a GPU box.
+# PMC_TARGET=bench/pmc_target_seq.py PMC_TAG=seq selects the sequence-model workload and a separate output directory.
 set -u
 ROOT="$(pwd)"
-OUT="$ROOT/gpurun_out/pmc"
+TARGET="$ROOT/${PMC_TARGET:-bench/pmc_target.py}"
+OUT="$ROOT/gpurun_out/pmc${PMC_TAG:+_$PMC_TAG}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python3 -c "import torch" || exit 1
 run_pass() {
   local name="$1"; shift
-  timeout -s KILL 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "/tmp/pmc_$name" -- python3 "$ROOT/bench/pmc_target.py" 3 \
+  timeout -s KILL 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "/tmp/pmc_$name" -- python3 "$TARGET" 3 \
       > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
   python3 "$ROOT/bench/pmc_summary.py" "/tmp/pmc_$name" > "$OUT/pmc_$name.txt" || return 1
   echo "pass $name ok"
