@@ -54,9 +54,15 @@ def main():
         def own():
             torch.autograd.grad(SmallLinear.apply(x, w, b), (x, w, b), dy)
 
-        f, a, c = bench(fwd), bench(lib), bench(own)
-        print(f"{R:6d} {i:5d} {o:5d} | {a - f:10.1f} | {c - f:8.1f} | {(a - f) / max(c - f, 1e-3):6.2f}   (forward {f:.1f})",
-              flush=True)
+        f, a = bench(fwd), bench(lib)
+        SmallLinear.TILE = 32
+        c32 = bench(own)
+        SmallLinear.TILE = 16
+        c16 = bench(own)
+        SmallLinear.TILE = 0
+        c = bench(own)
+        print(f"{R:6d} {i:5d} {o:5d} | {a - f:10.1f} | {c - f:8.1f} | {(a - f) / max(c - f, 1e-3):6.2f}   (forward {f:.1f}; "
+              f"32x32 tiles {c32 - f:.1f}, 16x16 tiles {c16 - f:.1f})", flush=True)
 
 
 if __name__ == "__main__":

@@ -4,12 +4,11 @@
 
 Small f32 layers (no autocast; at most ``SMALL_MAX_ROWS`` rows and ``in x out <= SMALL_MAX_WEIGHTS`` -- every
 projection of the sequence-regression Transformers at batch 32 x 50 tokens): the backward's three library launches
-(input gradient, weight gradient, bias column sum) become ONE launch of ``mt_small_linear_bwd_launch``
+(input gradient, weight gradient, bias column sum) become ONE launch of ``mt_small_linear_bwd_tiled_launch``
 (``csrc/small_linear.hip``, exact-f32 matrix instructions, sixteen waves per 32x32 tile adding their accumulators
-through LDS in a fixed order; no workspace and no traffic between workgroups).  Measured per backward inside a
-replayed graph (library / fused, us): 800x64x256 61.3 / 10.1, 1600x10x32 20.7 / 15.3, 1600x64x256 29.6 / 15.7,
-1600x128x384 27.6 / 16.5, 1600x128x512 28.6 / 19.7, 3200x64x256 43.9 / 30.3; past the bound the library's larger
-LDS-staged tiles catch up (4800x256x768 76.5 / 74.5, 1600x256x1024 37.1 / 40.4) and keep the layer.
+through LDS in a fixed order; no workspace and no traffic between workgroups).  Measured per backward inside a replayed graph (library / fused, us): 800x64x256 61.5 / 6.4, 1600x10x32 20.5 / 6.6,
+1600x64x256 29.9 / 6.9, 1600x128x384 27.5 / 13.0, 1600x128x512 28.3 / 15.3, 3200x64x256 43.7 / 18.3; past the bound the
+library's larger LDS-staged tiles catch up (4800x256x768 77.1 / 74.4, 1600x256x1024 37.4 / 40.5) and keep the layer.
 
 On a GPU, under bf16 autocast, with a long
 token dimension (FT-Transformer and sequence-encoder layers see M = batch x tokens ~ 10^4..10^5 rows against a few
@@ -21,6 +20,7 @@ gradient stay library GEMMs.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -60,6 +60,8 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 class SmallLinear(torch.autograd.Function):
+    TILE = int(os.environ.get("MITUNE_SMALL_LINEAR_TILE", "0"))   # 0: the launcher chooses 16x16 or 32x32 output tiles by layer size; 16 / 32 force one (tests, ablations)
+
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
@@ -79,10 +81,11 @@ class SmallLinear(torch.autograd.Function):
         dx = torch.empty(R, in_f, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         dw = torch.empty(out_f, in_f, device=dev, dtype=torch.float32)
         db = torch.empty(out_f, device=dev, dtype=torch.float32) if ctx.has_bias else None
-        L.check(so.mt_small_linear_bwd_launch(xc.data_ptr(), weight.data_ptr(), dyc.data_ptr(),
-                                              dx.data_ptr() if dx is not None else None, dw.data_ptr(),
-                                              db.data_ptr() if db is not None else None, R, in_f, out_f, torch.cuda.current_stream(dev).cuda_stream),
-                "mt_small_linear_bwd_launch")
+        L.check(so.mt_small_linear_bwd_tiled_launch(xc.data_ptr(), weight.data_ptr(), dyc.data_ptr(),
+                                                    dx.data_ptr() if dx is not None else None, dw.data_ptr(),
+                                                    db.data_ptr() if db is not None else None, R, in_f, out_f,
+                                                    SmallLinear.TILE, torch.cuda.current_stream(dev).cuda_stream),
+                "mt_small_linear_bwd_tiled_launch")
         return (dx.reshape(x.shape) if dx is not None else None), dw, db
 
 

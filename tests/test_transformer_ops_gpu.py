@@ -202,9 +202,11 @@ def test_in_kernel_dropout_masks_equal_the_materialised_mask():
 @pytest.mark.parametrize("R,in_f,out_f", [(1600, 64, 256), (1600, 256, 64), (1600, 10, 64), (32, 64, 1), (37, 50, 33),
                                           (1600, 128, 384), (3200, 32, 96), (800, 512, 128), (130, 36, 40)])
 @pytest.mark.parametrize("bias", [True, False])
-def test_small_linear_backward_matches_f32_reference(R, in_f, out_f, bias):
+@pytest.mark.parametrize("tile", [16, 32])
+def test_small_linear_backward_matches_f32_reference(R, in_f, out_f, bias, tile, monkeypatch):
     """One launch gives dX, dW and db of a small f32 layer; compared with a float64 product of the same operands."""
     from mitune.ops.linear import SmallLinear
+    monkeypatch.setattr(SmallLinear, "TILE", tile)
     linear = SmallLinear.apply                            # also past the size bound that ``linear`` applies
     g = torch.Generator(device="cuda").manual_seed(R + in_f + out_f)
     x = torch.randn(R // 4, 4, in_f, device="cuda", generator=g).requires_grad_() if R % 4 == 0 else \
