@@ -13,7 +13,10 @@ streams, so the small kernels of several trials are in flight at once (measured 
 Transformer, 25 steps x 4 trials: 65 ms replayed back to back on one stream, 21 ms on four streams; more hardware
 queues than the runtime's default four made it slower, not faster).  Every slot owns its dropout counter, its
 cursor and its loss accumulator, so the interleaving changes no trial's numbers.  Validation of all slots is
-issued the same way and read back with one synchronisation.
+issued the same way and read back with one synchronisation.  In the small-kernel regime a slot's validation pass is
+captured too and replayed right behind its last training step, so an epoch of the whole pack -- training and
+validation of every slot -- is one stretch of asynchronous replays and ONE host synchronisation (eager validation cost
+about 2 ms of host time per slot and epoch with the GPU idle meanwhile).
 
 Concurrent issue is confined to the regime it was built for and verified in: f32 models whose step touches at most
 ``SMALL_STEP_ROWS`` token rows (launch-latency-bound kernels of a few workgroups each).  Packs outside it -- bf16
@@ -45,6 +48,7 @@ SMALL_STEP_ROWS = 4096   # batch x tokens up to which slots are issued concurren
 
 class GraphPackEngine(TorchPackEngine):
     name = "graph"
+    _eval_warmed = False       # the validation pass has run once eagerly in this process (kernel modules loaded)
 
     def __init__(self, trainable, device="cuda", capacity: Optional[int] = None, seed: int = 0):
         super().__init__(trainable, device, capacity, seed)
@@ -53,6 +57,8 @@ class GraphPackEngine(TorchPackEngine):
         self._trainers: Dict[int, GraphedTrainer] = {}
         self._prepared: Dict[int, tuple] = {}          # trial_index -> (config, slot record, trainer), not yet in a slot
         self._pending_epoch = None
+        self._eval_ready = None        # slot -> [3] sums produced by the replays issued with the last training epoch
+        self._eval_graphs = bool(int(trainable.model_kwargs.get("eval_graphs", os.environ.get("MITUNE_EVAL_GRAPHS", 1))))
         self.prepared_total = 0
         n = int(trainable.model_kwargs.get("streams", os.environ.get("MITUNE_GRAPH_STREAMS", DEFAULT_STREAMS)))
         self._streams: List[torch.cuda.Stream] = [torch.cuda.Stream(self.device) for _ in range(max(1, min(n, 32)))]
@@ -82,7 +88,37 @@ class GraphPackEngine(TorchPackEngine):
             s.epoch, s.step = int(state.get("epoch", 0)), int(state.get("step", 0))
         trainer = GraphedTrainer(model, get_criterion(spec.loss_function), self.Xtr, self.ytr, spec.batch_size, s.opt,
                                  shuffle=False, drop_last=True, forward_ctx=self._autocast)
+        self._capture_eval(s, trainer)
         return s, trainer
+
+    # ------------------------------------------------------------------ validation
+    def _eval_into(self, s: _Slot, acc: torch.Tensor) -> None:
+        """Sums of the loss, the squared error and the absolute percentage error over the validation set -> acc[3]."""
+        n = self.Xva.shape[0]
+        was_training = s.model.training
+        s.model.eval()
+        with torch.no_grad():
+            acc.zero_()
+            for c0 in range(0, n, self.t.val_chunk):
+                x, y = self.Xva[c0:c0 + self.t.val_chunk], self.yva[c0:c0 + self.t.val_chunk]
+                with self._autocast():
+                    o = s.model(x)
+                o = o.float().reshape(y.shape)
+                d = o - y
+                acc += torch.stack([elementwise_loss(s.spec.loss_function, o, y).sum(), (d * d).sum(),
+                                    (d.abs() / (y.abs() + MAPE_EPS)).sum()]).double()
+        s.model.train(was_training)
+
+    def _capture_eval(self, s: _Slot, trainer: GraphedTrainer) -> None:
+        trainer.eval_acc = torch.zeros(3, device=self.device, dtype=torch.float64)
+        trainer.eval_graph = None
+        n = self.Xva.shape[0]
+        small = min(n, self.t.val_chunk) * self._tokens_per_sample() <= 4 * SMALL_STEP_ROWS
+        if self.amp or not small or not self._eval_graphs:
+            return
+        trainer.eval_graph = trainer.capture_callable(lambda: self._eval_into(s, trainer.eval_acc),
+                                                      warm=not GraphPackEngine._eval_warmed)
+        GraphPackEngine._eval_warmed = True
 
     def prepare(self, trial_index, config) -> bool:
         """Build and capture a trial that has no slot yet (host work the executor overlaps with a running epoch);
@@ -186,30 +222,41 @@ class GraphPackEngine(TorchPackEngine):
         streams = self._issue_streams(order, max(tr.B for _, tr, _ in plan))
         cur = self._fan_out(streams)
         ns = len(streams)
+        ride = all(tr.eval_graph is not None for _, tr, _ in plan)     # validation rides behind the last step
         if ns == 1:                                   # slot after slot: a slot's working set stays in cache
             for _, tr, batches in plan:
                 for i in range(batches):
                     tr.step_once(i)
+                if ride:
+                    tr.eval_graph.replay()
         else:
-            for i in range(max(b for _, _, b in plan)):
+            for i in range(max(b for _, _, b in plan) + 1):
                 for j, (_, tr, batches) in enumerate(plan):
                     if i < batches:
                         with torch.cuda.stream(streams[j % ns]):
                             tr.step_once(i)
+                    elif i == batches and ride:
+                        with torch.cuda.stream(streams[j % ns]):
+                            tr.eval_graph.replay()
         self._fan_in(cur, streams)
-        self._pending_epoch = (plan, torch.stack([tr.epoch_loss(b) for _, tr, b in plan]))
+        parts = [torch.stack([tr.epoch_loss(b) for _, tr, b in plan]).double()]
+        if ride:
+            parts.append(torch.stack([tr.eval_acc for _, tr, _ in plan]).reshape(-1))
+        self._pending_epoch = (plan, torch.cat(parts), ride, order)
 
     def train_epoch_end(self):
         """Wait for the issued epoch and book its losses."""
         if self._pending_epoch is None:
             return
-        plan, stacked = self._pending_epoch
+        plan, stacked, ride, order = self._pending_epoch
         self._pending_epoch = None
-        losses = stacked.tolist()                                                    # one synchronisation
-        for (s, tr, batches), loss in zip(plan, losses):
+        vals = stacked.tolist()                                                      # one synchronisation
+        for (s, tr, batches), loss in zip(plan, vals):
             s.train_loss = loss
             s.step += batches
             s.epoch += 1
+        k = len(plan)
+        self._eval_ready = {slot: vals[k + 3 * j:k + 3 * j + 3] for j, slot in enumerate(order)} if ride else None
 
     @torch.no_grad()
     def evaluate(self):
@@ -217,24 +264,24 @@ class GraphPackEngine(TorchPackEngine):
         if not order:
             return {}
         n = self.Xva.shape[0]
-        acc = torch.zeros(len(order), 3, device=self.device, dtype=torch.float64)      # loss, squared error, APE sums
-        streams = self._issue_streams(order, min(n, self.t.val_chunk), 4 * SMALL_STEP_ROWS)
-        cur = self._fan_out(streams)
-        ns = len(streams)
-        for j, slot in enumerate(order):
-            s = self.slots[slot]
-            s.model.eval()
-            with torch.cuda.stream(streams[j % ns]):
-                for c0 in range(0, n, self.t.val_chunk):
-                    x, y = self.Xva[c0:c0 + self.t.val_chunk], self.yva[c0:c0 + self.t.val_chunk]
-                    with self._autocast():
-                        o = s.model(x)
-                    o = o.float().reshape(y.shape)
-                    d = o - y
-                    acc[j] += torch.stack([elementwise_loss(s.spec.loss_function, o, y).sum(), (d * d).sum(),
-                                           (d.abs() / (y.abs() + MAPE_EPS)).sum()]).double()
-        self._fan_in(cur, streams)
-        rows = acc.tolist()                                                            # one synchronisation
+        ready, self._eval_ready = self._eval_ready, None
+        if ready is not None and sorted(ready) == order:        # produced by the replays behind the last training epoch
+            rows = [ready[slot] for slot in order]
+        else:
+            acc = torch.zeros(len(order), 3, device=self.device, dtype=torch.float64)  # loss, squared error, APE sums
+            streams = self._issue_streams(order, min(n, self.t.val_chunk), 4 * SMALL_STEP_ROWS)
+            cur = self._fan_out(streams)
+            ns = len(streams)
+            for j, slot in enumerate(order):
+                tr = self._trainers[slot]
+                with torch.cuda.stream(streams[j % ns]):
+                    if tr.eval_graph is not None:
+                        tr.eval_graph.replay()
+                        acc[j].copy_(tr.eval_acc)
+                    else:
+                        self._eval_into(self.slots[slot], acc[j])
+            self._fan_in(cur, streams)
+            rows = acc.tolist()                                                        # one synchronisation
         return {slot: {"train_loss": self.slots[slot].train_loss, "validation_loss": r[0] / n,
                        "validation_mse": r[1] / n, "validation_mape": 100.0 * r[2] / n}
                 for slot, r in zip(order, rows)}

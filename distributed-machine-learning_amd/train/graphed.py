@@ -278,6 +278,35 @@ class GraphedTrainer:
         o.finish_capture()
         self.graph = g
 
+    def capture_callable(self, fn: Callable[[], None], warm: bool = False) -> Optional["torch.cuda.CUDAGraph"]:
+        """Capture ``fn()`` (device work only, fixed addresses) into a hipGraph on a side stream; None if graphs are off
+        or the capture fails.  ``warm`` runs it once eagerly first (first use of its kernels in the process)."""
+        if self.graph is None:
+            return None
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        try:
+            if warm:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    fn()
+                cur.wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with _CAPTURE_LOCK:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    g.capture_begin(capture_error_mode="thread_local")
+                    try:
+                        fn()
+                    finally:
+                        g.capture_end()
+                cur.wait_stream(side)
+            return g
+        except Exception as e:       # noqa: BLE001 - the caller keeps its eager path
+            log.warning("hipGraph capture of an auxiliary pass failed (%s: %s); it stays eager", type(e).__name__, e)
+            torch.cuda.synchronize(self.X.device)
+            return None
+
     # ------------------------------------------------------------------ epochs
     def begin_epoch(self) -> int:
         """Shuffle, rewind the cursor; returns how many ``step_once`` calls make up the epoch."""
