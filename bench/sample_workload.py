@@ -80,7 +80,9 @@ def main():
                       "elapsed_s": el, "trials_per_hour": len(an.trials) / el * 3600.0,
                       "best_validation_loss": an.best_result["validation_loss"],
                       "trial_seconds_min_med_max": [per[0], per[len(per) // 2], per[-1]],
-                      "epochs_run": sum(t.training_iteration for t in an.trials)}))
+                      "epochs_run": sum(t.training_iteration for t in an.trials),
+                      "executor": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in an.stats.items()
+                                   if k in ("train_s", "eval_s", "comm_s", "epochs", "slot_epochs", "prepared_ahead", "engine")}}))
 
 
 if __name__ == "__main__":

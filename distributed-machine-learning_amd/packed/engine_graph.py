@@ -57,6 +57,7 @@ class GraphPackEngine(TorchPackEngine):
         self._trainers: Dict[int, GraphedTrainer] = {}
         self._prepared: Dict[int, tuple] = {}          # trial_index -> (config, slot record, trainer), not yet in a slot
         self._pending_epoch = None
+        self._prep_stream = torch.cuda.Stream(self.device)
         self._eval_ready = None        # slot -> [3] sums produced by the replays issued with the last training epoch
         self._eval_graphs = bool(int(trainable.model_kwargs.get("eval_graphs", os.environ.get("MITUNE_EVAL_GRAPHS", 1))))
         self.prepared_total = 0
@@ -86,8 +87,14 @@ class GraphPackEngine(TorchPackEngine):
                 except (ValueError, KeyError, TypeError):
                     pass       # another optimiser family or layout: fresh moments
             s.epoch, s.step = int(state.get("epoch", 0)), int(state.get("step", 0))
+        merged = {**self.t.model_kwargs, **config}
+        signature = (self.t.model if isinstance(self.t.model, str) else id(self.t.model), self.amp, spec.batch_size,
+                     spec.optimizer, spec.loss_function, spec.gradient_clipping > 0, tuple(self.Xtr.shape[1:]),
+                     tuple(tuple(p.shape) for p in flat.params),
+                     tuple(sorted((k, v if isinstance(v, (str, bool)) else v > 0) for k, v in merged.items()
+                                  if isinstance(v, (str, bool, int, float)))))
         trainer = GraphedTrainer(model, get_criterion(spec.loss_function), self.Xtr, self.ytr, spec.batch_size, s.opt,
-                                 shuffle=False, drop_last=True, forward_ctx=self._autocast)
+                                 shuffle=False, drop_last=True, forward_ctx=self._autocast, signature=signature)
         self._capture_eval(s, trainer)
         return s, trainer
 
@@ -127,7 +134,10 @@ class GraphPackEngine(TorchPackEngine):
             return True         # already waiting for its slot
         if len(self._prepared) >= self.capacity:
             return False
-        self._prepared[int(trial_index)] = (dict(config),) + self._make(trial_index, config)
+        # on a stream of its own: the host-to-device copies of a new model wait for the work queued before them on
+        # their stream, and on the main stream that is the whole running epoch
+        with torch.cuda.stream(self._prep_stream):
+            self._prepared[int(trial_index)] = (dict(config),) + self._make(trial_index, config)
         self.prepared_total += 1
         return True
 
@@ -209,6 +219,7 @@ class GraphPackEngine(TorchPackEngine):
         self._pending_epoch = None
         if not order:
             return
+        torch.cuda.current_stream(self.device).wait_stream(self._prep_stream)     # trials prepared ahead are complete
         n = self.Xtr.shape[0]
         plan = []
         for slot in order:

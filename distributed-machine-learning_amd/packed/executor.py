@@ -81,7 +81,8 @@ class PackedExecutor(Executor):
         self._queued: List[Event] = []
         self._awaiting: Dict[str, Optional[str]] = {}          # trial_id -> decision (None = not yet)
         self._epoch_time = 0.0
-        self._gpu_epoch_s = 0.0            # duration of the last training epoch (issue to completion)
+        self._retired_last = 0             # slots freed by the previous round's decisions
+        self._retired_now = 0
         self._n_undecided = 0
         self._hostname = socket.gethostname()
         self._diverged: set = set()
@@ -151,7 +152,6 @@ class PackedExecutor(Executor):
         self.stats["epochs"] += 1
         self.stats["slot_epochs"] += len(local)
         self.stats["train_s"] += t1 - t0
-        self._gpu_epoch_s = t1 - t0
         self.stats["prepared_ahead"] = getattr(self.engine, "prepared_total", 0)
         self.stats["eval_s"] += t2 - t1
         self.stats["comm_s"] += t3 - t2
@@ -198,18 +198,23 @@ class PackedExecutor(Executor):
         return events
 
     def _prefetch(self, t_issue: float) -> None:
-        """Prepare upcoming trials while the issued epoch runs: for as long as the previous epoch's GPU time suggests
-        the device stays busy, and never more than one pack's worth.  Only trials the runner can name in advance
-        without changing the search (already pending, or drawn from a searcher that does not look at results)."""
-        budget = 0.8 * self._gpu_epoch_s
-        if budget <= 0.0:
+        """Prepare upcoming trials while the issued epoch runs.  As many as are likely to get a slot when this epoch
+        ends: the trials that reach ``max_epochs`` now, or as many as the previous round retired, whichever is more.
+        That work has to be done before the next epoch anyway; done here it overlaps with the GPU instead of following
+        it.  Only trials the runner can name in advance without changing the search (already pending, or drawn from a
+        searcher that does not look at results)."""
+        sure = sum(1 for tr in self._live.values() if tr.training_iteration + 1 >= self.t.max_epochs)
+        want = min(self.capacity, max(sure, self._retired_last))
+        if want <= 0:
             return
-        for tr in self.runner.lookahead(self.capacity):
-            if time.time() - t_issue >= budget:
-                break
+        done = 0
+        for tr in self.runner.lookahead(want):
             if tr.restore_from is not None or tr.start_time is not None:
                 continue                              # resumes from a state: built when it gets its slot
             if not self.engine.prepare(tr.index, tr.config):
+                break
+            done += 1
+            if done >= want:
                 break
 
     def resolve(self, trial: Trial, decision: str) -> None:
@@ -237,6 +242,7 @@ class PackedExecutor(Executor):
                 self._retire(tr)
             elif self.t.checkpoint_freq and tr.training_iteration % self.t.checkpoint_freq == 0:
                 self._checkpoint(tr)
+        self._retired_last, self._retired_now = self._retired_now, 0
 
     def _checkpoint(self, tr: Trial) -> None:
         owner, slot = self._place[tr.trial_id]
@@ -267,6 +273,7 @@ class PackedExecutor(Executor):
         self._free[owner].append(slot)
         self._free[owner].sort()
         self._live.pop(tr.trial_id)
+        self._retired_now += 1
         self._queued.append(Event("done", tr, result={"decision": STOP}))
 
     def _exploit(self, tr: Trial) -> None:

@@ -39,6 +39,22 @@ _CAPTURE_LOCK = threading.Lock()
 # device work issued from sibling threads, so such trials step eagerly (each on its own stream) instead.
 SHARED_GPU_THREADS = False
 
+# Signatures whose kernels have all run once in this process, and ONE stream per device on which every warm-up and
+# capture is issued: the BLAS library keeps a workspace per (handle, stream), and on a stream that already has one a
+# capture never allocates it from a graph's private pool.
+_WARMED: set = set()
+_CAPTURE_STREAMS: Dict = {}
+
+
+def _capture_stream(device) -> "torch.cuda.Stream":
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _CAPTURE_STREAMS.get(key)
+    if st is None:
+        st = _CAPTURE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 _ALIGN = 8        # parameter offsets in the slab are multiples of 8 floats (32 bytes)
 _SEG = 2048       # elements per optimiser block / gradient-table segment
 
@@ -197,7 +213,12 @@ class GraphedTrainer:
 
     def __init__(self, model: torch.nn.Module, criterion: Callable, X: torch.Tensor, Y: torch.Tensor, batch_size: int,
                  optimizer: FlatOptimizer, shuffle: bool = True, seed: int = 0, use_graph: bool = True,
-                 drop_last: bool = False, forward_ctx: Optional[Callable] = None):
+                 drop_last: bool = False, forward_ctx: Optional[Callable] = None, signature=None):
+        """``signature``: a hashable description of everything that decides WHICH kernels a step launches (model family,
+        parameter shapes, batch, optimiser, loss, which regularisers are active).  The first trainer of a signature runs
+        one eager step before capturing (lazy initialisation must not happen inside a capture); later ones capture
+        straight away.  None: always warm up."""
+        self.signature = signature
         self.model, self.criterion, self.opt = model, criterion, optimizer
         self.drop_last = drop_last
         self.forward_ctx = forward_ctx or contextlib.nullcontext      # e.g. a bf16 autocast factory
@@ -247,21 +268,22 @@ class GraphedTrainer:
 
     def _capture(self) -> None:
         f, o = self.opt.flat, self.opt
-        keep = (f.P.clone(), o.M.clone(), o.V.clone(), o.state.clone(), None if self.rng is None else self.rng.ctr.clone())
         cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
+        side = _capture_stream(self.X.device)
         self.model.train()
-        with torch.cuda.stream(side):          # warm-up off the caller's stream (allocator, lazy init, library workspaces)
-            self.pos.zero_()
-            self._cursor_step()
-        cur.wait_stream(side)
-        with torch.no_grad():                  # undo the warm-up steps: training starts from the initial weights
-            f.P.copy_(keep[0]); o.M.copy_(keep[1]); o.V.copy_(keep[2]); o.state.copy_(keep[3])
-            o.zero_grad(); self.pos.zero_(); self.running.zero_()
-            if self.rng is not None:
-                self.rng.ctr.copy_(keep[4])
-        cur.synchronize()                      # stream-level only: a device-wide wait would disturb other threads
+        if self.signature is None or self.signature not in _WARMED:
+            keep = (f.P.clone(), o.M.clone(), o.V.clone(), o.state.clone(),
+                    None if self.rng is None else self.rng.ctr.clone())
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):      # warm-up off the caller's stream (allocator, lazy init, library workspaces)
+                self.pos.zero_()
+                self._cursor_step()
+            cur.wait_stream(side)
+            with torch.no_grad():              # undo the warm-up step: training starts from the initial weights
+                f.P.copy_(keep[0]); o.M.copy_(keep[1]); o.V.copy_(keep[2]); o.state.copy_(keep[3])
+                o.zero_grad(); self.pos.zero_(); self.running.zero_()
+                if self.rng is not None:
+                    self.rng.ctr.copy_(keep[4])
         g = torch.cuda.CUDAGraph()
         # Raw capture_begin / capture_end on the warm-up stream: the torch.cuda.graph context would first synchronise the
         # device, run the Python garbage collector and empty the allocator cache -- tens of milliseconds per trial that a
@@ -277,6 +299,8 @@ class GraphedTrainer:
             cur.wait_stream(side)
         o.finish_capture()
         self.graph = g
+        if self.signature is not None:
+            _WARMED.add(self.signature)
 
     def capture_callable(self, fn: Callable[[], None], warm: bool = False) -> Optional["torch.cuda.CUDAGraph"]:
         """Capture ``fn()`` (device work only, fixed addresses) into a hipGraph on a side stream; None if graphs are off
@@ -284,7 +308,7 @@ class GraphedTrainer:
         if self.graph is None:
             return None
         cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
+        side = _capture_stream(self.X.device)
         try:
             if warm:
                 side.wait_stream(cur)
