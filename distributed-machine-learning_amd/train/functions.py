@@ -122,8 +122,13 @@ def _fit_graphed(model, config: Dict, data_loader, val_loader, epochs: int, crit
     start = _resume(model, opt)
     opt.set_hyper(lr, weight_decay)           # PBT may have perturbed these since the checkpoint was taken
     bs = int(getattr(data_loader, "batch_size", None) or 32)
+    signature = (type(model).__name__, getattr(criterion, "__name__", type(criterion).__name__), opt_name, bs, clip > 0,
+                 tuple(train_t[0].shape[1:]), tuple(tuple(p.shape) for p in flat.params),
+                 tuple(sorted((k, v if isinstance(v, (str, bool)) else v > 0) for k, v in config.items()
+                              if isinstance(v, (str, bool, int, float)))))
     trainer = GraphedTrainer(model, criterion, train_t[0], train_t[1], bs, opt, shuffle=True,
-                             seed=int(config.get("seed", 0)), use_graph=bool(config.get("hip_graph", True)))
+                             seed=int(config.get("seed", 0)), use_graph=bool(config.get("hip_graph", True)),
+                             signature=signature)
     for epoch in range(start, epochs):
         train_loss = trainer.train_epoch()
         metrics = trainer.evaluate(val_t[0], val_t[1], mape_eps=MAPE_EPS)
