@@ -17,6 +17,11 @@ SHAPES = [(1600, 10, 32), (1600, 32, 96), (1600, 32, 128), (1600, 128, 32), (160
           (800, 64, 256), (4800, 256, 768), (1600, 256, 1024)]
 
 
+class _Ctx:
+    def save_for_backward(self, *a):
+        pass
+
+
 def bench(fn, reps=20, iters=20):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
@@ -48,12 +53,19 @@ def main():
             with torch.no_grad():
                 F.linear(x, w, b)
 
+        def fwd_own():
+            with torch.no_grad():
+                SmallLinear.forward(_Ctx(), x, w, b)
+
         def lib():
             torch.autograd.grad(F.linear(x, w, b), (x, w, b), dy)
 
         def own():
             torch.autograd.grad(SmallLinear.apply(x, w, b), (x, w, b), dy)
 
+        SmallLinear.OWN_FORWARD = True
+        f_own = bench(fwd_own)
+        SmallLinear.OWN_FORWARD = False          # backward columns: both sides on the library forward
         f, a = bench(fwd), bench(lib)
         SmallLinear.TILE = 32
         c32 = bench(own)
@@ -62,7 +74,7 @@ def main():
         SmallLinear.TILE = 0
         c = bench(own)
         print(f"{R:6d} {i:5d} {o:5d} | {a - f:10.1f} | {c - f:8.1f} | {(a - f) / max(c - f, 1e-3):6.2f}   (forward {f:.1f}; "
-              f"32x32 tiles {c32 - f:.1f}, 16x16 tiles {c16 - f:.1f})", flush=True)
+              f"32x32 tiles {c32 - f:.1f}, 16x16 tiles {c16 - f:.1f}; own forward {f_own:.1f})", flush=True)
 
 
 if __name__ == "__main__":

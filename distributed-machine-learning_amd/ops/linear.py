@@ -56,17 +56,52 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         return SplitKLinear.apply(x, weight, bias)
     if _small_eligible(x, weight, bias):
         return SmallLinear.apply(x, weight, bias)
+    if _small_inference(x, weight, bias):
+        return SmallLinear.forward(_NoCtx(), x, weight, bias)
     return F.linear(x, weight, bias)
+
+
+class _NoCtx:
+    def save_for_backward(self, *a):
+        pass
+
+
+def _small_inference(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
+    """The same small f32 layers when no gradient is recorded (validation passes): the forward kernel alone."""
+    if torch.is_grad_enabled() or not x.is_cuda or torch.is_autocast_enabled() or not SmallLinear.OWN_FORWARD:
+        return False
+    if x.dtype != torch.float32 or weight.dtype != torch.float32 or (bias is not None and bias.dtype != torch.float32):
+        return False
+    out_f, in_f = weight.shape
+    rows = x.numel() // max(in_f, 1)
+    return 0 < rows <= 4 * SMALL_MAX_ROWS and in_f * out_f <= SMALL_MAX_WEIGHTS
 
 
 class SmallLinear(torch.autograd.Function):
     TILE = int(os.environ.get("MITUNE_SMALL_LINEAR_TILE", "0"))   # 0: the launcher chooses 16x16 or 32x32 output tiles by layer size; 16 / 32 force one (tests, ablations)
 
+    # The forward has a kernel of the same family too (mt_small_linear_fwd_launch), OFF by default: measured against the
+    # library GEMM it is slower alone (1600x64x256: 7.5 vs 4.2 us, 1600x128x512: 11.0 vs 5.8 us) and, with its
+    # 1024-thread workgroups, it nearly halves what four concurrently replayed trials gain (step 110 -> 196 us).
+    OWN_FORWARD = bool(int(os.environ.get("MITUNE_SMALL_LINEAR_FWD", "0")))
+
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        if not SmallLinear.OWN_FORWARD:
+            return F.linear(x, weight, bias)
+        from . import lib as L
+        so = L.load()
+        out_f, in_f = weight.shape
+        xc = x.reshape(-1, in_f).contiguous()
+        wc = weight.contiguous()
+        y = torch.empty(xc.shape[0], out_f, device=x.device, dtype=torch.float32)
+        L.check(so.mt_small_linear_fwd_launch(xc.data_ptr(), wc.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                              y.data_ptr(), xc.shape[0], in_f, out_f, 0,
+                                              torch.cuda.current_stream(x.device).cuda_stream),
+                "mt_small_linear_fwd_launch")
+        return y.view(x.shape[:-1] + (out_f,))
 
     @staticmethod
     def backward(ctx, dy):

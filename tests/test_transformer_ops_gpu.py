@@ -236,6 +236,40 @@ def test_small_linear_backward_matches_f32_reference(R, in_f, out_f, bias, tile,
     assert torch.equal(w.grad, first)
 
 
+@pytest.mark.parametrize("R,in_f,out_f", [(1600, 64, 256), (1600, 256, 64), (1600, 10, 64), (32, 64, 1), (37, 50, 33),
+                                          (1600, 128, 384), (800, 512, 128), (130, 260, 40), (10000, 64, 192)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_small_linear_forward_matches_f32_reference(R, in_f, out_f, bias):
+    from mitune.ops import lib as L
+    so = L.load()
+    g = torch.Generator(device="cuda").manual_seed(R + in_f)
+    x = torch.randn(R, in_f, device="cuda", generator=g)
+    w = torch.randn(out_f, in_f, device="cuda", generator=g) * in_f ** -0.5
+    b = torch.randn(out_f, device="cuda", generator=g) if bias else None
+    for relu in (0, 1):
+        y = torch.full((R, out_f), float("nan"), device="cuda")
+        L.check(so.mt_small_linear_fwd_launch(x.data_ptr(), w.data_ptr(), b.data_ptr() if bias else None, y.data_ptr(), R, in_f,
+                                              out_f, relu, torch.cuda.current_stream().cuda_stream), "fwd")
+        ref = x.double() @ w.double().t() + (b.double() if bias else 0)
+        ref = ref.clamp_min(0) if relu else ref
+        assert torch.allclose(y.double(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_small_linear_forward_kernel_can_serve_training_and_validation_passes(monkeypatch):
+    from mitune.ops.linear import SmallLinear, linear
+    monkeypatch.setattr(SmallLinear, "OWN_FORWARD", True)
+    x = torch.randn(4, 50, 32, device="cuda", requires_grad=True)
+    w = torch.randn(48, 32, device="cuda", requires_grad=True)
+    b = torch.randn(48, device="cuda", requires_grad=True)
+    y = linear(x, w, b)
+    assert y.shape == (4, 50, 48) and "SmallLinear" in type(y.grad_fn).__name__
+    ref = torch.nn.functional.linear(x, w, b)
+    assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4)
+    with torch.no_grad():
+        z = linear(x, w, b)
+    assert z.grad_fn is None and torch.equal(z, y.detach())
+
+
 def test_small_linear_is_not_used_under_autocast_or_for_large_layers():
     from mitune.ops.linear import linear
     x = torch.randn(64, 32, device="cuda", requires_grad=True)
