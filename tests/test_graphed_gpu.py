@@ -364,6 +364,8 @@ def test_sequence_trials_issued_over_streams_equal_issue_on_one_stream():
             assert a[k]["validation_loss"] == pytest.approx(b[k]["validation_loss"], rel=2e-3)
             assert a[k]["train_loss"] == pytest.approx(b[k]["train_loss"], rel=2e-3)
     assert multi[-1][0]["validation_loss"] < multi[0][0]["validation_loss"] * 1.5
+    _, again = _sequence_pack(4)                          # concurrent replays share nothing: bitwise repeatable
+    assert again == multi
 
 
 def test_bf16_or_long_token_packs_stay_on_one_stream():
