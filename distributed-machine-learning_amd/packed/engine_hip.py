@@ -184,8 +184,10 @@ class HipPackEngine(PackEngine):
         # separate HIP streams.  One host thread cannot feed several chains kernel by kernel (a launch costs ~3.5 us
         # of host time), so each chain's steps are captured in blocks of GRAPH_STEPS as a hipGraph that reads its step
         # number from a device counter and is replayed block after block.  OFF by default ("streams": n or
-        # MITUNE_STREAMS=n enables it): on the machines measured, kernels of different streams did not overlap
-        # (rocprofv3 trace: overlap factor 1.03 with four chains), so splitting only shrank the launches.
+        # MITUNE_STREAMS=n enables it): measured wall-clock on the 256-trial search, 7.40 s with one chain, 7.86 s with
+        # three and 8.03 s with four -- the grouped launches of even a 16-trial pack are wide enough that splitting them
+        # only adds launches.  (Kernels of a few workgroups each, as in small Transformer trials, do overlap across
+        # streams; packed/engine_graph.py uses that.)
         self._streams = [torch.cuda.Stream(device=dev) for _ in range(MAX_STREAMS)]
         self._counters = torch.zeros(MAX_STREAMS, device=dev, dtype=torch.int32)
         self._chain_scratch = [torch.zeros_like(self.head_scratch) for _ in range(MAX_STREAMS - 1)]
