@@ -30,6 +30,7 @@ of the receiving slot stays valid because it only holds pointers.
 from __future__ import annotations
 
 import os
+import threading
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -48,7 +49,7 @@ SMALL_STEP_ROWS = 4096   # batch x tokens up to which slots are issued concurren
 
 class GraphPackEngine(TorchPackEngine):
     name = "graph"
-    _eval_warmed = False       # the validation pass has run once eagerly in this process (kernel modules loaded)
+    _eval_warmed: set = set()  # threads on which a validation pass has run once eagerly (kernel modules, BLAS handle)
 
     def __init__(self, trainable, device="cuda", capacity: Optional[int] = None, seed: int = 0):
         super().__init__(trainable, device, capacity, seed)
@@ -124,8 +125,8 @@ class GraphPackEngine(TorchPackEngine):
         if self.amp or not small or not self._eval_graphs:
             return
         trainer.eval_graph = trainer.capture_callable(lambda: self._eval_into(s, trainer.eval_acc),
-                                                      warm=not GraphPackEngine._eval_warmed)
-        GraphPackEngine._eval_warmed = True
+                                                      warm=threading.get_ident() not in GraphPackEngine._eval_warmed)
+        GraphPackEngine._eval_warmed.add(threading.get_ident())
 
     def prepare(self, trial_index, config) -> bool:
         """Build and capture a trial that has no slot yet (host work the executor overlaps with a running epoch);

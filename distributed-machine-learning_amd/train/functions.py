@@ -130,9 +130,8 @@ def _fit_graphed(model, config: Dict, data_loader, val_loader, epochs: int, crit
                              seed=int(config.get("seed", 0)), use_graph=bool(config.get("hip_graph", True)),
                              signature=signature)
     for epoch in range(start, epochs):
-        train_loss = trainer.train_epoch()
-        metrics = trainer.evaluate(val_t[0], val_t[1], mape_eps=MAPE_EPS)
-        metrics["train_loss"] = train_loss
+        metrics = trainer.epoch_with_validation(val_t[0], val_t[1], mape_eps=MAPE_EPS)
+        train_loss = metrics["train_loss"]
         metrics["graphed"] = trainer.graphed
         log.info("epoch %d  train_loss %.5f  validation_loss %.5f", epoch + 1, train_loss, metrics["validation_loss"])
         ckpt = None

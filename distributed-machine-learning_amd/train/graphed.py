@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import gc
 import logging
 import threading
 from typing import Callable, Dict, Optional
@@ -39,11 +40,25 @@ _CAPTURE_LOCK = threading.Lock()
 # device work issued from sibling threads, so such trials step eagerly (each on its own stream) instead.
 SHARED_GPU_THREADS = False
 
-# Signatures whose kernels have all run once in this process, and ONE stream per device on which every warm-up and
+# (thread, signature) pairs whose kernels have all run once on that thread, and ONE stream per device on which every warm-up and
 # capture is issued: the BLAS library keeps a workspace per (handle, stream), and on a stream that already has one a
 # capture never allocates it from a graph's private pool.
 _WARMED: set = set()
 _CAPTURE_STREAMS: Dict = {}
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """No cyclic garbage collection while a stream is capturing: a collection may destroy the graph of a trainer that
+    died earlier, and destroying a graph (or releasing its memory pool) inside a capture aborts the process.  (The
+    framework's own capture context collects *before* every capture instead, which costs milliseconds per trial.)"""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def _capture_stream(device) -> "torch.cuda.Stream":
@@ -271,7 +286,9 @@ class GraphedTrainer:
         cur = torch.cuda.current_stream()
         side = _capture_stream(self.X.device)
         self.model.train()
-        if self.signature is None or self.signature not in _WARMED:
+        # per thread: BLAS handles are per thread, and a handle's first use must not fall inside a capture
+        warm_key = (threading.get_ident(), self.signature)
+        if self.signature is None or warm_key not in _WARMED:
             keep = (f.P.clone(), o.M.clone(), o.V.clone(), o.state.clone(),
                     None if self.rng is None else self.rng.ctr.clone())
             side.wait_stream(cur)
@@ -288,7 +305,7 @@ class GraphedTrainer:
         # Raw capture_begin / capture_end on the warm-up stream: the torch.cuda.graph context would first synchronise the
         # device, run the Python garbage collector and empty the allocator cache -- tens of milliseconds per trial that a
         # search over hundreds of sub-second trials pays again and again (and every trial after it re-mallocs).
-        with _CAPTURE_LOCK:
+        with _CAPTURE_LOCK, _no_gc():
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 g.capture_begin(capture_error_mode="thread_local")
@@ -300,7 +317,7 @@ class GraphedTrainer:
         o.finish_capture()
         self.graph = g
         if self.signature is not None:
-            _WARMED.add(self.signature)
+            _WARMED.add(warm_key)
 
     def capture_callable(self, fn: Callable[[], None], warm: bool = False) -> Optional["torch.cuda.CUDAGraph"]:
         """Capture ``fn()`` (device work only, fixed addresses) into a hipGraph on a side stream; None if graphs are off
@@ -316,7 +333,7 @@ class GraphedTrainer:
                     fn()
                 cur.wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with _CAPTURE_LOCK:
+            with _CAPTURE_LOCK, _no_gc():
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     g.capture_begin(capture_error_mode="thread_local")
@@ -363,18 +380,47 @@ class GraphedTrainer:
         return float(self.epoch_loss(batches))
 
     @torch.no_grad()
-    def evaluate(self, Xv: torch.Tensor, Yv: torch.Tensor, chunk: int = 4096, mape_eps: float = 1e-8) -> Dict[str, float]:
-        """Sample-weighted validation loss and MAPE over the whole validation set in large chunks."""
+    def _validation_sums(self, Xv: torch.Tensor, Yv: torch.Tensor, chunk: int, mape_eps: float, out2: torch.Tensor) -> None:
+        """[sum of per-sample losses, sum of absolute percentage errors] over the validation set -> ``out2`` (f64)."""
+        was_training = self.model.training
         self.model.eval()
         n = int(Xv.shape[0])
-        loss_sum = torch.zeros((), device=Xv.device, dtype=torch.float64)
-        ape_sum = torch.zeros((), device=Xv.device, dtype=torch.float64)
+        out2.zero_()
         for c0 in range(0, n, chunk):
             x, y = Xv[c0:c0 + chunk], Yv[c0:c0 + chunk]
             with self.forward_ctx():
                 out = self.model(x)
             out = out.float().reshape(y.shape)
-            loss_sum += self.criterion(out, y).double() * y.numel()
-            ape_sum += (torch.abs(y - out) / (torch.abs(y) + mape_eps)).sum().double()
-        both = torch.stack([loss_sum, ape_sum]).tolist()       # one synchronisation
+            out2 += torch.stack([self.criterion(out, y).double() * y.numel(),
+                                 (torch.abs(y - out) / (torch.abs(y) + mape_eps)).sum().double()])
+        self.model.train(was_training)
+
+    def evaluate(self, Xv: torch.Tensor, Yv: torch.Tensor, chunk: int = 4096, mape_eps: float = 1e-8) -> Dict[str, float]:
+        """Sample-weighted validation loss and MAPE over the whole validation set in large chunks."""
+        n = int(Xv.shape[0])
+        acc = torch.zeros(2, device=Xv.device, dtype=torch.float64)
+        self._validation_sums(Xv, Yv, chunk, mape_eps, acc)
+        both = acc.tolist()                                    # one synchronisation
         return {"validation_loss": both[0] / max(n, 1), "validation_mape": 100.0 * both[1] / max(n, 1)}
+
+    def epoch_with_validation(self, Xv: torch.Tensor, Yv: torch.Tensor, chunk: int = 4096,
+                              mape_eps: float = 1e-8) -> Dict[str, float]:
+        """One training epoch followed by the validation pass, read back with ONE synchronisation.  With graphs on, the
+        validation pass over a small set is captured at the first call and replayed behind the last training step."""
+        n = int(Xv.shape[0])
+        key = (Xv.data_ptr(), Yv.data_ptr(), n, chunk)
+        if getattr(self, "_val_key", None) != key:
+            self._val_key, self._val_acc = key, torch.zeros(2, device=Xv.device, dtype=torch.float64)
+            self._val_graph = None
+            if self.graph is not None and min(n, chunk) * max(1, Xv[0].numel() // max(1, Xv.shape[-1])) <= 16384:
+                self._val_graph = self.capture_callable(
+                    lambda: self._validation_sums(Xv, Yv, chunk, mape_eps, self._val_acc), warm=True)
+        batches = self.begin_epoch()
+        for i in range(batches):
+            self.step_once(i)
+        if self._val_graph is not None:
+            self._val_graph.replay()
+        else:
+            self._validation_sums(Xv, Yv, chunk, mape_eps, self._val_acc)
+        vals = torch.cat([self.epoch_loss(batches).double().reshape(1), self._val_acc]).tolist()
+        return {"train_loss": vals[0], "validation_loss": vals[1] / max(n, 1), "validation_mape": 100.0 * vals[2] / max(n, 1)}

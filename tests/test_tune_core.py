@@ -3,6 +3,8 @@ import math
 import os
 
 import numpy as np
+import time
+
 import pytest
 from hypothesis import given, settings, strategies as st
 
@@ -373,6 +375,7 @@ def test_pbt_with_function_trainables_restarts_from_donor_checkpoint():
         seen.append((round(config["lr"], 6), start))
         for i in range(start, 8):
             w += config["lr"]
+            time.sleep(0.02)                                 # both trial threads advance side by side on a loaded box
             tune.report(score=w, checkpoint={"w": w, "it": i + 1})
 
     pbt = PopulationBasedTraining(metric="score", mode="max", perturbation_interval=2,
