@@ -49,7 +49,7 @@ SMALL_STEP_ROWS = 4096   # batch x tokens up to which slots are issued concurren
 
 class GraphPackEngine(TorchPackEngine):
     name = "graph"
-    _eval_warmed: set = set()  # threads on which a validation pass has run once eagerly (kernel modules, BLAS handle)
+    _eval_warmed = threading.local()   # .done on threads where a validation pass has run once eagerly
 
     def __init__(self, trainable, device="cuda", capacity: Optional[int] = None, seed: int = 0):
         super().__init__(trainable, device, capacity, seed)
@@ -125,8 +125,8 @@ class GraphPackEngine(TorchPackEngine):
         if self.amp or not small or not self._eval_graphs:
             return
         trainer.eval_graph = trainer.capture_callable(lambda: self._eval_into(s, trainer.eval_acc),
-                                                      warm=threading.get_ident() not in GraphPackEngine._eval_warmed)
-        GraphPackEngine._eval_warmed.add(threading.get_ident())
+                                                      warm=not getattr(GraphPackEngine._eval_warmed, "done", False))
+        GraphPackEngine._eval_warmed.done = True
 
     def prepare(self, trial_index, config) -> bool:
         """Build and capture a trial that has no slot yet (host work the executor overlaps with a running epoch);

@@ -40,10 +40,18 @@ _CAPTURE_LOCK = threading.Lock()
 # device work issued from sibling threads, so such trials step eagerly (each on its own stream) instead.
 SHARED_GPU_THREADS = False
 
-# (thread, signature) pairs whose kernels have all run once on that thread, and ONE stream per device on which every warm-up and
+# Signatures whose kernels have all run once on the calling thread, and ONE stream per device on which every warm-up and
 # capture is issued: the BLAS library keeps a workspace per (handle, stream), and on a stream that already has one a
 # capture never allocates it from a graph's private pool.
-_WARMED: set = set()
+_WARM_LOCAL = threading.local()        # thread-local, not keyed by thread id: the OS recycles ids of finished threads
+
+
+def _warmed_on_this_thread() -> set:
+    w = getattr(_WARM_LOCAL, "signatures", None)
+    if w is None:
+        w = _WARM_LOCAL.signatures = set()
+    return w
+
 _CAPTURE_STREAMS: Dict = {}
 
 
@@ -287,8 +295,8 @@ class GraphedTrainer:
         side = _capture_stream(self.X.device)
         self.model.train()
         # per thread: BLAS handles are per thread, and a handle's first use must not fall inside a capture
-        warm_key = (threading.get_ident(), self.signature)
-        if self.signature is None or warm_key not in _WARMED:
+        warmed = _warmed_on_this_thread()
+        if self.signature is None or self.signature not in warmed:
             keep = (f.P.clone(), o.M.clone(), o.V.clone(), o.state.clone(),
                     None if self.rng is None else self.rng.ctr.clone())
             side.wait_stream(cur)
@@ -317,7 +325,7 @@ class GraphedTrainer:
         o.finish_capture()
         self.graph = g
         if self.signature is not None:
-            _WARMED.add(warm_key)
+            warmed.add(self.signature)
 
     def capture_callable(self, fn: Callable[[], None], warm: bool = False) -> Optional["torch.cuda.CUDAGraph"]:
         """Capture ``fn()`` (device work only, fixed addresses) into a hipGraph on a side stream; None if graphs are off
