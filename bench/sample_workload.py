@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--warm", type=int, default=1, help="untimed trials first (library load, allocator warm-up)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--packed", type=int, default=0, help="trial slots of the packed executor (0: one function trial at a time)")
-    ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--streams", type=int, default=8)
     args = ap.parse_args()
     tl, vl = create_dummy_data(learnable=not args.noise_target)
     space = dict(SAMPLE_SPACE, device=args.device, hip_graph=not args.no_graph)

@@ -10,8 +10,8 @@ Feistel permutation of ``(seed, trial_index, epoch)``, so a trial's data order d
 
 Slots do not wait for each other: one host thread issues the slots' graph replays round-robin over a few HIP
 streams, so the small kernels of several trials are in flight at once (measured on one MI355X with the sample
-Transformer, 25 steps x 4 trials: 65 ms replayed back to back on one stream, 21 ms on four streams; more hardware
-queues than the runtime's default four made it slower, not faster).  Every slot owns its dropout counter, its
+Transformer, 25 steps x 4 trials: 65 ms replayed back to back on one stream, 21 ms on four streams; raising the
+runtime's number of hardware queues above its default four made it slower, not faster).  Every slot owns its dropout counter, its
 cursor and its loss accumulator, so the interleaving changes no trial's numbers.  Validation of all slots is
 issued the same way and read back with one synchronisation.  In the small-kernel regime a slot's validation pass is
 captured too and replayed right behind its last training step, so an epoch of the whole pack -- training and
@@ -43,7 +43,10 @@ from ..ops import rng
 from ..train.graphed import FlatOptimizer, FlatParams, GraphedTrainer
 from ..train.losses import MAPE_EPS, elementwise_loss, get_criterion
 
-DEFAULT_STREAMS = 4      # the HIP runtime's default number of hardware queues per process
+# The HIP runtime gives a process four hardware queues by default and deals streams onto them in creation order; eight
+# streams cover all four queues wherever in that order they fall (four streams sometimes land two to a queue: measured
+# 110 or 176 us per step for the same four trials depending on what else had created streams before).
+DEFAULT_STREAMS = 8
 SMALL_STEP_ROWS = 4096   # batch x tokens up to which slots are issued concurrently
 
 

@@ -23,6 +23,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import gc
+import os
 import logging
 import threading
 from typing import Callable, Dict, Optional
@@ -255,6 +256,10 @@ class GraphedTrainer:
         self.pos = torch.zeros(1, dtype=torch.int64, device=dev)
         self.running = torch.zeros((), device=dev)
         self.rng = rng.new_counter(dev, 0x1234567 + int(seed)) if dev.type == "cuda" else None
+        self._fast = False
+        if dev.type == "cuda":
+            from ..ops.batch_hip import cursor_batch_ok
+            self._fast = cursor_batch_ok(self.perm, self.pos, X, Y) and os.environ.get("MITUNE_FAST_BATCH", "1") != "0"
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.graphed = False
         if use_graph and not SHARED_GPU_THREADS and dev.type == "cuda" and self.N >= self.B:
@@ -269,16 +274,24 @@ class GraphedTrainer:
 
     # ------------------------------------------------------------------ one optimiser step
     def _step(self, rows: torch.Tensor) -> None:
-        x = self.X.index_select(0, rows)
-        y = self.Y.index_select(0, rows)
+        self._step_xy(self.X.index_select(0, rows), self.Y.index_select(0, rows))
+
+    def _step_xy(self, x: torch.Tensor, y: torch.Tensor) -> None:
+        fused_mse = self._fast and type(self.criterion) is torch.nn.MSELoss and self.criterion.reduction == "mean"
         with rng.scope(self.rng):
             rng.begin_step(x.device)          # the seed table is refilled inside the (captured) step
             with self.forward_ctx():
                 out = self.model(x)
-            loss = self.criterion(out.float().reshape(y.shape), y)
+            out = out.float().reshape(y.shape)
+            if fused_mse:                     # loss, its gradient and the running sum in one launch
+                from ..ops.batch_hip import FusedMSE
+                loss = FusedMSE.apply(out, y, self.running)
+            else:
+                loss = self.criterion(out, y)
             loss.backward()
         self.opt.step()
-        self.running += loss.detach()
+        if not fused_mse:
+            self.running += loss.detach()
 
     def seed(self, value: int) -> None:
         """Pin this trainer's dropout counter (stream-ordered)."""
@@ -286,7 +299,11 @@ class GraphedTrainer:
             self.rng.seed(value)
 
     def _cursor_step(self) -> None:
-        self._step(self.perm.index_select(0, self.ar + self.pos))
+        if self._fast:                        # batch rows picked at the device cursor in one launch
+            from ..ops.batch_hip import cursor_batch
+            self._step_xy(*cursor_batch(self.perm, self.pos, self.X, self.Y, self.B))
+        else:
+            self._step(self.perm.index_select(0, self.ar + self.pos))
         self.pos += self.B
 
     def _capture(self) -> None:

@@ -299,6 +299,37 @@ def test_relu_dropout_equals_dropout_of_relu(dtype):
     assert relu_dropout(x, 0.3, False).equal(torch.relu(x))
 
 
+@pytest.mark.parametrize("shape", [(50, 10), (7,), (96, 81)])
+def test_cursor_batch_equals_index_select(shape):
+    from mitune.ops.batch_hip import cursor_batch
+    g = torch.Generator(device=DEV).manual_seed(1)
+    N, B = 333, 32
+    X = torch.randn((N,) + shape, device=DEV, generator=g)
+    Y = torch.randn(N, device=DEV, generator=g)
+    perm = torch.randperm(N, device=DEV, generator=g)
+    for start in (0, 64, N - B):
+        pos = torch.tensor([start], dtype=torch.int64, device=DEV)
+        xb, yb = cursor_batch(perm, pos, X, Y, B)
+        rows = perm[start:start + B]
+        assert torch.equal(xb, X[rows]) and torch.equal(yb, Y[rows])
+
+
+@pytest.mark.parametrize("n", [32, 1000, 5])
+def test_fused_mse_matches_mse_loss(n):
+    from mitune.ops.batch_hip import FusedMSE
+    g = torch.Generator(device=DEV).manual_seed(n)
+    out = torch.randn(n, device=DEV, generator=g, requires_grad=True)
+    y = torch.randn(n, device=DEV, generator=g)
+    running = torch.full((), 2.0, device=DEV)
+    loss = FusedMSE.apply(out, y, running)
+    (3.0 * loss).backward()
+    ref_out = out.detach().clone().requires_grad_()
+    ref = torch.nn.functional.mse_loss(ref_out, y)
+    (3.0 * ref).backward()
+    assert torch.allclose(loss, ref, rtol=1e-5) and torch.allclose(out.grad, ref_out.grad, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(running, 2.0 + ref.detach(), rtol=1e-5)
+
+
 def test_keep_mask_statistics():
     from mitune.ops.elementwise import keep_mask
     m = keep_mask((64, 8, 65, 65), 0.2, torch.device(DEV))
@@ -380,7 +411,8 @@ def test_bf16_or_long_token_packs_stay_on_one_stream():
     assert eng._issue_streams([0, 1], 32) == [cur]                     # bf16 autocast
     eng.amp = False
     assert eng._issue_streams([0, 1], 1024) == [cur]                   # 1024 x 64 token rows per step
-    assert len(eng._issue_streams([0, 1], 32)) == 4
+    from mitune.packed.engine_graph import DEFAULT_STREAMS
+    assert len(eng._issue_streams([0, 1], 32)) == DEFAULT_STREAMS
 
 
 def test_packed_search_over_the_sample_space_on_gpu():
