@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--warm", type=int, default=1, help="untimed trials first (library load, allocator warm-up)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--packed", type=int, default=0, help="trial slots of the packed executor (0: one function trial at a time)")
-    ap.add_argument("--streams", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=4)
     args = ap.parse_args()
     tl, vl = create_dummy_data(learnable=not args.noise_target)
     space = dict(SAMPLE_SPACE, device=args.device, hip_graph=not args.no_graph)
@@ -82,7 +82,7 @@ def main():
                       "trial_seconds_min_med_max": [per[0], per[len(per) // 2], per[-1]],
                       "epochs_run": sum(t.training_iteration for t in an.trials),
                       "executor": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in an.stats.items()
-                                   if k in ("train_s", "eval_s", "comm_s", "epochs", "slot_epochs", "prepared_ahead", "engine")}}))
+                                   if k in ("train_s", "eval_s", "comm_s", "epochs", "slot_epochs", "prepared_ahead", "engine", "stream_window")}}))
 
 
 if __name__ == "__main__":

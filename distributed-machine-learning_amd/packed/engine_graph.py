@@ -40,13 +40,16 @@ from .engine import TorchPackEngine, _Slot
 from .permutation import permute, round_keys
 from ..models.mlp import MLPTrialSpec, init_mlp_state
 from ..ops import rng
-from ..train.graphed import FlatOptimizer, FlatParams, GraphedTrainer
+from ..train.graphed import _CAPTURE_LOCK, FlatOptimizer, FlatParams, GraphedTrainer, _no_gc
 from ..train.losses import MAPE_EPS, elementwise_loss, get_criterion
 
-# The HIP runtime gives a process four hardware queues by default and deals streams onto them in creation order; eight
-# streams cover all four queues wherever in that order they fall (four streams sometimes land two to a queue: measured
-# 110 or 176 us per step for the same four trials depending on what else had created streams before).
-DEFAULT_STREAMS = 8
+# The HIP runtime gives a process four hardware queues by default, and which queue a stream lands on is not something
+# the API tells: measured with the same four trials, four consecutive streams of the framework's pool gave 103 us per
+# step or 175 us per step (two streams sharing a queue) depending on which streams had been handed out before, and eight
+# streams 140.  So the engine takes CANDIDATE_STREAMS streams, times a small captured kernel chain on every window of
+# DEFAULT_STREAMS consecutive ones (a few milliseconds, once per engine) and keeps the fastest window.
+DEFAULT_STREAMS = 4
+CANDIDATE_STREAMS = 12
 SMALL_STEP_ROWS = 4096   # batch x tokens up to which slots are issued concurrently
 
 
@@ -66,7 +69,10 @@ class GraphPackEngine(TorchPackEngine):
         self._eval_graphs = bool(int(trainable.model_kwargs.get("eval_graphs", os.environ.get("MITUNE_EVAL_GRAPHS", 1))))
         self.prepared_total = 0
         n = int(trainable.model_kwargs.get("streams", os.environ.get("MITUNE_GRAPH_STREAMS", DEFAULT_STREAMS)))
-        self._streams: List[torch.cuda.Stream] = [torch.cuda.Stream(self.device) for _ in range(max(1, min(n, 32)))]
+        self._n_streams = max(1, min(n, 16))
+        self._streams: List[torch.cuda.Stream] = [torch.cuda.Stream(self.device)
+                                                  for _ in range(max(self._n_streams, CANDIDATE_STREAMS))]
+        self._calibrated = False
 
     # ------------------------------------------------------------------ slot management
     def _make(self, trial_index, config, state=None):
@@ -196,9 +202,62 @@ class GraphPackEngine(TorchPackEngine):
     def _issue_streams(self, order, samples_per_launch: int, bound: int = SMALL_STEP_ROWS) -> List[torch.cuda.Stream]:
         """Streams the slots in ``order`` are spread over: several only in the small-kernel f32 regime."""
         small = samples_per_launch * self._tokens_per_sample() <= bound
-        if self.amp or not small or len(self._streams) < 2 or len(order) < 2:
+        if self.amp or not small or self._n_streams < 2 or len(order) < 2:
             return [torch.cuda.current_stream(self.device)]
+        if not self._calibrated:
+            self._calibrate_streams()
         return self._streams
+
+    def _calibrate_streams(self) -> None:
+        """Keep the window of ``_n_streams`` consecutive candidate streams on which independent kernel chains overlap best."""
+        import time
+        self._calibrated = True
+        k, cand = self._n_streams, self._streams
+        if len(cand) <= k:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        bufs = [torch.zeros(1 << 14, device=self.device) for _ in range(k)]
+        graphs = []
+        side = torch.cuda.Stream(self.device)
+        try:
+            for b in bufs:                               # one small captured chain per concurrent lane
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    b.add_(1.0)                          # the kernel is loaded before anything is captured
+                    g = torch.cuda.CUDAGraph()
+                    with _CAPTURE_LOCK, _no_gc():
+                        g.capture_begin(capture_error_mode="thread_local")
+                        try:
+                            for _ in range(64):
+                                b.add_(1.0)
+                        finally:
+                            g.capture_end()
+                cur.wait_stream(side)
+                graphs.append(g)
+
+            def run(window) -> float:
+                for st in window:
+                    st.wait_stream(cur)
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    for g, st in zip(graphs, window):
+                        with torch.cuda.stream(st):
+                            g.replay()
+                torch.cuda.synchronize(self.device)
+                return time.perf_counter() - t0
+
+            best, best_t = 0, float("inf")
+            for off in range(0, len(cand) - k + 1):
+                run(cand[off:off + k])
+                t = min(run(cand[off:off + k]), run(cand[off:off + k]))
+                if t < best_t * 0.93:                    # a later window must be clearly better to replace an earlier one
+                    best, best_t = off, t
+            self._streams = cand[best:best + k]
+            self.stream_window = (best, best_t)
+        except Exception:                                # noqa: BLE001 - calibration is an optimisation only
+            self._streams = cand[:k]
+            torch.cuda.synchronize(self.device)
 
     def _fan_out(self, streams):
         cur = torch.cuda.current_stream(self.device)

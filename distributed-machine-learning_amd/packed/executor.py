@@ -153,6 +153,8 @@ class PackedExecutor(Executor):
         self.stats["slot_epochs"] += len(local)
         self.stats["train_s"] += t1 - t0
         self.stats["prepared_ahead"] = getattr(self.engine, "prepared_total", 0)
+        if hasattr(self.engine, "stream_window"):
+            self.stats["stream_window"] = str(self.engine.stream_window)
         self.stats["eval_s"] += t2 - t1
         self.stats["comm_s"] += t3 - t2
 

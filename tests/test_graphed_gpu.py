@@ -385,7 +385,7 @@ def test_sequence_trials_issued_over_streams_equal_issue_on_one_stream():
     """Slots of different shapes replayed round-robin over four streams end where the same slots end when they are
     replayed one after the other: own dropout counter, cursor and loss accumulator per slot."""
     eng4, multi = _sequence_pack(4)
-    assert len(eng4._issue_streams(eng4.occupied(), 32)) == 4
+    assert len(eng4._issue_streams(eng4.occupied(), 32)) == 4 and eng4._calibrated
     eng1, single = _sequence_pack(1)
     assert len(eng1._issue_streams(eng1.occupied(), 32)) == 1
     for a, b in zip(multi, single):
