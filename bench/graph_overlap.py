@@ -30,7 +30,8 @@ def main():
     for t in trs:
         t.train_epoch()
     torch.cuda.synchronize()
-    streams = [torch.cuda.Stream() for _ in range(K)]
+    pool = [torch.cuda.Stream() for _ in range(K + 8)]
+    streams = pool[:K]
 
     def one_stream(n):
         t0 = time.perf_counter()
@@ -55,10 +56,13 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0, host
 
-    for _ in range(2):
+    # which hardware queue a stream lands on is not visible: try every window of K consecutive pool streams
+    for off in range(0, 9):
+        streams[:] = pool[off:off + K]
+        many_streams(25)
         a, _ = one_stream(25)
         b, host = many_streams(25)
-        print(f"K={K} one stream {a * 1e3:.1f} ms ({a / K / 25 * 1e6:.0f} us/step)  {K} streams {b * 1e3:.1f} ms "
+        print(f"K={K} window {off}: one stream {a * 1e3:.1f} ms ({a / K / 25 * 1e6:.0f} us/step)  {K} streams {b * 1e3:.1f} ms "
               f"({b / K / 25 * 1e6:.0f} us/step)  speedup {a / b:.2f}  host issue {host * 1e3:.1f} ms", flush=True)
 
 
