@@ -510,3 +510,48 @@ def test_process_executor_pins_a_gpu_per_trial(tmp_path):
     assert [t.status for t in an.trials] == ["TERMINATED", "TERMINATED"]
     assert all(t.training_iteration == 3 and t.last_result["visible"] == "0" for t in an.trials)
     assert an.best_result["loss"] < an.trials[0].results[0]["loss"]
+
+
+# ------------------------------------------------------------------ two ranks, replicated scheduler, graph engine
+def _two_rank_worker(rank, world, port, out_dir):
+    import json
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import mitune
+    from mitune import tune
+    from mitune.data import create_dummy_data
+    from mitune.packed import PackedExecutor, PackedTrainable
+    from mitune.parallel.comm import TorchDistComm
+    from mitune.schedulers import ASHAScheduler
+    dev = torch.device("cuda", 0)                  # both ranks share the one GPU of the test box
+    torch.cuda.set_device(dev)
+    comm = TorchDistComm(backend="gloo", device=torch.device("cpu"), rank=rank, world_size=world)
+    tl, vl = create_dummy_data(num_samples=300, seq_len=16, input_size=6)
+    tr = PackedTrainable(model="simple_transformer", train=tuple(tl.dataset.tensors), val=tuple(vl.dataset.tensors),
+                         max_epochs=3, dtype="f32", capacity=3, model_kwargs={"batch_size": 32, "optimizer": "adamw"})
+    ex = PackedExecutor(tr, comm=comm, device=dev, capacity=3, seed=0)
+    an = mitune.run(tr, config={"d_model": tune.choice([32, 64]), "num_heads": 2, "num_layers": tune.choice([1, 2]),
+                                "dropout": 0.1, "learning_rate": tune.loguniform(1e-4, 1e-2)},
+                    num_samples=8, scheduler=ASHAScheduler(metric="validation_loss", mode="min", max_t=3, reduction_factor=2),
+                    executor=ex, seed=0, verbose=0, metric="validation_loss", mode="min")
+    res = {t.trial_id: [t.training_iteration, t.last_result["validation_loss"], t.placement["rank"]] for t in an.trials}
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump({"res": res, "engine": an.stats["engine"]}, f)
+    comm.close()
+
+
+def test_two_ranks_with_the_graph_engine_reach_the_same_decisions(tmp_path):
+    """Replicated searcher and scheduler over a gloo metric exchange, each rank training its own slots with captured
+    steps on the GPU: both ranks end with the same table, and both owned trials."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = json.load(open(tmp_path / "rank0.json"))
+    b = json.load(open(tmp_path / "rank1.json"))
+    assert a["engine"] == b["engine"] == "graph"
+    assert a["res"] == b["res"] and len(a["res"]) == 8
+    assert {v[2] for v in a["res"].values()} == {0, 1}
+    assert all(math.isfinite(v[1]) for v in a["res"].values())
