@@ -139,3 +139,28 @@ def test_layer0_splits_its_weight_gradient_further_than_wide_layers():
     for slot in range(12):
         assert got[slot]["validation_mse"] == pytest.approx(want[slot]["validation_mse"], rel=0.08, abs=0.02 * var_y), slot
         assert got[slot]["train_loss"] == pytest.approx(want[slot]["train_loss"], rel=0.08, abs=0.02 * var_y), slot
+
+
+def test_bench_runs_under_the_driver_launch_line_with_two_ranks():
+    """``python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2``: the launch line used for N > 1, here
+    with both ranks on the one GPU of the test box and a gloo metric exchange (RCCL refuses two ranks per device)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MITUNE_COMM_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--trials-per-gpu", "8", "--rows", "20000"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 alone prints the JSON line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["config"]["trials"] == 16 and rec["value"] > 0
+    assert rec["scaling"] == "weak" and rec["higher_is_better"] is True
