@@ -26,6 +26,7 @@ from typing import Optional
 import torch
 import torch.nn.functional as F
 
+SPLIT_TARGET = int(os.environ.get("MITUNE_WGRAD_WORKGROUPS", "512"))      # workgroups a weight-gradient launch aims for
 MIN_ROWS = 4096        # below this the library GEMM is fine and the slab reduction is pure overhead
 SMALL_MAX_ROWS = 4096
 SMALL_MAX_WEIGHTS = 65536     # in x out, e.g. 128 x 512
@@ -144,7 +145,7 @@ class SplitKLinear(torch.autograd.Function):
         M = xc.shape[0]
         dx = (dyc @ weight).reshape(x.shape) if ctx.needs_input_grad[0] else None
         tiles = ((out_f + 127) // 128) * ((in_f + 127) // 128)
-        ksplits = max(1, min(127, (M + 63) // 64, (768 + tiles - 1) // tiles))     # 127: split index field
+        ksplits = max(1, min(127, (M + 63) // 64, (SPLIT_TARGET + tiles - 1) // tiles))     # 127: split index field
         slab = (out_f * in_f + out_f + 63) // 64 * 64
         arena = torch.empty(ksplits, slab, device=x.device, dtype=torch.float32)
         db_ptr = arena.data_ptr() + out_f * in_f * 4 if ctx.has_bias else None
