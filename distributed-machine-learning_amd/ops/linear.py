@@ -52,9 +52,20 @@ def _small_eligible(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     return 0 < rows <= SMALL_MAX_ROWS and in_f * out_f <= SMALL_MAX_WEIGHTS
 
 
+def _shadow(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """bf16 copy of a parameter kept current by the flat optimiser (``FlatParams(bf16_shadow=True)``), if there is one."""
+    return getattr(t, "_mt_bf16", None) if t is not None else None
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     if _eligible(x, weight):
-        return SplitKLinear.apply(x, weight, bias)
+        xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        return SplitKLinear.apply(xb, weight, bias, _shadow(weight), _shadow(bias))
+    w16 = _shadow(weight)
+    if (w16 is not None and x.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16 and (bias is None or _shadow(bias) is not None)):
+        with torch.autocast("cuda", enabled=False):       # validation pass: no per-call casts of the weights either
+            return F.linear(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), w16, _shadow(bias))
     if _small_eligible(x, weight, bias):
         return SmallLinear.apply(x, weight, bias)
     if _small_inference(x, weight, bias):
@@ -126,16 +137,25 @@ class SmallLinear(torch.autograd.Function):
 
 
 class SplitKLinear(torch.autograd.Function):
-    @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+    """``x`` arrives in bf16; ``w16`` / ``b16`` are bf16 shadows of the f32 master parameters when the optimiser keeps
+    them (one cast of the whole parameter slab per step instead of two cast launches per layer call), else None."""
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
+    def forward(ctx, x, weight, bias, w16=None, b16=None):
+        with torch.autocast("cuda", enabled=False):
+            wb = w16 if w16 is not None else weight.to(torch.bfloat16)
+            bb = None if bias is None else (b16 if b16 is not None else bias.to(torch.bfloat16))
+            ctx.save_for_backward(x, wb)
+            ctx.has_bias = bias is not None
+            return F.linear(x, wb, bb)
+
+    @staticmethod
     def backward(ctx, dy):
+        with torch.autocast("cuda", enabled=False):
+            return SplitKLinear._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         from . import lib as L
         so = L.load()
         x, weight = ctx.saved_tensors
@@ -155,4 +175,4 @@ class SplitKLinear(torch.autograd.Function):
         total = arena.sum(0) if ksplits > 1 else arena[0]
         dw = total[:out_f * in_f].view(out_f, in_f)
         db = total[out_f * in_f:out_f * in_f + out_f] if ctx.has_bias else None
-        return dx, dw, db
+        return dx, dw, db, None, None

@@ -84,7 +84,7 @@ class GraphPackEngine(TorchPackEngine):
             model.load_state_dict(init_mlp_state(spec, self.seed, trial_index))
         if state is not None and "model" in state:
             model.load_state_dict(state["model"])
-        flat = FlatParams(model, grad_slab=False)
+        flat = FlatParams(model, grad_slab=False, bf16_shadow=self.amp)
         s.model = model
         s.opt = FlatOptimizer(flat, spec.optimizer, spec.learning_rate, spec.weight_decay, spec.momentum,
                               (spec.beta1, spec.beta2), spec.eps, spec.gradient_clipping, spec.warmup_steps,
@@ -177,6 +177,7 @@ class GraphPackEngine(TorchPackEngine):
             return super().clone(src, dst, config)       # shapes differ: go through a state_dict
         with torch.no_grad():
             b.opt.flat.P.copy_(a.opt.flat.P)
+            b.opt.flat.refresh_shadow()
             b.opt.M.copy_(a.opt.M)
             b.opt.V.copy_(a.opt.V)
             b.opt._i32[b.opt._STEP:b.opt._STEP + 1].copy_(a.opt._i32[a.opt._STEP:a.opt._STEP + 1])

@@ -91,7 +91,10 @@ class FlatParams:
     ops produced and the optimiser reads them where they are (``FlatOptimizer`` keeps a table of their addresses).
     """
 
-    def __init__(self, model: torch.nn.Module, grad_slab: bool = True):
+    def __init__(self, model: torch.nn.Module, grad_slab: bool = True, bf16_shadow: bool = False):
+        """``bf16_shadow``: also keep a bf16 copy of the slab (every parameter gets a ``_mt_bf16`` view of it), refreshed
+        by ``refresh_shadow()`` after each update -- for bf16-autocast models whose dense layers would otherwise cast
+        their weight and bias on every call."""
         self.grad_slab = grad_slab
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
@@ -112,6 +115,15 @@ class FlatParams:
                 p.data = self.P[o:o + p.numel()].view(p.shape)
                 # slab mode: autograd accumulates in place into the slab
                 p.grad = self.G[o:o + p.numel()].view(p.shape) if grad_slab else None
+        self.Pb: Optional[torch.Tensor] = None
+        if bf16_shadow:
+            self.Pb = self.P.to(torch.bfloat16)
+            for p, o in zip(self.params, offs):
+                p._mt_bf16 = self.Pb[o:o + p.numel()].view(p.shape)
+
+    def refresh_shadow(self) -> None:
+        if self.Pb is not None:
+            self.Pb.copy_(self.P)
 
 
 class FlatOptimizer:
@@ -193,6 +205,7 @@ class FlatOptimizer:
                      "mt_flat_optim_seg_launch")
         for p in f.params:
             p.grad = None            # the next backward hands over fresh tensors (same addresses under graph replay)
+        f.refresh_shadow()
 
     def step(self) -> None:
         f = self.flat
@@ -203,6 +216,7 @@ class FlatOptimizer:
                                                   1 if self.use_clip else 0, 1,
                                                   torch.cuda.current_stream(f.P.device).cuda_stream),
                      "mt_flat_optim_launch")
+        f.refresh_shadow()
 
     def zero_grad(self) -> None:      # the update kernel already zeroes the slab; this is for completeness
         if self._segs is not None:
@@ -323,6 +337,7 @@ class GraphedTrainer:
             cur.wait_stream(side)
             with torch.no_grad():              # undo the warm-up step: training starts from the initial weights
                 f.P.copy_(keep[0]); o.M.copy_(keep[1]); o.V.copy_(keep[2]); o.state.copy_(keep[3])
+                f.refresh_shadow()
                 o.zero_grad(); self.pos.zero_(); self.running.zero_()
                 if self.rng is not None:
                     self.rng.ctr.copy_(keep[4])

@@ -459,6 +459,34 @@ def test_trials_prepared_during_a_running_epoch_end_like_trials_built_on_demand(
         assert ahead[k][1] == pytest.approx(on_demand[k][1], rel=2e-3)
 
 
+def test_bf16_shadow_of_the_parameter_slab_tracks_updates_and_feeds_the_dense_layers():
+    from mitune.ops.linear import linear
+    from mitune.train.graphed import FlatOptimizer, FlatParams
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 48).to(DEV)
+    flat = FlatParams(lin, grad_slab=False, bf16_shadow=True)
+    opt = FlatOptimizer(flat, "adamw", 1e-2, 0.0)
+    x = torch.randn(8192, 64, device=DEV)
+    dy = torch.randn(8192, 48, device=DEV)
+    assert lin.weight._mt_bf16.dtype == torch.bfloat16 and torch.equal(lin.weight._mt_bf16, lin.weight.detach().bfloat16())
+    for _ in range(2):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = linear(x, lin.weight, lin.bias)
+            assert "SplitKLinear" in type(y.grad_fn).__name__ and y.dtype == torch.bfloat16
+        ref = torch.nn.functional.linear(x.bfloat16(), lin.weight.detach().bfloat16(), lin.bias.detach().bfloat16())
+        assert torch.equal(y.detach(), ref)                          # the shadow is exactly the cast of the master
+        y.backward(dy.to(y.dtype))
+        assert lin.weight.grad.dtype == torch.float32
+        before = lin.weight.detach().clone()
+        opt.step()
+        assert not torch.equal(lin.weight.detach(), before)
+        assert torch.equal(lin.weight._mt_bf16, lin.weight.detach().bfloat16())
+        assert torch.equal(lin.bias._mt_bf16, lin.bias.detach().bfloat16())
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        z = linear(x, lin.weight, lin.bias)
+    assert torch.equal(z, torch.nn.functional.linear(x.bfloat16(), lin.weight.detach().bfloat16(), lin.bias.detach().bfloat16()))
+
+
 # ------------------------------------------------------------------ split-contraction weight gradient
 @pytest.mark.parametrize("M,in_f,out_f", [(66560, 192, 576), (8192, 256, 192), (5000, 72, 40)])
 def test_split_k_linear_matches_reference(M, in_f, out_f):
