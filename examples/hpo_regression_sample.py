@@ -4,7 +4,11 @@
 Counterpart of /root/reference/ray-tune-hpo-regression-sample.py:152-172 with the imports switched from
 ``ray.tune`` to ``mitune.tune``; no cluster runtime, no hard-coded home directory.
 
-    python examples/hpo_regression_sample.py [--num-samples 10] [--local-dir ./mitune_results] [--epochs 5]
+    python examples/hpo_regression_sample.py [--num-samples 10] [--local-dir ./mitune_results] [--epochs 5] [--packed K]
+
+``--packed K`` hands the same search to the packed executor: K trials resident on the GPU at a time, every one with a
+captured training step, replayed over a few HIP streams by one host thread (several times the throughput of running
+the function trainable one trial at a time; the result tree on disk has the same layout).
 """
 import argparse
 import os
@@ -26,15 +30,25 @@ def main():
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--local-dir", default="./mitune_results")
     ap.add_argument("--noise-target", action="store_true", help="target independent of the inputs, like the reference")
+    ap.add_argument("--packed", type=int, default=0, help="trial slots of the packed executor (0: function trainable)")
     args = ap.parse_args()
     logger = setup_logging(args.local_dir, prefix="mitune_workflow_sample_run")
     logger.info("Starting the mitune workflow...")
     train_loader, val_loader = create_dummy_data(learnable=not args.noise_target)
+    if args.packed:
+        from mitune.packed import PackedTrainable
+        trainable = PackedTrainable(model="simple_transformer", train=tuple(train_loader.dataset.tensors),
+                                    val=tuple(val_loader.dataset.tensors), max_epochs=args.epochs, dtype="f32",
+                                    capacity=args.packed, name="train_dummy_model_packed",
+                                    model_kwargs={"batch_size": 32, "optimizer": "adamw"})
+    else:
+        trainable = tune.with_parameters(train_dummy_model, data_loader=train_loader, val_loader=val_loader,
+                                         epochs=args.epochs)
     analysis = tune.run(
-        tune.with_parameters(train_dummy_model, data_loader=train_loader, val_loader=val_loader, epochs=args.epochs),
+        trainable,
         config=SAMPLE_SPACE,
         num_samples=args.num_samples,
-        scheduler=ASHAScheduler(metric="validation_loss", mode="min"),
+        scheduler=ASHAScheduler(metric="validation_loss", mode="min", max_t=args.epochs),
         resources_per_trial={"cpu": 2, "gpu": 1},
         local_dir=args.local_dir,
         verbose=1,
