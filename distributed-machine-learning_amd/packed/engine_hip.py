@@ -43,6 +43,7 @@ BIG_TILE = 256         # tile edge of the throughput-form GEMM kernels
 # the 128-tile forms at every pack size (256 slots x 512^3: fwd 166 vs 122 us, dgrad 309 vs 135, wgrad 242 vs 160);
 # MITUNE_BIG_MIN_TILES=<n> turns them on for launches with at least n such tiles.
 BIG_MIN_TILES = int(os.environ.get("MITUNE_BIG_MIN_TILES", "0"))
+KSPLITS_SMALL = int(os.environ.get("MITUNE_KSPLITS_SMALL", str(MAX_KSPLITS)))     # wgrad splits of packs with <= 128 tiles
 GRAPH_STEPS = 25       # steps per captured hipGraph block (3125 = 125 blocks; shorter epochs run the rest directly)
 
 
@@ -319,11 +320,13 @@ class HipPackEngine(PackEngine):
                 per_layer[l] = per_layer.get(l, 0) + ((h + TILE - 1) // TILE) * ((lay.in_dims[l] + TILE - 1) // TILE)
 
         def rule(tiles: int) -> int:
-            # measured on 512-wide layers: 4 splits win 1.4x at 128 tiles, nothing at 256, and every split
-            # costs the optimiser one more slab to read
-            if tiles <= 128:
-                return MAX_KSPLITS
-            return 2 if tiles <= 192 else 1
+            # The GEMM alone gains from splitting up to about 128 tiles (512-wide layers: 4 splits 1.4x faster at 128
+            # tiles, nothing at 256), but every split is one more f32 slab the weight gradient writes and the optimiser
+            # reads, and the optimiser is a quarter of a late-round step: end to end the 256-trial search takes 7.37 s
+            # with 4 splits up to 128 tiles, 7.16 s with 2 and 7.15 s with none.  Splits are kept for very small packs.
+            if tiles <= 32:
+                return min(4, KSPLITS_SMALL)
+            return min(2, KSPLITS_SMALL) if tiles <= 64 else 1
 
         rest = rule(max([v for l, v in per_layer.items() if l > 0] or [per_layer[0]]))
         return rest, max(rest, rule(per_layer[0]))

@@ -129,7 +129,7 @@ def test_layer0_splits_its_weight_gradient_further_than_wide_layers():
     eng.train_epoch()
     got = eng.evaluate()
     plan = eng._chains[0].plan
-    assert (plan.ksplits, plan.ksplits0) == (2, 4)
+    assert (plan.ksplits, plan.ksplits0) == (1, 2)
     ref = TorchPackEngine(tr, device="cuda", capacity=12, seed=1)
     for slot, (idx, cfg) in enumerate(cfgs):
         ref.load(slot, idx, cfg)
