@@ -133,9 +133,9 @@ class TorchPackEngine(PackEngine):
                     model = SimpleTransformerModel.from_config(merged, spec.in_features)
                 else:
                     model = self.t.model(config, spec.in_features)
-        model = model.to(self.device)
         if not with_optimizer:
-            return model, None
+            return model, None              # still on the CPU: the flat parameter slab uploads it in one copy
+        model = model.to(self.device)
         opt = build_optimizer(spec.optimizer, model.parameters(), spec.learning_rate, spec.weight_decay,
                               spec.momentum, spec.beta1, spec.beta2, spec.eps)
         return model, opt

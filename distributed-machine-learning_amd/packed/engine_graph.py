@@ -84,7 +84,7 @@ class GraphPackEngine(TorchPackEngine):
             model.load_state_dict(init_mlp_state(spec, self.seed, trial_index))
         if state is not None and "model" in state:
             model.load_state_dict(state["model"])
-        flat = FlatParams(model, grad_slab=False, bf16_shadow=self.amp)
+        flat = FlatParams(model, grad_slab=False, bf16_shadow=self.amp, device=self.device)
         s.model = model
         s.opt = FlatOptimizer(flat, spec.optimizer, spec.learning_rate, spec.weight_decay, spec.momentum,
                               (spec.beta1, spec.beta2), spec.eps, spec.gradient_clipping, spec.warmup_steps,

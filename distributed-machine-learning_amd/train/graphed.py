@@ -91,15 +91,19 @@ class FlatParams:
     ops produced and the optimiser reads them where they are (``FlatOptimizer`` keeps a table of their addresses).
     """
 
-    def __init__(self, model: torch.nn.Module, grad_slab: bool = True, bf16_shadow: bool = False):
-        """``bf16_shadow``: also keep a bf16 copy of the slab (every parameter gets a ``_mt_bf16`` view of it), refreshed
+    def __init__(self, model: torch.nn.Module, grad_slab: bool = True, bf16_shadow: bool = False, device=None):
+        """``device``: where the slab lives.  A model still on the CPU is moved there by ONE upload of the flattened
+        parameters (a module's own ``.to(device)`` issues a blocking copy per parameter); buffers follow one by one.
+
+        ``bf16_shadow``: also keep a bf16 copy of the slab (every parameter gets a ``_mt_bf16`` view of it), refreshed
         by ``refresh_shadow()`` after each update -- for bf16-autocast models whose dense layers would otherwise cast
         their weight and bias on every call."""
         self.grad_slab = grad_slab
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("model has no trainable parameters")
-        dev = self.params[0].device
+        src = self.params[0].device
+        dev = torch.device(device) if device is not None else src
         offs, n = [], 0
         for p in self.params:
             if p.dtype != torch.float32:
@@ -107,11 +111,25 @@ class FlatParams:
             offs.append(n)
             n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.n, self.offsets = n, offs
-        self.P = torch.zeros(n, device=dev)
         self.G = torch.zeros(n if grad_slab else 0, device=dev)
         with torch.no_grad():
+            if src.type == "cpu" and dev.type != "cpu":
+                host = torch.zeros(n)
+                for p, o in zip(self.params, offs):
+                    host[o:o + p.numel()] = p.detach().reshape(-1)
+                self.P = host.to(dev)                        # one upload
+                frozen = [q for q in model.parameters() if not q.requires_grad]
+                for t in frozen:
+                    t.data = t.data.to(dev)
+                for mod in model.modules():                  # buffers (e.g. the positional-encoding table)
+                    for name, buf in list(mod._buffers.items()):
+                        if buf is not None:
+                            mod._buffers[name] = buf.to(dev)
+            else:
+                self.P = torch.zeros(n, device=dev)
+                for p, o in zip(self.params, offs):
+                    self.P[o:o + p.numel()].copy_(p.detach().reshape(-1))
             for p, o in zip(self.params, offs):
-                self.P[o:o + p.numel()].copy_(p.detach().reshape(-1))
                 p.data = self.P[o:o + p.numel()].view(p.shape)
                 # slab mode: autograd accumulates in place into the slab
                 p.grad = self.G[o:o + p.numel()].view(p.shape) if grad_slab else None
