@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--warm", type=int, default=2)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="packed executor: f32, or bf16 autocast")
     ap.add_argument("--windows", type=int, default=2000, help="96-step windows in the synthetic table (70 % train)")
     args = ap.parse_args()
     tl, vl = frames_to_loaders(synthetic_glucose_frame(96 * args.windows, seed=7))
@@ -54,7 +55,7 @@ def main():
         if args.packed:
             from mitune.packed import PackedTrainable
             tr = PackedTrainable(model="transformer", train=tuple(tl.dataset.tensors), val=tuple(vl.dataset.tensors),
-                                 max_epochs=args.epochs, dtype="f32", capacity=args.packed, name="full_packed")
+                                 max_epochs=args.epochs, dtype=args.dtype, capacity=args.packed, name="full_packed")
             return tune.run(tr, config=space, num_samples=n, scheduler=sched, search_alg=alg, local_dir=None, verbose=0,
                             seed=seed, metric="validation_mape", mode="min", device=torch.device(args.device))
         return tune.run(tune.with_parameters(train_transformer_model, data_loader=tl, val_loader=vl, epochs=args.epochs),
@@ -73,7 +74,7 @@ def main():
     el = time.perf_counter() - t0
     X = tl.dataset.tensors[0]
     print(json.dumps({"workload": "full-transformer-search", "device": args.device, "trials": len(an.trials),
-                      "packed_slots": args.packed, "bayes": args.bayes, "epochs": args.epochs,
+                      "packed_slots": args.packed, "dtype": args.dtype if args.packed else "f32", "bayes": args.bayes, "epochs": args.epochs,
                       "data": f"synthetic {list(X.shape)}", "elapsed_s": el, "trials_per_hour": len(an.trials) / el * 3600.0,
                       "best_validation_mape": an.best_result["validation_mape"],
                       "epochs_run": sum(t.training_iteration for t in an.trials),
