@@ -14,7 +14,8 @@ from mitune.ops.linear import SmallLinear        # noqa: E402
 
 SHAPES = [(1600, 10, 32), (1600, 32, 96), (1600, 32, 128), (1600, 128, 32), (1600, 64, 192), (1600, 64, 256),
           (1600, 256, 64), (1600, 128, 384), (1600, 128, 512), (1600, 512, 128), (32, 64, 1), (3200, 64, 256),
-          (800, 64, 256), (4800, 256, 768), (1600, 256, 1024)]
+          (800, 64, 256), (4800, 256, 768), (1600, 256, 1024),
+          (6144, 64, 256), (6144, 128, 512), (6144, 192, 64), (12288, 64, 192), (12288, 128, 128), (24576, 64, 128)]
 
 
 class _Ctx:

@@ -28,8 +28,10 @@ import torch.nn.functional as F
 
 SPLIT_TARGET = int(os.environ.get("MITUNE_WGRAD_WORKGROUPS", "512"))      # workgroups a weight-gradient launch aims for
 MIN_ROWS = 4096        # below this the library GEMM is fine and the slab reduction is pure overhead
-SMALL_MAX_ROWS = 4096
+SMALL_MAX_ROWS = 32768
 SMALL_MAX_WEIGHTS = 65536     # in x out, e.g. 128 x 512
+SMALL_MAX_MACS = 1 << 29      # rows x in x out; measured wins up to here: 6144x128x512 66.5 / 51.7 us, 12288x64x192
+                              # 109.4 / 58.3, 24576x64x128 135.8 / 110.4 (library / fused)
 
 
 def _eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
@@ -49,7 +51,7 @@ def _small_eligible(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
         return False
     out_f, in_f = weight.shape
     rows = x.numel() // max(in_f, 1)
-    return 0 < rows <= SMALL_MAX_ROWS and in_f * out_f <= SMALL_MAX_WEIGHTS
+    return 0 < rows <= SMALL_MAX_ROWS and in_f * out_f <= SMALL_MAX_WEIGHTS and rows * in_f * out_f <= SMALL_MAX_MACS
 
 
 def _shadow(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:

@@ -276,7 +276,7 @@ def test_small_linear_is_not_used_under_autocast_or_for_large_layers():
     w = torch.randn(16, 32, device="cuda", requires_grad=True)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert "SmallLinear" not in type(linear(x, w).grad_fn).__name__
-    xl = torch.randn(20000, 32, device="cuda", requires_grad=True)
+    xl = torch.randn(40000, 32, device="cuda", requires_grad=True)
     assert "SmallLinear" not in type(linear(xl, w).grad_fn).__name__
     wl = torch.randn(1024, 256, device="cuda", requires_grad=True)
     assert "SmallLinear" not in type(linear(torch.randn(64, 256, device="cuda"), wl).grad_fn).__name__
