@@ -50,6 +50,7 @@ from ..train.losses import MAPE_EPS, elementwise_loss, get_criterion
 # DEFAULT_STREAMS consecutive ones (some tens of milliseconds, once per engine) and keeps the fastest window.
 DEFAULT_STREAMS = 4
 CANDIDATE_STREAMS = 12
+_CALIBRATED_STREAMS: Dict = {}
 SMALL_STEP_ROWS = 4096   # batch x tokens up to which slots are issued concurrently
 
 
@@ -70,9 +71,14 @@ class GraphPackEngine(TorchPackEngine):
         self.prepared_total = 0
         n = int(trainable.model_kwargs.get("streams", os.environ.get("MITUNE_GRAPH_STREAMS", DEFAULT_STREAMS)))
         self._n_streams = max(1, min(n, 16))
-        self._streams: List[torch.cuda.Stream] = [torch.cuda.Stream(self.device)
-                                                  for _ in range(max(self._n_streams, CANDIDATE_STREAMS))]
-        self._calibrated = False
+        key = (self.device.index if self.device.index is not None else torch.cuda.current_device(), self._n_streams)
+        cached = _CALIBRATED_STREAMS.get(key)            # the stream pool is per process: calibrate once per process
+        if cached is not None:
+            self._streams, self.stream_window = list(cached[0]), cached[1]
+        else:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(max(self._n_streams, CANDIDATE_STREAMS))]
+        self._calibrated = cached is not None
+        self._stream_key = key
 
     # ------------------------------------------------------------------ slot management
     def _make(self, trial_index, config, state=None):
@@ -258,6 +264,7 @@ class GraphPackEngine(TorchPackEngine):
                     best, best_t = off, t
             self._streams = cand[best:best + k]
             self.stream_window = (best, best_t)
+            _CALIBRATED_STREAMS[self._stream_key] = (tuple(self._streams), self.stream_window)
         except Exception:                                # noqa: BLE001 - calibration is an optimisation only
             self._streams = cand[:k]
             torch.cuda.synchronize(self.device)
