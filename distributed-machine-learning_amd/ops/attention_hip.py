@@ -35,7 +35,7 @@ class FusedShortAttention(torch.autograd.Function):
         L.check(so.mt_attn_fwd_launch(qb.data_ptr(), kb.data_ptr(), vb.data_ptr(),
                                       keep_u8.data_ptr() if keep_u8 is not None else None, out.data_ptr(),
                                       stat.data_ptr(), B * h, S, dk, dv, scale, keep_scale, _KIND[kind],
-                                      torch.cuda.current_stream(q.device).cuda_stream), "mt_attn_fwd_launch")
+                                      L.raw_stream(q.device)), "mt_attn_fwd_launch")
         ctx.save_for_backward(qb, kb, vb, stat, keep_u8 if keep_u8 is not None else torch.empty(0, device=q.device))
         ctx.meta = (kind, scale, keep_scale, keep is not None, q.dtype, k.dtype, v.dtype)
         return out.to(q.dtype)
@@ -54,7 +54,7 @@ class FusedShortAttention(torch.autograd.Function):
         L.check(so.mt_attn_bwd_launch(qb.data_ptr(), kb.data_ptr(), vb.data_ptr(), do.data_ptr(),
                                       keep_u8.data_ptr() if has_keep else None, stat.data_ptr(), dq.data_ptr(),
                                       dk_.data_ptr(), dv_.data_ptr(), B * h, S, dk, dv, scale, keep_scale,
-                                      _KIND[kind], torch.cuda.current_stream(qb.device).cuda_stream),
+                                      _KIND[kind], L.raw_stream(qb.device)),
                 "mt_attn_bwd_launch")
         return dq.to(qd), dk_.to(kd), dv_.to(vd), None, None, None
 
@@ -82,7 +82,7 @@ class FusedQKVAttention(torch.autograd.Function):
         L.check(so.mt_attn_fwd_strided_launch(base, base + h * dk * es, base + 2 * h * dk * es, None, out.data_ptr(),
                                               stat.data_ptr(), B * h, S, dk, dv, scale, keep_scale, _KIND[kind], h,
                                               W, W, h * dv, f32, seed.data_ptr() if seed is not None else None,
-                                              float(dropout_p), torch.cuda.current_stream(qkv.device).cuda_stream),
+                                              float(dropout_p), L.raw_stream(qkv.device)),
                 "mt_attn_fwd_strided_launch")
         ctx.save_for_backward(qkv, stat)
         ctx.meta = (h, dk, dv, kind, scale, keep_scale, f32)
@@ -103,7 +103,7 @@ class FusedQKVAttention(torch.autograd.Function):
                                               stat.data_ptr(), g, g + h * dk * 4, g + 2 * h * dk * 4, B * h, S, dk, dv,
                                               scale, keep_scale, _KIND[kind], h, W, W, h * dv, f32,
                                               ctx.seed.data_ptr() if ctx.seed is not None else None, ctx.p,
-                                              torch.cuda.current_stream(qkv.device).cuda_stream), "mt_attn_bwd_strided_launch")
+                                              L.raw_stream(qkv.device)), "mt_attn_bwd_strided_launch")
         return dqkv.to(qkv.dtype), None, None, None, None, None
 
 
@@ -135,7 +135,7 @@ class FusedSelfAttention(torch.autograd.Function):
                                               stat.data_ptr(), B * h, S, dk, dv, scale, keep_scale, _KIND[kind], h,
                                               2 * h * dk, h * dv, h * dv, f32,
                                               seed.data_ptr() if seed is not None else None, float(dropout_p),
-                                              torch.cuda.current_stream(qk.device).cuda_stream), "mt_attn_fwd_strided_launch")
+                                              L.raw_stream(qk.device)), "mt_attn_fwd_strided_launch")
         ctx.save_for_backward(qk, v, stat, keep_u8 if keep_u8 is not None else torch.empty(0, device=qk.device))
         ctx.meta = (h, kind, scale, keep_scale, keep is not None, f32)
         ctx.seed, ctx.p = seed, float(dropout_p)
@@ -157,5 +157,5 @@ class FusedSelfAttention(torch.autograd.Function):
                                               dqk.data_ptr() + h * dk * 4, dv_.data_ptr(), B * h, S, dk, dv, scale,
                                               keep_scale, _KIND[kind], h, 2 * h * dk, h * dv, h * dv, f32,
                                               ctx.seed.data_ptr() if ctx.seed is not None else None, ctx.p,
-                                              torch.cuda.current_stream(qk.device).cuda_stream), "mt_attn_bwd_strided_launch")
+                                              L.raw_stream(qk.device)), "mt_attn_bwd_strided_launch")
         return dqk.to(qk.dtype), dv_.to(v.dtype), None, None, None, None, None

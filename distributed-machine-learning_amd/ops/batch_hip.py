@@ -17,7 +17,7 @@ def cursor_batch(perm: torch.Tensor, pos: torch.Tensor, X: torch.Tensor, Y: torc
     ye = max(1, Y[0].numel())
     L.check(so.mt_cursor_batch_launch(perm.data_ptr(), pos.data_ptr(), perm.numel(), X.data_ptr(), Y.data_ptr(), X.shape[0],
                                       xe, ye, xb.data_ptr(), yb.data_ptr(), B,
-                                      torch.cuda.current_stream(X.device).cuda_stream), "mt_cursor_batch_launch")
+                                      L.raw_stream(X.device)), "mt_cursor_batch_launch")
     return xb, yb
 
 
@@ -37,7 +37,7 @@ class FusedMSE(torch.autograd.Function):
         loss = torch.empty((), device=oc.device, dtype=torch.float32)
         L.check(so.mt_mse_fwd_launch(oc.data_ptr(), yc.data_ptr(), oc.numel(), grad.data_ptr(), loss.data_ptr(),
                                      running.data_ptr() if running is not None else None,
-                                     torch.cuda.current_stream(oc.device).cuda_stream), "mt_mse_fwd_launch")
+                                     L.raw_stream(oc.device)), "mt_mse_fwd_launch")
         ctx.save_for_backward(grad)
         ctx.shape = out.shape
         return loss

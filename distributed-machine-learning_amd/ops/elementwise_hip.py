@@ -7,7 +7,7 @@ from . import lib as L
 
 
 def _stream(t: torch.Tensor) -> int:
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return L.raw_stream(t.device)
 
 
 class FusedPosEncDropout(torch.autograd.Function):
@@ -82,7 +82,7 @@ def hip_keep_mask(shape, p: float, device) -> torch.Tensor:
     out = torch.empty(shape, dtype=torch.uint8, device=device)
     seed = next_seed(device)
     L.check(so.mt_keep_mask_launch(out.data_ptr(), out.numel(), seed.data_ptr(), p,
-                                   torch.cuda.current_stream(device).cuda_stream), "mt_keep_mask_launch")
+                                   L.raw_stream(device)), "mt_keep_mask_launch")
     return out
 
 

@@ -69,7 +69,7 @@ class FusedHeadMLP(torch.autograd.Function):
         acts = torch.empty(B, max(hd.act_stride, 1), device=x.device, dtype=torch.float32)
         out = torch.empty(B, ws[-1].shape[0], device=x.device, dtype=torch.float32)
         L.check(so.mt_head_mlp_fwd_launch(C.byref(hd), x.data_ptr(), x.stride(0), acts.data_ptr(), out.data_ptr(), B,
-                                          torch.cuda.current_stream(x.device).cuda_stream), "mt_head_mlp_fwd_launch")
+                                          L.raw_stream(x.device)), "mt_head_mlp_fwd_launch")
         ctx.save_for_backward(x, acts, *ws, *bs)
         ctx.n = n
         return out
@@ -90,5 +90,5 @@ class FusedHeadMLP(torch.autograd.Function):
         L.check(so.mt_head_mlp_bwd_launch(C.byref(hd), x.data_ptr(), x.stride(0), acts.data_ptr(),
                                           dout.contiguous().data_ptr(), dz.data_ptr(),
                                           dx.data_ptr() if dx is not None else None, x.shape[1], B,
-                                          torch.cuda.current_stream(x.device).cuda_stream), "mt_head_mlp_bwd_launch")
+                                          L.raw_stream(x.device)), "mt_head_mlp_bwd_launch")
         return (dx, None, *dws, *dbs)

@@ -35,7 +35,7 @@ class FusedResidualLayerNorm(torch.autograd.Function):
         L.check(so.mt_ln_fwd_launch(xf.data_ptr(), rf.data_ptr(), keep_u8.data_ptr() if keep_u8 is not None else None,
                                     w.data_ptr(), b.data_ptr(), y.data_ptr(), z.data_ptr(), stats.data_ptr(), M, d,
                                     float(eps), keep_scale, seed.data_ptr() if seed is not None else None,
-                                    float(dropout_p), torch.cuda.current_stream(x.device).cuda_stream),
+                                    float(dropout_p), L.raw_stream(x.device)),
                 "mt_ln_fwd_launch")
         ctx.save_for_backward(z, stats, w, keep_u8 if keep_u8 is not None else torch.empty(0, device=x.device))
         ctx.meta = (keep is not None, keep_scale, x.shape)
@@ -56,6 +56,6 @@ class FusedResidualLayerNorm(torch.autograd.Function):
                                     keep_u8.data_ptr() if has_keep else None, w.data_ptr(), dx.data_ptr(),
                                     dres.data_ptr(), part.data_ptr(), M, d, keep_scale,
                                     ctx.seed.data_ptr() if ctx.seed is not None else None, ctx.p,
-                                    torch.cuda.current_stream(z.device).cuda_stream), "mt_ln_bwd_launch")
+                                    L.raw_stream(z.device)), "mt_ln_bwd_launch")
         dwb = part.sum(0)
         return dx.view(shape), dres.view(shape), dwb[0], dwb[1], None, None, None, None

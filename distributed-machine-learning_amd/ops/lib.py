@@ -240,3 +240,11 @@ def check(code: int, what: str) -> None:
 def current_stream_ptr() -> int:
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def raw_stream(device) -> int:
+    """Handle of the current HIP stream of ``device`` (a ``torch.device`` or a tensor's ``.device``) without building a
+    ``torch.cuda.Stream`` object: this sits on the launch path of every kernel binding."""
+    import torch
+    idx = device.index
+    return torch._C._cuda_getCurrentRawStream(idx if idx is not None else torch.cuda.current_device())

@@ -113,7 +113,7 @@ class SmallLinear(torch.autograd.Function):
         y = torch.empty(xc.shape[0], out_f, device=x.device, dtype=torch.float32)
         L.check(so.mt_small_linear_fwd_launch(xc.data_ptr(), wc.data_ptr(), bias.data_ptr() if bias is not None else None,
                                               y.data_ptr(), xc.shape[0], in_f, out_f, 0,
-                                              torch.cuda.current_stream(x.device).cuda_stream),
+                                              L.raw_stream(x.device)),
                 "mt_small_linear_fwd_launch")
         return y.view(x.shape[:-1] + (out_f,))
 
@@ -133,7 +133,7 @@ class SmallLinear(torch.autograd.Function):
         L.check(so.mt_small_linear_bwd_tiled_launch(xc.data_ptr(), weight.data_ptr(), dyc.data_ptr(),
                                                     dx.data_ptr() if dx is not None else None, dw.data_ptr(),
                                                     db.data_ptr() if db is not None else None, R, in_f, out_f,
-                                                    SmallLinear.TILE, torch.cuda.current_stream(dev).cuda_stream),
+                                                    SmallLinear.TILE, L.raw_stream(dev)),
                 "mt_small_linear_bwd_tiled_launch")
         return (dx.reshape(x.shape) if dx is not None else None), dw, db
 
@@ -172,7 +172,7 @@ class SplitKLinear(torch.autograd.Function):
         arena = torch.empty(ksplits, slab, device=x.device, dtype=torch.float32)
         db_ptr = arena.data_ptr() + out_f * in_f * 4 if ctx.has_bias else None
         L.check(so.mt_wgrad_single_launch(dyc.data_ptr(), xc.data_ptr(), arena.data_ptr(), db_ptr, M, out_f, in_f,
-                                          ksplits, slab, torch.cuda.current_stream(x.device).cuda_stream),
+                                          ksplits, slab, L.raw_stream(x.device)),
                 "mt_wgrad_single_launch")
         total = arena.sum(0) if ksplits > 1 else arena[0]
         dw = total[:out_f * in_f].view(out_f, in_f)
