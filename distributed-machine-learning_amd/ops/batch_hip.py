@@ -27,16 +27,18 @@ def cursor_batch_ok(perm: torch.Tensor, pos: torch.Tensor, X: torch.Tensor, Y: t
 
 
 class FusedMSE(torch.autograd.Function):
-    """``mean((out - y)^2)``; the same launch stores the gradient and adds the loss to ``running`` (a device scalar)."""
+    """``mean((out - y)^2)``; the same launch stores the gradient, adds the loss to ``running`` (a device scalar) and, if
+    given, advances ``cursor`` (int64 [1]) by ``cursor_inc``."""
 
     @staticmethod
-    def forward(ctx, out, y, running):
+    def forward(ctx, out, y, running, cursor=None, cursor_inc=0):
         so = L.load()
         oc, yc = out.contiguous(), y.contiguous()
         grad = torch.empty_like(oc)
         loss = torch.empty((), device=oc.device, dtype=torch.float32)
         L.check(so.mt_mse_fwd_launch(oc.data_ptr(), yc.data_ptr(), oc.numel(), grad.data_ptr(), loss.data_ptr(),
                                      running.data_ptr() if running is not None else None,
+                                     cursor.data_ptr() if cursor is not None else None, int(cursor_inc),
                                      L.raw_stream(oc.device)), "mt_mse_fwd_launch")
         ctx.save_for_backward(grad)
         ctx.shape = out.shape
@@ -45,4 +47,4 @@ class FusedMSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return (grad * g).view(ctx.shape), None, None
+        return (grad * g).view(ctx.shape), None, None, None, None

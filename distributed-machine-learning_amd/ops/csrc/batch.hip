@@ -7,7 +7,11 @@
 //   mt_cursor_batch   x[i] = X[perm[pos + i]], y[i] = Y[perm[pos + i]] for i < B, with the epoch cursor `pos` and
 //                     the permutation read from device memory (was: index add, three index_select launches)
 //   mt_mse_fwd        loss = mean((out - y)^2), grad = 2 (out - y) / n kept for the backward pass, running += loss
-//                     (was: elementwise square, mean reduction, accumulate, and an elementwise backward)
+//                     (was: elementwise square, mean reduction, accumulate, and an elementwise backward); the same
+//                     single-workgroup launch can advance the epoch cursor, which every workgroup of mt_cursor_batch
+//                     has finished reading by then (stream order)
+//   mt_seed_refill    table[i] = counter + (i + 1) * stride for i < n, counter += n * stride: the per-step refill of
+//                     the dropout seed table (ops/rng.py) in one launch instead of two
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -46,7 +50,8 @@ extern "C" int mt_cursor_batch_launch(const int64_t* perm, const int64_t* pos, l
 // One workgroup (n is a batch: tens to thousands of numbers).  loss and running are f32 scalars in device memory.
 __global__ __launch_bounds__(256) void mt_mse_fwd_kernel(const float* __restrict__ out, const float* __restrict__ y, long n,
                                                          float* __restrict__ grad, float* __restrict__ loss,
-                                                         float* __restrict__ running) {
+                                                         float* __restrict__ running, int64_t* __restrict__ cursor,
+                                                         long cursor_inc) {
   __shared__ float red[256];
   const float inv = 1.f / (float)n;
   float s = 0.f;
@@ -65,12 +70,29 @@ __global__ __launch_bounds__(256) void mt_mse_fwd_kernel(const float* __restrict
     const float l = red[0] * inv;
     loss[0] = l;
     if (running != nullptr) running[0] += l;
+    if (cursor != nullptr) cursor[0] += cursor_inc;
   }
 }
 
 extern "C" int mt_mse_fwd_launch(const float* out, const float* y, long n, float* grad, float* loss, float* running,
-                                 hipStream_t stream) {
+                                 int64_t* cursor, long cursor_inc, hipStream_t stream) {
   if (n <= 0 || !out || !y || !grad || !loss) return -2;
-  hipLaunchKernelGGL(mt_mse_fwd_kernel, dim3(1), dim3(256), 0, stream, out, y, n, grad, loss, running);
+  hipLaunchKernelGGL(mt_mse_fwd_kernel, dim3(1), dim3(256), 0, stream, out, y, n, grad, loss, running, cursor, cursor_inc);
+  return (int)hipGetLastError();
+}
+
+// One workgroup; n <= 256.  Every thread reads the counter before thread 0 advances it (barrier in between).
+__global__ __launch_bounds__(256) void mt_seed_refill_kernel(int64_t* __restrict__ counter, int64_t* __restrict__ table, int n,
+                                                             int64_t stride) {
+  const uint64_t c = (uint64_t)counter[0];
+  __syncthreads();
+  const int i = threadIdx.x;
+  if (i < n) table[i] = (int64_t)(c + (uint64_t)(i + 1) * (uint64_t)stride);      // wraps modulo 2^64
+  if (i == 0) counter[0] = (int64_t)(c + (uint64_t)n * (uint64_t)stride);
+}
+
+extern "C" int mt_seed_refill_launch(int64_t* counter, int64_t* table, int n, int64_t stride, hipStream_t stream) {
+  if (!counter || !table || n <= 0 || n > 256) return -2;
+  hipLaunchKernelGGL(mt_seed_refill_kernel, dim3(1), dim3(256), 0, stream, counter, table, n, stride);
   return (int)hipGetLastError();
 }

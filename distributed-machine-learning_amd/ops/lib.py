@@ -195,8 +195,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_cursor_batch_launch.argtypes = [c_void_p, c_void_p, C.c_long, c_void_p, c_void_p, C.c_long, C.c_long, C.c_long,
                                            c_void_p, c_void_p, C.c_int, c_void_p]
     lib.mt_cursor_batch_launch.restype = C.c_int
-    lib.mt_mse_fwd_launch.argtypes = [c_void_p, c_void_p, C.c_long, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.mt_mse_fwd_launch.argtypes = [c_void_p, c_void_p, C.c_long, c_void_p, c_void_p, c_void_p, c_void_p, C.c_long, c_void_p]
     lib.mt_mse_fwd_launch.restype = C.c_int
+    lib.mt_seed_refill_launch.argtypes = [c_void_p, c_void_p, C.c_int, C.c_int64, c_void_p]
+    lib.mt_seed_refill_launch.restype = C.c_int
     lib.mt_keep_mask_launch.argtypes = [c_void_p, C.c_long, c_void_p, c_float, c_void_p]
     lib.mt_dropout_launch.argtypes = [c_void_p, c_void_p, C.c_long, c_void_p, c_float, C.c_int, c_void_p]
     lib.mt_keep_mask_launch.restype = lib.mt_dropout_launch.restype = C.c_int

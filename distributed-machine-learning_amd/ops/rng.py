@@ -2,7 +2,7 @@
 
 A ``Counter`` is an int64 on the device plus a table of the next ``TABLE`` seeds derived from it.  A dropout site
 takes the next table entry as its seed (a view: no launch); when the table is used up -- and at the start of every
-training step, see ``begin_step`` -- two small launches write a fresh table from the counter and advance the
+training step, see ``begin_step`` -- one small launch writes a fresh table from the counter and advances the
 counter.  The kernels of ``csrc/dropout.hip`` / ``csrc/posenc.hip`` / attention / LayerNorm hash ``(seed, element
 index)``.  Because counter and table live on the device and are advanced *by the issued work itself*, the refill is
 capturable in a hipGraph: a replayed training step draws new masks every time, and nothing depends on the
@@ -56,8 +56,14 @@ class Counter:
     def next(self) -> torch.Tensor:
         """Seed for one dropout site: a [1] int64 view that stays valid for the backward pass."""
         if self.idx >= TABLE:
-            self.table = self.ctr + self._steps          # wraps modulo 2^64
-            self.ctr.add_(_i64(TABLE * _STRIDE))
+            if self.ctr.is_cuda:                         # one launch: write the table, advance the counter
+                from . import lib as L
+                self.table = torch.empty(TABLE, dtype=torch.int64, device=self.ctr.device)
+                L.check(L.load().mt_seed_refill_launch(self.ctr.data_ptr(), self.table.data_ptr(), TABLE, _i64(_STRIDE),
+                                                       L.raw_stream(self.ctr.device)), "mt_seed_refill_launch")
+            else:
+                self.table = self.ctr + self._steps      # wraps modulo 2^64
+                self.ctr.add_(_i64(TABLE * _STRIDE))
             self.idx = 0
         s = self.table[self.idx:self.idx + 1]
         self.idx += 1

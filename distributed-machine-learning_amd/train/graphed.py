@@ -308,7 +308,9 @@ class GraphedTrainer:
     def _step(self, rows: torch.Tensor) -> None:
         self._step_xy(self.X.index_select(0, rows), self.Y.index_select(0, rows))
 
-    def _step_xy(self, x: torch.Tensor, y: torch.Tensor) -> None:
+    def _step_xy(self, x: torch.Tensor, y: torch.Tensor, advance: bool = False) -> bool:
+        """One optimiser step on the batch (x, y).  ``advance``: the epoch cursor should move on by one batch; returns
+        True when that was folded into the fused loss launch (else the caller advances it)."""
         fused_mse = self._fast and type(self.criterion) is torch.nn.MSELoss and self.criterion.reduction == "mean"
         with rng.scope(self.rng):
             rng.begin_step(x.device)          # the seed table is refilled inside the (captured) step
@@ -317,13 +319,14 @@ class GraphedTrainer:
             out = out.float().reshape(y.shape)
             if fused_mse:                     # loss, its gradient and the running sum in one launch
                 from ..ops.batch_hip import FusedMSE
-                loss = FusedMSE.apply(out, y, self.running)
+                loss = FusedMSE.apply(out, y, self.running, self.pos if advance else None, self.B)
             else:
                 loss = self.criterion(out, y)
             loss.backward()
         self.opt.step()
         if not fused_mse:
             self.running += loss.detach()
+        return fused_mse and advance
 
     def seed(self, value: int) -> None:
         """Pin this trainer's dropout counter (stream-ordered)."""
@@ -333,7 +336,8 @@ class GraphedTrainer:
     def _cursor_step(self) -> None:
         if self._fast:                        # batch rows picked at the device cursor in one launch
             from ..ops.batch_hip import cursor_batch
-            self._step_xy(*cursor_batch(self.perm, self.pos, self.X, self.Y, self.B))
+            if self._step_xy(*cursor_batch(self.perm, self.pos, self.X, self.Y, self.B), advance=True):
+                return
         else:
             self._step(self.perm.index_select(0, self.ar + self.pos))
         self.pos += self.B
