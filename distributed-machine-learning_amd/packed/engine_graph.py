@@ -40,17 +40,10 @@ from .engine import TorchPackEngine, _Slot
 from .permutation import permute, round_keys
 from ..models.mlp import MLPTrialSpec, init_mlp_state
 from ..ops import rng
-from ..train.graphed import _CAPTURE_LOCK, FlatOptimizer, FlatParams, GraphedTrainer, _no_gc
+from ..train.graphed import FlatOptimizer, FlatParams, GraphedTrainer
 from ..train.losses import MAPE_EPS, elementwise_loss, get_criterion
 
-# The HIP runtime gives a process four hardware queues by default, and which queue a stream lands on is not something
-# the API tells: measured with the same four trials, four consecutive streams of the framework's pool gave 103 us per
-# step or 175 us per step (two streams sharing a queue) depending on which streams had been handed out before, and eight
-# streams 140.  So the engine takes CANDIDATE_STREAMS streams, times a small captured kernel chain on every window of
-# DEFAULT_STREAMS consecutive ones (some tens of milliseconds, once per engine) and keeps the fastest window.
-DEFAULT_STREAMS = 4
-CANDIDATE_STREAMS = 12
-_CALIBRATED_STREAMS: Dict = {}
+DEFAULT_STREAMS = 4      # = the runtime's hardware queues per process; which streams exactly: packed/streams.py
 SMALL_STEP_ROWS = 4096   # batch x tokens up to which slots are issued concurrently
 
 
@@ -71,14 +64,8 @@ class GraphPackEngine(TorchPackEngine):
         self.prepared_total = 0
         n = int(trainable.model_kwargs.get("streams", os.environ.get("MITUNE_GRAPH_STREAMS", DEFAULT_STREAMS)))
         self._n_streams = max(1, min(n, 16))
-        key = (self.device.index if self.device.index is not None else torch.cuda.current_device(), self._n_streams)
-        cached = _CALIBRATED_STREAMS.get(key)            # the stream pool is per process: calibrate once per process
-        if cached is not None:
-            self._streams, self.stream_window = list(cached[0]), cached[1]
-        else:
-            self._streams = [torch.cuda.Stream(self.device) for _ in range(max(self._n_streams, CANDIDATE_STREAMS))]
-        self._calibrated = cached is not None
-        self._stream_key = key
+        self._streams: List[torch.cuda.Stream] = []     # picked at the first concurrent epoch (packed/streams.py)
+        self._calibrated = False
 
     # ------------------------------------------------------------------ slot management
     def _make(self, trial_index, config, state=None):
@@ -216,58 +203,10 @@ class GraphPackEngine(TorchPackEngine):
         return self._streams
 
     def _calibrate_streams(self) -> None:
-        """Keep the window of ``_n_streams`` consecutive candidate streams on which independent kernel chains overlap best."""
-        import time
+        """Keep the window of consecutive pool streams on which independent kernel chains overlap best."""
+        from .streams import pick_streams
         self._calibrated = True
-        k, cand = self._n_streams, self._streams
-        if len(cand) <= k:
-            return
-        cur = torch.cuda.current_stream(self.device)
-        # Chains of SMALL kernels (a few workgroups, like a small trial's): wide kernels fill the chip and hide which
-        # queue they came from.  512 dependent launches per lane take about 2.5 ms on the GPU against about 0.5 ms of
-        # host time per graph launch, so two lanes sharing a queue show up as nearly twice the time.
-        bufs = [torch.zeros(1 << 14, device=self.device) for _ in range(k)]
-        graphs = []
-        side = torch.cuda.Stream(self.device)
-        try:
-            for b in bufs:                               # one small captured chain per concurrent lane
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    b.add_(1.0)                          # the kernel is loaded before anything is captured
-                    g = torch.cuda.CUDAGraph()
-                    with _CAPTURE_LOCK, _no_gc():
-                        g.capture_begin(capture_error_mode="thread_local")
-                        try:
-                            for _ in range(512):
-                                b.add_(1.0)
-                        finally:
-                            g.capture_end()
-                cur.wait_stream(side)
-                graphs.append(g)
-
-            def run(window) -> float:
-                for st in window:
-                    st.wait_stream(cur)
-                torch.cuda.synchronize(self.device)
-                t0 = time.perf_counter()
-                for g, st in zip(graphs, window):
-                    with torch.cuda.stream(st):
-                        g.replay()
-                torch.cuda.synchronize(self.device)
-                return time.perf_counter() - t0
-
-            best, best_t = 0, float("inf")
-            for off in range(0, len(cand) - k + 1):
-                run(cand[off:off + k])
-                t = run(cand[off:off + k])
-                if t < best_t * 0.85:                    # a later window must be clearly better to replace an earlier one
-                    best, best_t = off, t
-            self._streams = cand[best:best + k]
-            self.stream_window = (best, best_t)
-            _CALIBRATED_STREAMS[self._stream_key] = (tuple(self._streams), self.stream_window)
-        except Exception:                                # noqa: BLE001 - calibration is an optimisation only
-            self._streams = cand[:k]
-            torch.cuda.synchronize(self.device)
+        self._streams, self.stream_window = pick_streams(self.device, self._n_streams)
 
     def _fan_out(self, streams):
         cur = torch.cuda.current_stream(self.device)

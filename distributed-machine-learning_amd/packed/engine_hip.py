@@ -185,11 +185,11 @@ class HipPackEngine(PackEngine):
         # separate HIP streams.  One host thread cannot feed several chains kernel by kernel (a launch costs ~3.5 us
         # of host time), so each chain's steps are captured in blocks of GRAPH_STEPS as a hipGraph that reads its step
         # number from a device counter and is replayed block after block.  OFF by default ("streams": n or
-        # MITUNE_STREAMS=n enables it): measured wall-clock on the 256-trial search, 7.40 s with one chain, 7.86 s with
-        # three and 8.03 s with four -- the grouped launches of even a 16-trial pack are wide enough that splitting them
-        # only adds launches.  (Kernels of a few workgroups each, as in small Transformer trials, do overlap across
+        # MITUNE_STREAMS=n enables it): measured wall-clock on the 256-trial search with streams on distinct hardware
+        # queues, 7.02 s with one chain, 7.12 s with two or three and 7.23 s with four -- the grouped launches of even a
+        # 16-trial pack are wide enough that splitting them only adds launches.  (Kernels of a few workgroups each, as in small Transformer trials, do overlap across
         # streams; packed/engine_graph.py uses that.)
-        self._streams = [torch.cuda.Stream(device=dev) for _ in range(MAX_STREAMS)]
+        self._streams = [torch.cuda.Stream(device=dev) for _ in range(MAX_STREAMS)]     # replaced by a calibrated set when chains are on
         self._counters = torch.zeros(MAX_STREAMS, device=dev, dtype=torch.int32)
         self._chain_scratch = [torch.zeros_like(self.head_scratch) for _ in range(MAX_STREAMS - 1)]
         self._chains: List[_Chain] = []
@@ -491,6 +491,8 @@ class HipPackEngine(PackEngine):
             ch.graph = None
             self._chains.append(ch)
         if n > 1:
+            from .streams import pick_streams
+            self._streams, _ = pick_streams(self.device, MAX_STREAMS)     # streams that land on different hardware queues
             torch.cuda.synchronize(self.device)
             for ch, st in zip(self._chains, self._streams):
                 self._epoch_tables(ch.plan, ch.ids, ch.tag)       # gives the per-epoch tables their (stable) addresses
