@@ -143,7 +143,14 @@ def main():
     assert n_trials == args.trials_per_gpu * n_gpus
     assert analysis.stats["epochs"] == args.steps, (analysis.stats["epochs"], args.steps)
     value = n_trials / elapsed * 3600.0
+    # The baseline figure is for the default budget: 640 trial-epochs per 256 trials on the 1M-row table.  Its cost is
+    # linear in trial-epochs and rows, so for any other --steps / --rows it is rescaled to THIS run's budget
+    # (identical to the constant for the default run, on any number of GPUs).
     baseline = _read_baseline() or BASELINE_TRIALS_PER_HOUR
+    trial_epochs = sum(t.training_iteration for t in analysis.trials)
+    if baseline and trial_epochs > 0:
+        sec_per_trial_epoch = 3600.0 / baseline * 256.0 / 640.0 * (args.rows / 1.0e6)
+        baseline = 3600.0 * n_trials / (trial_epochs * sec_per_trial_epoch)
     best = analysis.best_result or {}
     if comm.rank == 0:
         print(json.dumps({
@@ -151,6 +158,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1000.0,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": (value / baseline) if baseline else None,
+            "baseline_trials_per_hour_same_budget": baseline,
             "dtype": "bf16", "data": "synthetic",
             "config": {"model": "mlp_64-w-w-w-1_width<=512", "trials": n_trials,
                        "trials_per_gpu": args.trials_per_gpu, "rows": args.rows, "features": args.features,
