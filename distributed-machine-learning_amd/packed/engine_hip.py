@@ -287,6 +287,48 @@ class HipPackEngine(PackEngine):
         b.step = a.step
         self._dirty = True
 
+    # ------------------------------------------------------------------ moving a trial to another GPU
+    @property
+    def raw_numel(self) -> int:
+        return 3 * self.stride + 4
+
+    def export_raw(self, slot: int) -> torch.Tensor:
+        """One slot's parameters and both optimiser moment regions as a single device tensor, epoch / step counters in
+        the last four words.  A slot's layout depends on the trial's shape only, so the regions are valid in any slot
+        of any engine built from the same trainable: another GPU's ``import_raw`` copies them in without the host."""
+        s, n = self.slots[slot], self.stride
+        out = torch.empty(self.raw_numel, device=self.device, dtype=torch.float32)
+        for i, slab in enumerate((self.P, self.M, self.V)):
+            out[i * n:(i + 1) * n].copy_(self._region(slab, slot))
+        meta = torch.tensor([s.epoch, s.step, s.trial_index, 0], dtype=torch.int32)
+        out[3 * n:].view(torch.int32).copy_(meta)
+        return out
+
+    def import_raw(self, slot: int, trial_index: int, config: Dict, raw: torch.Tensor) -> None:
+        if slot in self.slots:
+            raise RuntimeError(f"slot {slot} is occupied")
+        n = self.stride
+        if raw.numel() != self.raw_numel:
+            raise ValueError(f"raw slot state of {raw.numel()} words, this engine's slots take {self.raw_numel}")
+        spec = MLPTrialSpec.from_config(config, self.F)
+        epoch, step, owner, _ = raw[3 * n:].view(torch.int32).tolist()
+        if owner != int(trial_index):
+            raise ValueError(f"slot state belongs to trial {owner}, not {trial_index}")
+        s = _HSlot()
+        s.trial_index, s.spec, s.config = int(trial_index), spec, dict(config)
+        s.layout = SlotLayout(spec, self.Fpad)
+        s.epoch, s.step = int(epoch), int(step)
+        raw = raw.to(self.device)
+        for i, slab in enumerate((self.P, self.M, self.V)):
+            self._region(slab, slot).copy_(raw[i * n:(i + 1) * n])
+        for sp in range(MAX_KSPLITS):
+            off = (sp * self.capacity + slot) * self.stride
+            self.G[off:off + self.stride].zero_()
+        self._region(self.Pb, slot).copy_(self._region(self.P, slot).to(torch.bfloat16))
+        self.loss_acc[slot] = 0
+        self.slots[slot] = s
+        self._dirty = True
+
     def import_state(self, slot, state, config):
         keep = self.slots[slot].trial_index
         epoch = self.slots[slot].epoch

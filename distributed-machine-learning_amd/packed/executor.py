@@ -4,7 +4,10 @@ Replaces the reference's "one Ray actor + one GPU per trial" placement
 (/root/reference/ray-tune-hpo-regression.py:475).  Every rank (one process per GPU) runs this
 executor under an identical ``TrialRunner``: searcher and scheduler are replicated and seeded
 alike, so all ranks create the same trials in the same order.  A trial is *owned* by one rank
-(the one with the most free slots when it starts) and only its owner trains it.  After each epoch
+(the one with the most free slots when it starts) and only its owner trains it; once early stopping
+has thinned the GPUs unevenly and no pending trial is left to fill the holes, trials move from the
+fullest GPU to the emptiest (their slab is broadcast over the job's communicator), because a round
+lasts as long as its fullest GPU.  After each epoch
 the ranks all-gather one ``[capacity, 6]`` record table (RCCL over xGMI on a GPU node); every rank
 then feeds the same trial-id-sorted batch of results to its scheduler and reaches the same
 CONTINUE / STOP / RESTART decisions without a coordinator.  Stopped trials free their slot at once
@@ -90,7 +93,8 @@ class PackedExecutor(Executor):
         self.runner = None
         self.stats: Dict[str, Any] = {"epochs": 0, "slot_epochs": 0, "train_s": 0.0, "eval_s": 0.0,
                                       "comm_s": 0.0, "engine": self.engine.name, "world_size": self.world,
-                                      "capacity_per_gpu": self.capacity, "exploits": 0, "diverged": 0}
+                                      "capacity_per_gpu": self.capacity, "exploits": 0, "diverged": 0,
+                                      "migrations": 0, "migrate_s": 0.0}
 
     def bind_runner(self, runner) -> None:
         self.runner = runner
@@ -124,6 +128,8 @@ class PackedExecutor(Executor):
             return []
         if self._n_undecided > 0:
             return []      # the runner still owes decisions for the previous round
+        if self.world > 1 and self.t.rebalance_gap > 0:
+            self._rebalance()      # the runner has filled what it could with pending trials; even out what is left
         t0 = time.time()
         begin = getattr(self.engine, "train_epoch_begin", None)
         if begin is not None and self.world == 1 and self.runner is not None and hasattr(self.engine, "prepare"):
@@ -299,6 +305,47 @@ class PackedExecutor(Executor):
             send_state(self.comm, self.engine.export(dslot), rrank)
         elif self.rank == rrank:
             self.engine.import_state(rslot, recv_state(self.comm, self.engine.export(rslot), drank), tr.config)
+
+    # ------------------------------------------------------------------ load balance between GPUs
+    def _rebalance(self) -> None:
+        """Move trials from the fullest rank to the emptiest until their live-trial counts differ by less than
+        ``rebalance_gap``.  Every rank holds the same placement tables, so all of them plan the same moves in the same
+        order with no message exchanged; a move itself is one broadcast from the trial's old owner."""
+        t0, moved = time.time(), False
+        while True:
+            load = [self.capacity - len(self._free[r]) for r in range(self.world)]
+            hi = max(range(self.world), key=lambda r: (load[r], -r))
+            lo = min(range(self.world), key=lambda r: (load[r], r))
+            if load[hi] - load[lo] < self.t.rebalance_gap or not self._free[lo]:
+                break
+            tid = max((t for t, (r, _) in self._place.items() if r == hi), key=lambda t: self._live[t].index)
+            self._move(self._live[tid], lo)
+            moved = True
+        if moved:
+            self.stats["migrate_s"] += time.time() - t0
+
+    def _move(self, tr: Trial, dst: int) -> None:
+        src, sslot = self._place[tr.trial_id]
+        dslot = self._free[dst].pop(0)
+        eng = self.engine
+        if hasattr(eng, "export_raw"):
+            # parameters and optimiser moments travel as the device-resident slab they already are: HBM -> xGMI -> HBM
+            buf = eng.export_raw(sslot) if self.rank == src else \
+                torch.empty(eng.raw_numel, dtype=torch.float32, device=self.device)
+            self.comm.broadcast(buf, src=src)
+            if self.rank == dst:
+                eng.import_raw(dslot, tr.index, tr.config, buf)
+        else:
+            state = self.comm.broadcast_object(eng.export(sslot) if self.rank == src else None, src=src)
+            if self.rank == dst:
+                eng.load(dslot, tr.index, tr.config, state=state)
+        if self.rank == src:
+            eng.evict(sslot)
+        self._free[src].append(sslot)
+        self._free[src].sort()
+        self._place[tr.trial_id] = (dst, dslot)
+        tr.placement = {"rank": dst, "slot": dslot}
+        self.stats["migrations"] += 1
 
     def shutdown(self) -> None:
         self.engine.close()

@@ -29,6 +29,8 @@ class PackedTrainable:
     checkpoint_at_end: bool = False                      # write model.pt / optimizer.pt when a trial ends
     checkpoint_freq: int = 0                             # also every k epochs (0 = never)
     on_nonfinite: str = "stop"                           # NaN/inf loss in a slot: "stop" | "error" | "ignore"
+    rebalance_gap: int = 2                               # move trials between GPUs once live-trial counts differ by
+                                                         # this much (0 = a trial never leaves its first GPU)
     name: str = "packed"
     model_kwargs: Dict[str, Any] = field(default_factory=dict)
 

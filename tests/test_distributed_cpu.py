@@ -88,6 +88,34 @@ def test_pbt_exploit_moves_weights_between_ranks():
     assert all(v[0] == 6 for v in r0.values())                # PBT never stops a trial early
 
 
+class _StopEvenTrials(ASHAScheduler):
+    """Stops every even-numbered trial after its first epoch: with trials dealt to two ranks in turn that empties
+    rank 0 and leaves rank 1 full, whatever the losses are."""
+
+    def on_batch_result(self, runner, trials, results):
+        return [self.STOP if (t.index % 2 == 0 or r["training_iteration"] >= 4) else self.CONTINUE
+                for t, r in zip(trials, results)]
+
+
+def test_trials_move_to_idle_ranks_without_changing_their_trajectory():
+    def fn(comm, gap=2):
+        train, val = _data()
+        tr = PackedTrainable(train=train, val=val, max_epochs=4, engine="torch", capacity=4, rebalance_gap=gap)
+        ex = PackedExecutor(tr, comm=comm, device=torch.device("cpu"), capacity=4, seed=0)
+        an = mitune.run(tr, config=SPACE, num_samples=8, executor=ex, seed=0, verbose=0,
+                        scheduler=_StopEvenTrials(metric="validation_loss", mode="min", max_t=4))
+        return ({t.trial_id: (t.training_iteration, t.last_result["validation_loss"]) for t in an.trials},
+                {t.trial_id: t.placement["rank"] for t in an.trials}, an.stats["migrations"])
+
+    (r0, p0, m0), (r1, p1, m1) = _run_ranks(2, fn)
+    assert r0 == r1 and p0 == p1 and m0 == m1 == 2          # ranks held 0 and 4 trials: two of them moved
+    odd = [tid for tid, (it, _) in r0.items() if it == 4]
+    assert len(odd) == 4 and sorted(p0[t] for t in odd) == [0, 0, 1, 1]
+    (s0, q0, n0), _ = _run_ranks(2, lambda c: fn(c, gap=0))
+    assert n0 == 0 and sorted(q0[t] for t in odd) == [1, 1, 1, 1]
+    assert s0 == r0                                           # bit-identical losses with and without the moves
+
+
 def _gloo_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from mitune.parallel.comm import TorchDistComm
@@ -96,7 +124,8 @@ def _gloo_worker(rank, world, port, out_dir):
     t = torch.tensor([float(rank + 1)])
     comm.all_reduce(t)
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
-        json.dump({"res": res, "sum": t.item(), "comm_s": an.stats["comm_s"]}, f)
+        json.dump({"res": res, "sum": t.item(), "comm_s": an.stats["comm_s"],
+                   "migrations": an.stats["migrations"]}, f)
     comm.close()
 
 
@@ -110,6 +139,31 @@ def test_gloo_two_process_search_agrees(tmp_path):
     assert a["res"] == b["res"] and a["sum"] == 3.0
     single, _ = _search(LocalComm(), num_samples=8, capacity=8)
     assert {k: v[:2] for k, v in a["res"].items()} == {k: list(v[:2]) for k, v in single.items()}
+
+
+def _gloo_move_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from mitune.parallel.comm import TorchDistComm
+    comm = TorchDistComm(backend="gloo", rank=rank, world_size=world)
+    res, an = _search(comm, num_samples=8, capacity=4,
+                      scheduler=_StopEvenTrials(metric="validation_loss", mode="min", max_t=4))
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump({"res": res, "migrations": an.stats["migrations"]}, f)
+    comm.close()
+
+
+def test_gloo_trial_moves_between_processes(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gloo_move_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = json.load(open(tmp_path / "rank0.json"))
+    b = json.load(open(tmp_path / "rank1.json"))
+    assert a == b and a["migrations"] == 2
+    single, _ = _search(LocalComm(), num_samples=8, capacity=8,
+                        scheduler=_StopEvenTrials(metric="validation_loss", mode="min", max_t=4))
+    assert {k: v[:2] for k, v in a["res"].items()} == {k: list(v[:2]) for k, v in single.items()}
+    assert sorted(v[2] for v in a["res"].values() if v[0] == 4) == [0, 0, 1, 1]
 
 
 def _rank_loss_worker(rank, world, port, out_dir):

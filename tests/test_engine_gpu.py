@@ -77,6 +77,93 @@ def test_packing_invariance_is_bitwise():
         assert torch.equal(v, packed[2]["model"][k]), k
 
 
+def test_a_slot_moved_between_engines_continues_bit_for_bit():
+    """export_raw -> import_raw (what a trial's move to another GPU does) mid-training changes nothing."""
+    from mitune.packed import PackedTrainable
+    from mitune.packed.engine_hip import HipPackEngine
+    train, val = _data(seed=4)
+    tr = PackedTrainable(train=train, val=val, max_epochs=4, val_chunk=512,
+                         model_kwargs={"max_width": 256, "max_layers": 3, "max_batch": 512})
+    hist, stay = _run(HipPackEngine, tr, [(11, CONFIGS[1]), (12, CONFIGS[3])], [1, 4], 4, device="cuda", capacity=6, seed=2)
+    a = HipPackEngine(tr, device="cuda", capacity=6, seed=2)
+    b = HipPackEngine(tr, device="cuda", capacity=6, seed=2)
+    a.load(1, 11, CONFIGS[1])
+    a.load(4, 12, CONFIGS[3])
+    b.load(0, 20, CONFIGS[0])                        # the destination pack has a tenant of its own
+    for _ in range(2):
+        a.train_epoch()
+        b.train_epoch()
+    raw = a.export_raw(4)
+    assert raw.numel() == a.raw_numel and raw.device.type == "cuda"
+    a.evict(4)
+    with pytest.raises(ValueError):
+        b.import_raw(3, 13, CONFIGS[3], raw)         # a slab is bound to its trial
+    b.import_raw(3, 12, CONFIGS[3], raw)
+    for _ in range(2):
+        a.train_epoch()
+        b.train_epoch()
+    assert b.evaluate()[3] == hist[-1][4] and a.evaluate()[1] == hist[-1][1]
+    moved = b.export(3)
+    for k, v in stay[4]["model"].items():
+        assert torch.equal(v, moved["model"][k]), k
+    for k, v in stay[4]["optimizer"]["exp_avg_sq"].items():
+        assert torch.equal(v, moved["optimizer"]["exp_avg_sq"][k]), k
+    assert moved["epoch"] == 4 and moved["step"] == stay[4]["step"]
+
+
+def test_two_ranks_rebalance_hip_packs_after_uneven_stopping():
+    """Two executors (ranks wired through threads, both packs on this GPU): one rank loses all its trials after the
+    first epoch, two of the other's move over as device slabs, and no trial's losses change."""
+    import threading
+    import mitune
+    from mitune import tune
+    from mitune.packed import PackedExecutor, PackedTrainable
+    from mitune.parallel.comm import ThreadComm
+    from mitune.schedulers import ASHAScheduler
+
+    class StopEven(ASHAScheduler):
+        def on_batch_result(self, runner, trials, results):
+            return [self.STOP if (t.index % 2 == 0 or r["training_iteration"] >= 4) else self.CONTINUE
+                    for t, r in zip(trials, results)]
+
+    train, val = _data(n=8000, f=16, seed=6)
+    space = {"width": tune.choice([32, 64, 128]), "num_layers": tune.choice([1, 2]),
+             "learning_rate": tune.loguniform(1e-3, 1e-2), "batch_size": tune.choice([128, 256])}
+
+    def search(gap):
+        comms = ThreadComm.make(2)
+        out, errs = [None, None], []
+
+        def body(r):
+            try:
+                tr = PackedTrainable(train=train, val=val, max_epochs=4, val_chunk=2048, capacity=4, rebalance_gap=gap,
+                                     model_kwargs={"max_width": 128, "max_layers": 2, "max_batch": 256})
+                ex = PackedExecutor(tr, comm=comms[r], device=torch.device("cuda", 0), capacity=4, seed=0)
+                an = mitune.run(tr, config=space, num_samples=8, executor=ex, seed=0, verbose=0,
+                                scheduler=StopEven(metric="validation_loss", mode="min", max_t=4))
+                out[r] = ({t.trial_id: (t.training_iteration, t.last_result["validation_loss"], t.last_result["train_loss"])
+                           for t in an.trials},
+                          sorted(t.placement["rank"] for t in an.trials if t.training_iteration == 4),
+                          an.stats["migrations"], an.stats["engine"])
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+                comms[r].hub.barrier.abort()
+
+        ths = [threading.Thread(target=body, args=(r,)) for r in range(2)]
+        [t.start() for t in ths]
+        [t.join(timeout=100) for t in ths]
+        if errs:
+            raise errs[0]
+        assert out[0] == out[1]
+        return out[0]
+
+    res, ranks, moves, engine = search(2)
+    res0, ranks0, moves0, _ = search(0)
+    assert engine == "hip" and moves == 2 and ranks == [0, 0, 1, 1]
+    assert moves0 == 0 and ranks0 == [1, 1, 1, 1]
+    assert res == res0
+
+
 def test_end_to_end_packed_search_on_gpu(tmp_path):
     import mitune
     from mitune import tune
