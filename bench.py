@@ -169,6 +169,7 @@ def main():
             "elapsed_s": elapsed, "train_s": analysis.stats.get("train_s"), "eval_s": analysis.stats.get("eval_s"),
             "comm_s": analysis.stats.get("comm_s"), "slot_epochs": analysis.stats.get("slot_epochs"),
             "early_stopped": analysis.stats.get("num_stopped_early"),
+            "migrations": analysis.stats.get("migrations"), "migrate_s": analysis.stats.get("migrate_s"),
         }))
     comm.close()
 

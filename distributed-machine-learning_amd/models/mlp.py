@@ -115,8 +115,9 @@ def init_mlp_state(spec: MLPTrialSpec, seed: int, trial_index: int) -> Dict[str,
     dims = spec.layer_dims
     for li, (o, i) in enumerate(dims):
         bound = 1.0 / math.sqrt(i)
-        w = (torch.rand(o, i, generator=g) * 2 - 1) * bound
-        b = (torch.rand(o, generator=g) * 2 - 1) * bound
+        # in place: the same three roundings per element as ``(u * 2 - 1) * bound`` without three temporaries
+        w = torch.rand(o, i, generator=g).mul_(2).sub_(1).mul_(bound)
+        b = torch.rand(o, generator=g).mul_(2).sub_(1).mul_(bound)
         name = f"layers.{li}" if li < len(dims) - 1 else "head"
         state[f"{name}.weight"], state[f"{name}.bias"] = w, b
     return state

@@ -179,6 +179,7 @@ class HipPackEngine(PackEngine):
         self.head_scratch = torch.zeros(int(self.lib.mt_head_scratch_floats(T, self.rows_max, self.max_width)),
                                         device=dev, dtype=torch.float32)
         self.slots: Dict[int, _HSlot] = {}
+        self._stage: Optional[torch.Tensor] = None
         self._tables: Dict[str, Any] = {}
         self._dirty = True
         # Optional concurrent chains: trials are independent, so a pack can be split into up to MAX_STREAMS chains on
@@ -208,14 +209,18 @@ class HipPackEngine(PackEngine):
         return slab[slot * self.stride:(slot + 1) * self.stride]
 
     def _write_params(self, slot: int, lay: SlotLayout, state: Dict[str, torch.Tensor], slab: torch.Tensor) -> None:
-        host = torch.zeros(self.stride, dtype=torch.float32)
+        host = self._stage                      # one pinned staging region for every upload, not a fresh one per call
+        if host is None:
+            host = self._stage = torch.zeros(self.stride, dtype=torch.float32).pin_memory()
+        else:
+            host.zero_()
         for key, off, (rows, cols), ld in lay.names():
             src = state[key].detach().to("cpu", torch.float32).reshape(rows, cols)
             if ld == cols:
                 host[off:off + rows * cols] = src.reshape(-1)
             else:       # padded row stride: the pad columns stay zero
                 host[off:off + rows * ld].view(rows, ld)[:, :cols] = src
-        self._region(slab, slot).copy_(host.to(self.device))
+        self._region(slab, slot).copy_(host)      # blocking: the staging region is free again on return
 
     def _read_params(self, slot: int, lay: SlotLayout, slab: torch.Tensor) -> Dict[str, torch.Tensor]:
         host = self._region(slab, slot).detach().to("cpu", torch.float32)

@@ -96,6 +96,10 @@ class PackedExecutor(Executor):
                                       "capacity_per_gpu": self.capacity, "exploits": 0, "diverged": 0,
                                       "migrations": 0, "migrate_s": 0.0}
 
+        if self.world > 1 and self.t.rebalance_gap > 0 and hasattr(self.engine, "raw_numel"):
+            # the first use of a collective kind sets up its connections: paid here, not inside a scheduling round
+            self.comm.broadcast(torch.zeros(self.engine.raw_numel, dtype=torch.float32, device=self.device), src=0)
+
     def bind_runner(self, runner) -> None:
         self.runner = runner
 

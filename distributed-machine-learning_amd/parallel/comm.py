@@ -111,6 +111,14 @@ class TorchDistComm(Comm):
             self._own = True
         self.backend = dist.get_backend()
         self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+        # One process per GPU: the ranks of a node share its CPUs.  Left alone, every rank keeps a full-size intra-op
+        # thread pool whose idle workers spin; together they overrun the node's CPU allowance and each small host-side
+        # tensor op then stalls for milliseconds (measured with two ranks: 1.2 ms per in-place multiply of a weight
+        # matrix, 44 ms per trial load instead of under 1 ms).  The host work of a rank is small tensors: a few threads.
+        local = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+        if local > 1:
+            want = int(os.environ.get("MITUNE_CPU_THREADS", "0") or 0) or max(1, min(4, torch.get_num_threads() // local))
+            torch.set_num_threads(want)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
         self.device = device
@@ -134,6 +142,12 @@ class TorchDistComm(Comm):
         return self.dist.all_reduce(t, op=rop, async_op=async_op)
 
     def broadcast(self, t, src=0):
+        if t.device != self.device:      # a GPU-resident buffer under the CPU backend: staged through the host
+            buf = t.to(self.device)
+            self.dist.broadcast(buf, src=src)
+            if self.rank != src:
+                t.copy_(buf)
+            return t
         self.dist.broadcast(t, src=src)
         return t
 
