@@ -142,9 +142,12 @@ def test_gloo_two_process_search_agrees(tmp_path):
 
 
 def _gloo_move_worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_WORLD_SIZE=str(world))           # as the launcher sets it for the ranks of one node
     from mitune.parallel.comm import TorchDistComm
+    torch.set_num_threads(8)
     comm = TorchDistComm(backend="gloo", rank=rank, world_size=world)
+    assert torch.get_num_threads() == 4                       # ranks sharing a node do not keep full-size thread pools
     res, an = _search(comm, num_samples=8, capacity=4,
                       scheduler=_StopEvenTrials(metric="validation_loss", mode="min", max_t=4))
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
