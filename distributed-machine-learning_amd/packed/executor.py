@@ -316,11 +316,12 @@ class PackedExecutor(Executor):
         ``rebalance_gap``.  Every rank holds the same placement tables, so all of them plan the same moves in the same
         order with no message exchanged; a move itself is one broadcast from the trial's old owner."""
         t0, moved = time.time(), False
+        gap = max(2, int(self.t.rebalance_gap))      # a difference of one cannot be improved, only passed back and forth
         while True:
             load = [self.capacity - len(self._free[r]) for r in range(self.world)]
             hi = max(range(self.world), key=lambda r: (load[r], -r))
             lo = min(range(self.world), key=lambda r: (load[r], r))
-            if load[hi] - load[lo] < self.t.rebalance_gap or not self._free[lo]:
+            if load[hi] - load[lo] < gap or not self._free[lo]:
                 break
             tid = max((t for t, (r, _) in self._place.items() if r == hi), key=lambda t: self._live[t].index)
             self._move(self._live[tid], lo)
