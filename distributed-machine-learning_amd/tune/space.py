@@ -329,25 +329,56 @@ def _copy_containers(node: Any) -> Any:
     return node
 
 
-def resolve(space: Dict, rng: np.random.Generator, grid_assignment: Dict[Tuple, Any] | None = None) -> Dict:
+class _Plan:
+    """What ``resolve`` finds out about a search space by walking it, kept by ``generate_variants`` for all its draws
+    (every rank of a multi-GPU search draws every trial, so this walk was paid trials x ranks times)."""
+    __slots__ = ("plain", "functions", "flat")
+
+    def __init__(self, space: Dict):
+        self.plain: List[Tuple[Tuple, Domain]] = []
+        self.functions: List[Tuple[Tuple, Function]] = []
+        for path, leaf in _walk(space):
+            if isinstance(leaf, GridSearch):
+                raise ValueError(f"grid_search at {path} needs a grid assignment; use generate_variants()")
+            if isinstance(leaf, Function):
+                self.functions.append((path, leaf))
+            elif isinstance(leaf, Domain):
+                self.plain.append((path, leaf))
+        self.flat = not any(isinstance(v, (dict, list, tuple)) for v in space.values())
+
+
+def resolve(space: Dict, rng: np.random.Generator, grid_assignment: Dict[Tuple, Any] | None = None,
+            plan: "_Plan | None" = None) -> Dict:
     """Sample one concrete config from ``space``.
 
     Plain domains are drawn in dict order (so a fixed seed gives a fixed config);
     ``sample_from`` leaves are retried until every key they read has been resolved, which
     gives dependency-ordered evaluation without declaring the dependencies.
     """
-    cfg = _copy_containers(space)
-    if grid_assignment:
-        for p, v in grid_assignment.items():
-            _set(cfg, p, v)
-    pending: List[Tuple[Tuple, Function]] = []
-    for path, leaf in list(_walk(cfg)):
-        if isinstance(leaf, GridSearch):
-            raise ValueError(f"grid_search at {path} needs a grid assignment; use generate_variants()")
-        if isinstance(leaf, Function):
-            pending.append((path, leaf))
-        elif isinstance(leaf, Domain):
-            _set(cfg, path, leaf.sample(rng))
+    pending: List[Tuple[Tuple, Function]]
+    if plan is not None and not grid_assignment:
+        if plan.flat:
+            cfg = dict(space)
+            for (key,), leaf in plan.plain:
+                cfg[key] = leaf.sample(rng)
+        else:
+            cfg = _copy_containers(space)
+            for path, leaf in plan.plain:
+                _set(cfg, path, leaf.sample(rng))
+        pending = list(plan.functions)
+    else:
+        cfg = _copy_containers(space)
+        if grid_assignment:
+            for p, v in grid_assignment.items():
+                _set(cfg, p, v)
+        pending = []
+        for path, leaf in list(_walk(cfg)):
+            if isinstance(leaf, GridSearch):
+                raise ValueError(f"grid_search at {path} needs a grid assignment; use generate_variants()")
+            if isinstance(leaf, Function):
+                pending.append((path, leaf))
+            elif isinstance(leaf, Domain):
+                _set(cfg, path, leaf.sample(rng))
     while pending:
         still: List[Tuple[Tuple, Function]] = []
         for path, fn in pending:
@@ -375,12 +406,13 @@ def generate_variants(space: Dict, num_samples: int, seed: int | None = 0) -> It
     """``num_samples`` random draws, multiplied by the cross product of any ``grid_search`` axes."""
     rng = np.random.default_rng(seed)
     axes = grid_axes(space)
+    plan = None if axes else _Plan(space)
     for _ in range(num_samples):
         if axes:
             for combo in itertools.product(*[vals for _, vals in axes]):
                 yield resolve(space, rng, {p: v for (p, _), v in zip(axes, combo)})
         else:
-            yield resolve(space, rng)
+            yield resolve(space, rng, plan=plan)
 
 
 def count_variants(space: Dict, num_samples: int) -> int:
