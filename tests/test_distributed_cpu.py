@@ -260,3 +260,19 @@ def test_dp_trainable_under_replicated_driver():
 
     r0, r1 = _run_ranks(2, fn)
     assert r0 == r1 and len(r0) == 4
+
+
+def test_four_ranks_stay_balanced_through_an_asha_search():
+    """The headline search's placement replayed on a stand-in engine: with moves the live-trial counts of the ranks
+    never differ by more than one at the start of a round; without them early stopping leaves them uneven."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rebalance_sim", os.path.join(root, "bench", "rebalance_sim.py"))
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    live, stats = sim.run(4, 32, 8, gap=2)
+    assert live.shape == (4, 8) and int((live.max(0) - live.min(0)).max()) <= 1 and stats["migrations"] > 0
+    assert live.sum(0).tolist() == [128, 32, 32, 32, 8, 8, 8, 8]          # rungs at 1 and 4, reduction factor 4
+    still, stats0 = sim.run(4, 32, 8, gap=0)
+    assert stats0["migrations"] == 0 and int((still.max(0) - still.min(0)).max()) > 1
+    assert still.sum(0).tolist() == live.sum(0).tolist()                  # the moves change where, never what
