@@ -38,6 +38,8 @@ class PackEngine:
 
     capacity: int
     name = "base"
+    move_cost_s = 0.0        # what bringing a trial up from its exported state costs (seconds); weighed against the round
+                             # time a move to an emptier GPU saves
 
     def load(self, slot: int, trial_index: int, config: Dict, state: Optional[Dict] = None) -> None:
         raise NotImplementedError

@@ -49,6 +49,7 @@ SMALL_STEP_ROWS = 4096   # batch x tokens up to which slots are issued concurren
 
 class GraphPackEngine(TorchPackEngine):
     name = "graph"
+    move_cost_s = 0.02       # a moved trial is built, uploaded and captured again on its new GPU
     _eval_warmed = threading.local()   # .done on threads where a validation pass has run once eagerly
 
     def __init__(self, trainable, device="cuda", capacity: Optional[int] = None, seed: int = 0):

@@ -84,6 +84,7 @@ class PackedExecutor(Executor):
         self._queued: List[Event] = []
         self._awaiting: Dict[str, Optional[str]] = {}          # trial_id -> decision (None = not yet)
         self._epoch_time = 0.0
+        self._slot_time: Optional[float] = None   # seconds per live trial of the costliest rank, last round (replicated)
         self._retired_last = 0             # slots freed by the previous round's decisions
         self._retired_now = 0
         self._n_undecided = 0
@@ -151,6 +152,9 @@ class PackedExecutor(Executor):
             tr = self._live[mine[slot]]
             rows_local[slot] = [float(tr.index), float(tr.training_iteration + 1), m["train_loss"], m["validation_loss"],
                                 m["validation_mse"], m["validation_mape"]]
+        # one more row: this rank's time for the round and how many trials it spent it on; gathered with the metrics, so
+        # that every rank knows every rank's cost per trial and all of them weigh a move the same way
+        rows_local.append([-2.0, t2 - t0, float(len(local)), 0.0, 0.0, 0.0])
         table = torch.tensor(rows_local, dtype=torch.float64)         # one conversion, not one per slot
         try:
             gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
@@ -171,6 +175,8 @@ class PackedExecutor(Executor):
         by_index = {tr.index: tr for tr in self._live.values()}
         # numpy, not torch: a masked select + argsort of a few hundred rows costs tens of milliseconds per call through
         # the tensor library's intra-op thread pool and one millisecond here
+        per_rank = gathered.reshape(self.world, self.capacity + 1, _REC)[:, -1, 1:3].tolist()
+        self._slot_time = max((sec / n for sec, n in per_rank if n > 0), default=None)
         rows = gathered.reshape(-1, _REC).numpy()
         rows = rows[rows[:, 0] >= 0]
         rows = rows[np.argsort(rows[:, 0], kind="stable")]
@@ -315,6 +321,12 @@ class PackedExecutor(Executor):
         """Move trials from the fullest rank to the emptiest until their live-trial counts differ by less than
         ``rebalance_gap``.  Every rank holds the same placement tables, so all of them plan the same moves in the same
         order with no message exchanged; a move itself is one broadcast from the trial's old owner."""
+        # A move has a price (building the trial again on the other GPU; for the slab engines next to nothing) and
+        # buys one trial's time per round off the fullest rank.  It has to pay within the two rounds a trial that just
+        # survived a rung can be expected to run at the least.  Both numbers are the same on every rank.
+        cost = float(getattr(self.engine, "move_cost_s", 0.0))
+        if cost > 0.0 and (self._slot_time is None or 2.0 * self._slot_time < cost):
+            return
         t0, moved = time.time(), False
         gap = max(2, int(self.t.rebalance_gap))      # a difference of one cannot be improved, only passed back and forth
         while True:

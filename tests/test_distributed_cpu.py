@@ -111,6 +111,14 @@ def test_trials_move_to_idle_ranks_without_changing_their_trajectory():
     assert r0 == r1 and p0 == p1 and m0 == m1 == 2          # ranks held 0 and 4 trials: two of them moved
     odd = [tid for tid, (it, _) in r0.items() if it == 4]
     assert len(odd) == 4 and sorted(p0[t] for t in odd) == [0, 0, 1, 1]
+    # an engine that declares moves dearer than the round time they save keeps its trials where they are
+    from mitune.packed.engine import TorchPackEngine
+    TorchPackEngine.move_cost_s = 1e6
+    try:
+        (_, q1, n1), _ = _run_ranks(2, fn)
+    finally:
+        TorchPackEngine.move_cost_s = 0.0
+    assert n1 == 0 and sorted(q1[t] for t in odd) == [1, 1, 1, 1]
     (s0, q0, n0), _ = _run_ranks(2, lambda c: fn(c, gap=0))
     assert n0 == 0 and sorted(q0[t] for t in odd) == [1, 1, 1, 1]
     assert s0 == r0                                           # bit-identical losses with and without the moves
