@@ -227,7 +227,9 @@ class TrialRunner:
         if self._should_stop(trial, result):
             decision = STOP
         elif decision == STOP:
-            self.stats["num_stopped_early"] += 1
+            max_t = getattr(self.scheduler, "max_t", None)
+            if max_t is None or result.get("training_iteration", 0) < max_t:     # a trial that ran its full budget
+                self.stats["num_stopped_early"] += 1                              # was not stopped early
         self._pending_decision[trial.trial_id] = decision
         self.executor.resolve(trial, decision)
 
