@@ -345,17 +345,22 @@ class PackedExecutor(Executor):
         src, sslot = self._place[tr.trial_id]
         dslot = self._free[dst].pop(0)
         eng = self.engine
-        if hasattr(eng, "export_raw"):
-            # parameters and optimiser moments travel as the device-resident slab they already are: HBM -> xGMI -> HBM
-            buf = eng.export_raw(sslot) if self.rank == src else \
-                torch.empty(eng.raw_numel, dtype=torch.float32, device=self.device)
-            self.comm.broadcast(buf, src=src)
-            if self.rank == dst:
-                eng.import_raw(dslot, tr.index, tr.config, buf)
-        else:
-            state = self.comm.broadcast_object(eng.export(sslot) if self.rank == src else None, src=src)
-            if self.rank == dst:
-                eng.load(dslot, tr.index, tr.config, state=state)
+        try:
+            if hasattr(eng, "export_raw"):
+                # parameters and optimiser moments travel as the device-resident slab they already are: HBM -> xGMI -> HBM
+                buf = eng.export_raw(sslot) if self.rank == src else \
+                    torch.empty(eng.raw_numel, dtype=torch.float32, device=self.device)
+                payload = self.comm.broadcast(buf, src=src)
+            else:
+                payload = self.comm.broadcast_object(eng.export(sslot) if self.rank == src else None, src=src)
+        except Exception as e:          # noqa: BLE001 - RCCL / gloo raise backend-specific types
+            raise RankLostError(f"rank {self.rank} of {self.world}: moving trial {tr.trial_id} from rank {src} to "
+                                f"rank {dst} failed ({type(e).__name__}: {e})") from e
+        if self.rank == dst:
+            if hasattr(eng, "import_raw"):
+                eng.import_raw(dslot, tr.index, tr.config, payload)
+            else:
+                eng.load(dslot, tr.index, tr.config, state=payload)
         if self.rank == src:
             eng.evict(sslot)
         self._free[src].append(sslot)
