@@ -251,3 +251,51 @@ def test_bench_runs_under_the_driver_launch_line_with_two_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["config"]["trials"] == 16 and rec["value"] > 0
     assert rec["scaling"] == "weak" and rec["higher_is_better"] is True
+
+
+_RCCL_SCRIPT = r"""
+import os, sys, json
+import torch
+sys.path.insert(0, os.getcwd())
+from mitune.parallel.comm import TorchDistComm
+comm = TorchDistComm(backend="nccl", rank=0, world_size=1)
+dev = comm.device
+out = {"backend": comm.backend, "device": str(dev)}
+table = torch.arange(18, dtype=torch.float64).reshape(3, 6) - 2          # CPU metric table, as the executor sends it
+g = comm.all_gather(table)
+out["gather_ok"] = bool(g.shape == (1, 3, 6) and g.device.type == "cpu" and torch.equal(g[0], table))
+el = torch.tensor([1.25], dtype=torch.float64, device=dev)
+comm.all_reduce(el, op="max")
+out["max"] = float(el.item())
+slab = torch.randn(1 << 20, device=dev)
+ref = slab.clone()
+out["bcast_ok"] = bool(torch.equal(comm.broadcast(slab, src=0), ref))
+out["obj"] = comm.broadcast_object({"epoch": 3}, src=0)
+grad = torch.ones(4096, device=dev, dtype=torch.bfloat16)
+w = comm.all_reduce(grad, op="avg", async_op=True)
+if w is not None:
+    w.wait()
+out["avg"] = float(grad.float().mean().item())
+comm.barrier()
+comm.close()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_rccl_backend_one_rank_collectives():
+    """Every collective the executors use, on the real RCCL backend (a one-rank group: the test box has one GPU)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    assert rec["backend"] == "nccl" and rec["device"] == "cuda:0"
+    assert rec["gather_ok"] and rec["bcast_ok"] and rec["max"] == 1.25 and rec["avg"] == 1.0 and rec["obj"] == {"epoch": 3}
