@@ -28,12 +28,45 @@ __device__ __forceinline__ void loss_and_grad(int type, float out, float y, floa
   }
 }
 
+
+// Eight consecutive activations of one row as the lane holds them: packed bf16 (one 16-byte load) or f32 (two).
+template <bool F32> struct HRow8;
+template <> struct HRow8<false> {
+  u32x4 v;
+  __device__ __forceinline__ void load(const void* H, size_t idx, bool ok) {
+    v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(H) + (ok ? idx : (size_t)0));
+    if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+  }
+  __device__ __forceinline__ float get(int e) const {
+    return (e & 1) ? bf16_bits_to_f32(v[e >> 1] >> 16) : bf16_bits_to_f32(v[e >> 1] & 0xFFFFu);
+  }
+  static __device__ __forceinline__ void store(void* D, size_t idx, const float (&o)[8]) {
+    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(D) + idx) =
+        u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+  }
+};
+template <> struct HRow8<true> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const void* H, size_t idx, bool ok) {
+    const float* p = reinterpret_cast<const float*>(H) + (ok ? idx : (size_t)0);
+    a = *reinterpret_cast<const f32x4*>(p);
+    b = *reinterpret_cast<const f32x4*>(p + 4);
+    if (!ok) { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
+  }
+  __device__ __forceinline__ float get(int e) const { return e < 4 ? a[e] : b[e - 4]; }
+  static __device__ __forceinline__ void store(void* D, size_t idx, const float (&o)[8]) {
+    float* p = reinterpret_cast<float*>(D) + idx;
+    *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
+  }
+};
+
 // Training: grid (row_chunks, active slots).  Workgroup (c, a) handles rows [c*HL_ROWS, (c+1)*HL_ROWS) of
 // slot ids[a] and writes one partial record {gw[0..W), gb, loss} to scratch; mt_head_reduce_kernel then adds
 // the records of a slot in chunk order (fixed order => bitwise reproducible, no float atomics).
 #define HL_RB 4          // rows a wave keeps in flight at once
 
-template <int NCHUNK>
+template <int NCHUNK, bool F32>
 __global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSlot* __restrict__ slots,
                                                                   const int32_t* __restrict__ ids, int step_imm,
                                                                   float* __restrict__ scratch, int max_chunks,
@@ -48,8 +81,8 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSl
   __shared__ float red[HL_WAVES][NCHUNK * 512];
   __shared__ float red_s[HL_WAVES][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint16_t* H = reinterpret_cast<const uint16_t*>(s.H);
-  uint16_t* dH = reinterpret_cast<uint16_t*>(s.dH);
+  const void* H = s.H;
+  void* dH = s.dH;
 
   float w[NCHUNK][8], gw[NCHUNK][8];
 #pragma unroll
@@ -67,16 +100,14 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSl
   // rows wave, wave+4, ... of the chunk; HL_RB of them are loaded before the first is reduced, so the
   // row loads overlap instead of forming a chain of dependent memory round trips
   for (int i0 = row_lo + wave; i0 < row_hi; i0 += HL_WAVES * HL_RB) {
-    u32x4 hv[HL_RB][NCHUNK];
+    HRow8<F32> hv[HL_RB][NCHUNK];
 #pragma unroll
     for (int r = 0; r < HL_RB; ++r) {
       const int i = i0 + r * HL_WAVES;
 #pragma unroll
       for (int c = 0; c < NCHUNK; ++c) {
         const int k0 = c * 512 + lane * 8;
-        const bool ok = (i < row_hi) && (k0 < s.W);
-        hv[r][c] = *reinterpret_cast<const u32x4*>(H + (ok ? ((size_t)i * s.ldh + k0) : (size_t)0));
-        if (!ok) hv[r][c] = u32x4{0u, 0u, 0u, 0u};
+        hv[r][c].load(H, (size_t)i * s.ldh + k0, (i < row_hi) && (k0 < s.W));
       }
     }
 #pragma unroll
@@ -87,10 +118,7 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSl
 #pragma unroll
       for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dot += bf16_bits_to_f32(hv[r][c][e] & 0xFFFFu) * w[c][2 * e];
-          dot += bf16_bits_to_f32(hv[r][c][e] >> 16) * w[c][2 * e + 1];
-        }
+        for (int e = 0; e < 8; ++e) dot += hv[r][c].get(e) * w[c][e];
       const float out = wave_sum(dot) + bias;
       float l, g;
       loss_and_grad(s.loss_type, out, s.y[i], l, g);
@@ -101,15 +129,14 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_loss_kernel(const MtHeadSl
       for (int c = 0; c < NCHUNK; ++c) {
         const int k0 = c * 512 + lane * 8;
         if (k0 < s.W) {
-          u32x4 o;
+          float o[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float h0 = bf16_bits_to_f32(hv[r][c][e] & 0xFFFFu), h1 = bf16_bits_to_f32(hv[r][c][e] >> 16);
-            gw[c][2 * e] += dout * h0;
-            gw[c][2 * e + 1] += dout * h1;
-            o[e] = pack_bf16x2(h0 > 0.f ? dout * w[c][2 * e] : 0.f, h1 > 0.f ? dout * w[c][2 * e + 1] : 0.f);
+          for (int e = 0; e < 8; ++e) {
+            const float h = hv[r][c].get(e);
+            gw[c][e] += dout * h;
+            o[e] = h > 0.f ? dout * w[c][e] : 0.f;
           }
-          *reinterpret_cast<u32x4*>(dH + (size_t)i * s.ldh + k0) = o;
+          HRow8<F32>::store(dH, (size_t)i * s.ldh + k0, o);
         }
       }
     }
@@ -142,7 +169,7 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_reduce_kernel(const MtHead
 // of its HL_EVAL_ROWS rows to scratch, mt_head_eval_reduce_kernel adds them (chunk order) into the f64 table.
 #define HL_EVAL_ROWS 256
 
-template <int NCHUNK>
+template <int NCHUNK, bool F32>
 __global__ __launch_bounds__(HL_THREADS) void mt_head_eval_kernel(const MtHeadSlot* __restrict__ slots,
                                                                   const int32_t* __restrict__ ids, int row0, int nrows,
                                                                   float* __restrict__ scratch, int max_chunks) {
@@ -158,7 +185,7 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_eval_kernel(const MtHeadSl
   const int row_hi = (row_lo + HL_EVAL_ROWS < s.B) ? row_lo + HL_EVAL_ROWS : s.B;
   __shared__ float red_s[HL_WAVES][3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint16_t* H = reinterpret_cast<const uint16_t*>(s.H);
+  const void* H = s.H;
   float w[NCHUNK][8];
 #pragma unroll
   for (int c = 0; c < NCHUNK; ++c)
@@ -174,13 +201,10 @@ __global__ __launch_bounds__(HL_THREADS) void mt_head_eval_kernel(const MtHeadSl
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
       const int k0 = c * 512 + lane * 8;
-      u32x4 hv = {0u, 0u, 0u, 0u};
-      if (k0 < s.W) hv = *reinterpret_cast<const u32x4*>(H + (size_t)i * s.ldh + k0);
+      HRow8<F32> hv;
+      hv.load(H, (size_t)i * s.ldh + k0, k0 < s.W);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        dot += bf16_bits_to_f32(hv[e] & 0xFFFFu) * w[c][2 * e];
-        dot += bf16_bits_to_f32(hv[e] >> 16) * w[c][2 * e + 1];
-      }
+      for (int e = 0; e < 8; ++e) dot += hv.get(e) * w[c][e];
     }
     const float out = wave_sum(dot) + bias;
     const float y = s.y[i];
@@ -223,20 +247,22 @@ extern "C" long mt_head_scratch_floats(int n_slots, int max_rows, int max_width)
 
 // ids: the n_active physical slot numbers to process; scratch: mt_head_scratch_floats(n_slots_total, ...) floats.
 // with_reduce = 0 leaves the partial records in scratch for a later launch to add (mt_gemm_bwd_head_launch).
-static int head_loss_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch, int max_width,
-                            int step, float* scratch, int with_reduce, hipStream_t stream) {
+// f32: the activation buffers H / dH hold f32 instead of bf16.
+template <bool F32>
+static int head_loss_launch_t(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch, int max_width,
+                              int step, float* scratch, int with_reduce, hipStream_t stream) {
   if (n_active <= 0) return 0;
   const int rec = ((max_width + 7) / 8) * 8 + 8;
   const int max_chunks = (max_batch + HL_ROWS - 1) / HL_ROWS;
   dim3 grid(max_chunks, n_active), block(HL_THREADS);
   if (max_width <= 512)
-    hipLaunchKernelGGL(mt_head_loss_kernel<1>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
+    hipLaunchKernelGGL((mt_head_loss_kernel<1, F32>), grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
                        mt_step_base_tls);
   else if (max_width <= 1024)
-    hipLaunchKernelGGL(mt_head_loss_kernel<2>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
+    hipLaunchKernelGGL((mt_head_loss_kernel<2, F32>), grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
                        mt_step_base_tls);
   else if (max_width <= 2048)
-    hipLaunchKernelGGL(mt_head_loss_kernel<4>, grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
+    hipLaunchKernelGGL((mt_head_loss_kernel<4, F32>), grid, block, 0, stream, slots, ids, step, scratch, max_chunks, rec,
                        mt_step_base_tls);
   else return -2;
   if (with_reduce)
@@ -247,28 +273,45 @@ static int head_loss_launch(const MtHeadSlot* slots, const int32_t* ids, int n_a
 
 extern "C" int mt_head_loss_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch,
                                    int max_width, int step, float* scratch, hipStream_t stream) {
-  return head_loss_launch(slots, ids, n_active, max_batch, max_width, step, scratch, 1, stream);
+  return head_loss_launch_t<false>(slots, ids, n_active, max_batch, max_width, step, scratch, 1, stream);
 }
 
 extern "C" int mt_head_loss_partials_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch,
                                             int max_width, int step, float* scratch, hipStream_t stream) {
-  return head_loss_launch(slots, ids, n_active, max_batch, max_width, step, scratch, 0, stream);
+  return head_loss_launch_t<false>(slots, ids, n_active, max_batch, max_width, step, scratch, 0, stream);
 }
 
-extern "C" int mt_head_eval_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_width,
-                                   int row0, int nrows, int max_rows, float* scratch, hipStream_t stream) {
+// f32 activations; with_reduce as above.
+extern "C" int mt_head_loss_f32_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch,
+                                       int max_width, int step, float* scratch, int with_reduce, hipStream_t stream) {
+  return head_loss_launch_t<true>(slots, ids, n_active, max_batch, max_width, step, scratch, with_reduce, stream);
+}
+
+template <bool F32>
+static int head_eval_launch_t(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_width, int row0,
+                              int nrows, int max_rows, float* scratch, hipStream_t stream) {
   if (n_active <= 0) return 0;
   const int rows = nrows > 0 ? nrows : max_rows;
   const int max_chunks = (max_rows + HL_EVAL_ROWS - 1) / HL_EVAL_ROWS;
   dim3 grid((rows + HL_EVAL_ROWS - 1) / HL_EVAL_ROWS, n_active), block(HL_THREADS);
   if (max_width <= 512)
-    hipLaunchKernelGGL(mt_head_eval_kernel<1>, grid, block, 0, stream, slots, ids, row0, nrows, scratch, max_chunks);
+    hipLaunchKernelGGL((mt_head_eval_kernel<1, F32>), grid, block, 0, stream, slots, ids, row0, nrows, scratch, max_chunks);
   else if (max_width <= 1024)
-    hipLaunchKernelGGL(mt_head_eval_kernel<2>, grid, block, 0, stream, slots, ids, row0, nrows, scratch, max_chunks);
+    hipLaunchKernelGGL((mt_head_eval_kernel<2, F32>), grid, block, 0, stream, slots, ids, row0, nrows, scratch, max_chunks);
   else if (max_width <= 2048)
-    hipLaunchKernelGGL(mt_head_eval_kernel<4>, grid, block, 0, stream, slots, ids, row0, nrows, scratch, max_chunks);
+    hipLaunchKernelGGL((mt_head_eval_kernel<4, F32>), grid, block, 0, stream, slots, ids, row0, nrows, scratch, max_chunks);
   else return -2;
   hipLaunchKernelGGL(mt_head_eval_reduce_kernel, dim3(n_active), dim3(64), 0, stream, slots, ids, nrows, scratch,
                      max_chunks);
   return (int)hipGetLastError();
+}
+
+extern "C" int mt_head_eval_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_width,
+                                   int row0, int nrows, int max_rows, float* scratch, hipStream_t stream) {
+  return head_eval_launch_t<false>(slots, ids, n_active, max_width, row0, nrows, max_rows, scratch, stream);
+}
+
+extern "C" int mt_head_eval_f32_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_width,
+                                       int row0, int nrows, int max_rows, float* scratch, hipStream_t stream) {
+  return head_eval_launch_t<true>(slots, ids, n_active, max_width, row0, nrows, max_rows, scratch, stream);
 }

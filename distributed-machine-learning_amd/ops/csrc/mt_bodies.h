@@ -15,12 +15,16 @@ struct MtHeadReduceArgs {      // by-value kernel argument of the launch that ca
 };
 
 // Mini-batch gather, workgroup (bx, by) of a grid (ceil(max_batch / rows_per_block), active slots), 256 threads.
+// F32 = false: rows are written as bf16, one 16-byte chunk (8 features) per thread; F32 = true: as f32, one 16-byte
+// chunk (4 features) per thread.  Fpad is a multiple of 8 either way.
+template <bool F32>
 __device__ __forceinline__ void mt_gather_body(const MtGatherSlot* __restrict__ slots, const int32_t* __restrict__ ids,
                                                const float* __restrict__ X, const float* __restrict__ Y, uint32_t n_rows,
                                                int F, int Fpad, int hb, int step, int bx, int by) {
   const MtGatherSlot s = slots[ids[by]];
   if (step >= s.active_steps) return;
-  const int cpr = Fpad >> 3;                 // 16-byte output chunks per row
+  constexpr int EPC = F32 ? 4 : 8;           // elements per 16-byte output chunk
+  const int cpr = Fpad / EPC;                // chunks per row
   const int rows_per_block = 256 / cpr;
   const int tid = threadIdx.x;
   const int r = tid / cpr, c = tid - r * cpr;
@@ -30,19 +34,24 @@ __device__ __forceinline__ void mt_gather_body(const MtGatherSlot* __restrict__ 
   const uint32_t pos = (uint32_t)step * (uint32_t)s.B + (uint32_t)i;
   const uint32_t src = mt_permute(pos, n_rows, s.key, hb);
   const float* xr = X + (size_t)src * F;
-  float v[8];
-  const int f0 = c * 8;
-  if ((F & 3) == 0 && f0 + 8 <= F) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(xr + f0);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(xr + f0 + 4);
-    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
-    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  float v[EPC];
+  const int f0 = c * EPC;
+  if ((F & 3) == 0 && f0 + EPC <= F) {
+#pragma unroll
+    for (int q = 0; q < EPC / 4; ++q) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + f0 + 4 * q);
+      v[4 * q] = a[0]; v[4 * q + 1] = a[1]; v[4 * q + 2] = a[2]; v[4 * q + 3] = a[3];
+    }
   } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (f0 + e < F) ? xr[f0 + e] : 0.f;
+    for (int e = 0; e < EPC; ++e) v[e] = (f0 + e < F) ? xr[f0 + e] : 0.f;
   }
-  u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-  *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(s.X0) + (size_t)i * Fpad + f0) = o;
+  if constexpr (F32) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(s.X0) + (size_t)i * Fpad + f0) = f32x4{v[0], v[1], v[2], v[3]};
+  } else {
+    u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(s.X0) + (size_t)i * Fpad + f0) = o;
+  }
   if (c == 0) s.y[i] = Y[src];
 }
 

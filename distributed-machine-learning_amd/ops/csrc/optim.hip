@@ -5,7 +5,8 @@
 // (x, s) handles elements [x*2048, x*2048 + 2048) of slot s with that slot's own optimiser family,
 // learning rate (including the warm-up / decay factor of its own step count), weight decay, betas and
 // clip scale, read from a small descriptor table -- so heterogeneous trials still cost one launch.
-// The same pass refreshes the bf16 shadow; a separate "cast" pass never exists.
+// The same pass refreshes the bf16 shadow; a separate "cast" pass never exists.  Pb = null (the exact-f32 engine, whose
+// GEMMs read the f32 master parameters directly) skips the shadow: 24 bytes per parameter instead of 30.
 //
 // Global-norm clipping: mt_sqnorm_kernel writes one partial sum of squares per (slot, block); each
 // optimiser block re-adds its slot's partials in index order (a fixed order, so bitwise reproducible)
@@ -157,12 +158,13 @@ __device__ __forceinline__ void optim_body(float* __restrict__ P, const float* _
     *reinterpret_cast<f32x4*>(M + off + 4) = f32x4{m[4], m[5], m[6], m[7]};
     *reinterpret_cast<f32x4*>(V + off) = f32x4{v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(V + off + 4) = f32x4{v[4], v[5], v[6], v[7]};
-    *reinterpret_cast<u32x4*>(Pb + off) = u32x4{pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]),
-                                                pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+    if (Pb != nullptr)
+      *reinterpret_cast<u32x4*>(Pb + off) = u32x4{pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]),
+                                                  pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
   } else {
     for (int e = 0; e < n; ++e) {
       P[off + e] = p[e]; M[off + e] = m[e]; V[off + e] = v[e];
-      Pb[off + e] = (uint16_t)f32_to_bf16_bits(p[e]);
+      if (Pb != nullptr) Pb[off + e] = (uint16_t)f32_to_bf16_bits(p[e]);
     }
   }
 }
@@ -191,6 +193,7 @@ struct MtGatherArgs {
   int32_t F, Fpad, hb, blocks;      // blocks: gather workgroups per slot (0 = no gather in this launch)
 };
 
+template <bool F32>      // F32: the rider gathers f32 rows (exact-f32 engine) instead of bf16 rows
 __global__ __launch_bounds__(OPT_THREADS) void mt_optim_gather_kernel(float* __restrict__ P, const float* __restrict__ G,
                                                                       float* __restrict__ M, float* __restrict__ V,
                                                                       uint16_t* __restrict__ Pb, size_t slot_stride,
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_optim_gather_kernel(float* __r
     optim_body<false>(P, G, M, V, Pb, slot_stride, hp, ids, partials, max_blocks, step, gsplits, gsplit_stride, blockIdx.x,
                       blockIdx.y);
   else
-    mt_gather_body(ga.slots, ids, ga.X, ga.Y, ga.n_rows, ga.F, ga.Fpad, ga.hb, step + 1, (int)blockIdx.x - nb_opt,
+    mt_gather_body<F32>(ga.slots, ids, ga.X, ga.Y, ga.n_rows, ga.F, ga.Fpad, ga.hb, step + 1, (int)blockIdx.x - nb_opt,
                    blockIdx.y);
 }
 
@@ -217,10 +220,12 @@ extern "C" int mt_optim_gather_launch(float* P, const float* G, float* M, float*
   if (gsplits < 1) return -6;
   if (n_active <= 0 || max_params <= 0) return 0;
   if (slot_stride % 8 != 0) return -2;
-  if (Fpad % 8 != 0 || Fpad / 8 > 256 || Fpad < F) return -2;
+  const bool f32 = (Pb == nullptr);       // no bf16 shadow: the pack trains in exact f32 and gathers f32 rows
+  const int cpr = f32 ? Fpad / 4 : Fpad / 8;
+  if (Fpad % 8 != 0 || cpr > 256 || Fpad < F) return -2;
   const int nb = (max_params + OPT_PER_BLOCK - 1) / OPT_PER_BLOCK;
   if (nb > max_blocks) return -4;
-  const int rows_per_block = 256 / (Fpad / 8);
+  const int rows_per_block = 256 / cpr;
   MtGatherArgs ga = {gslots, X, Y, n_rows, F, Fpad, hb, (max_batch + rows_per_block - 1) / rows_per_block};
   dim3 block(OPT_THREADS);
   if (use_clip) {
@@ -228,9 +233,14 @@ extern "C" int mt_optim_gather_launch(float* P, const float* G, float* M, float*
     hipLaunchKernelGGL(mt_sqnorm_kernel, dim3(nb, n_active), block, 0, stream, G, slot_stride, hp, ids, partials, max_blocks,
                        step, gsplits, gsplit_stride, mt_step_base_tls);
   }
-  hipLaunchKernelGGL(mt_optim_gather_kernel, dim3(nb + ga.blocks, n_active), block, 0, stream, P, G, M, V,
-                     reinterpret_cast<uint16_t*>(Pb), slot_stride, hp, ids, use_clip ? partials : nullptr, max_blocks, step,
-                     gsplits, gsplit_stride, mt_step_base_tls, nb, ga);
+  if (f32)
+    hipLaunchKernelGGL(mt_optim_gather_kernel<true>, dim3(nb + ga.blocks, n_active), block, 0, stream, P, G, M, V,
+                       (uint16_t*)nullptr, slot_stride, hp, ids, use_clip ? partials : nullptr, max_blocks, step, gsplits,
+                       gsplit_stride, mt_step_base_tls, nb, ga);
+  else
+    hipLaunchKernelGGL(mt_optim_gather_kernel<false>, dim3(nb + ga.blocks, n_active), block, 0, stream, P, G, M, V,
+                       reinterpret_cast<uint16_t*>(Pb), slot_stride, hp, ids, use_clip ? partials : nullptr, max_blocks,
+                       step, gsplits, gsplit_stride, mt_step_base_tls, nb, ga);
   return (int)hipGetLastError();
 }
 

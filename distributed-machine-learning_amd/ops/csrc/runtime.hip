@@ -32,6 +32,17 @@ int mt_gemm_bwd_head_launch(const MtGemmGroup* wgroups, const MtTile* wtiles, in
                             MtHeadReduceArgs hr, hipStream_t stream);
 int mt_head_loss_partials_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch, int max_width,
                                  int step, float* scratch, hipStream_t stream);
+int mt_gemm_f32_launch(int mode, const MtGemmGroup* groups, const MtTile* tiles, int ntiles, int step, int flags,
+                       int arow0, int i_override, int ksplits, size_t split_stride, int tile_edge, hipStream_t stream);
+int mt_gemm_f32_bwd_head_launch(const MtGemmGroup* wgroups, const MtTile* wtiles, int n_wtiles, const MtGemmGroup* dgroups,
+                                const MtTile* dtiles, int n_dtiles, int step, int ksplits, size_t split_stride,
+                                int tile_edge, MtHeadReduceArgs hr, hipStream_t stream);
+int mt_gather_f32_launch(const MtGatherSlot* slots, const int32_t* ids, int n_active, int max_batch, const float* X,
+                         const float* Y, uint32_t n_rows, int F, int Fpad, int hb, int step, hipStream_t stream);
+int mt_head_loss_f32_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_batch, int max_width,
+                            int step, float* scratch, int with_reduce, hipStream_t stream);
+int mt_head_eval_f32_launch(const MtHeadSlot* slots, const int32_t* ids, int n_active, int max_width, int row0, int nrows,
+                            int max_rows, float* scratch, hipStream_t stream);
 int mt_optim_gather_launch(float* P, const float* G, float* M, float* V, void* Pb, size_t slot_stride, const MtOptSlot* hp,
                            const int32_t* ids, int n_active, int max_params, float* partials, int max_blocks, int use_clip,
                            int step, int gsplits, size_t gsplit_stride, const MtGatherSlot* gslots, const float* X,
@@ -72,9 +83,10 @@ struct MtMlpPlan {
   int32_t ksplits;        // wgrad contraction splits; G holds that many slabs of gsplit_stride floats
   size_t gsplit_stride;
   int32_t ksplits0;       // contraction splits of layer 0's wgrad (its tile list is built with this count)
-  int32_t pad0;
-  int32_t fwd_big[MT_MAX_LAYERS];   // 1: this layer's forward tile list holds 256x256 tiles
-  int32_t bwd_big[MT_MAX_LAYERS];   // 1: this layer's wgrad and dgrad tile lists hold 256x256 tiles
+  int32_t f32;            // 1: exact-f32 pack (f32 activations, GEMMs read P, Pb is null); 0: bf16 MFMA with f32 masters
+  // tile edge of this layer's forward / backward tile lists: 0 = 128; 1 = 256 (bf16 packs only); 2 = 64 (f32 packs only)
+  int32_t fwd_big[MT_MAX_LAYERS];
+  int32_t bwd_big[MT_MAX_LAYERS];
 };
 
 thread_local const int* mt_step_base_tls = nullptr;
@@ -85,34 +97,57 @@ thread_local const int* mt_step_base_tls = nullptr;
     if (_e != 0) return _e;  \
   } while (0)
 
+static inline int f32_edge(int code) { return code == 2 ? 64 : 128; }
+
+static int plan_gather(const MtMlpPlan* p, int step, hipStream_t stream) {
+  return (p->f32 ? mt_gather_f32_launch : mt_gather_launch)(p->gather, p->active_ids, p->n_active, p->max_batch, p->X, p->Y,
+                                                            p->n_rows, p->F, p->Fpad, p->hb, step, stream);
+}
+
+static int plan_forward(const MtMlpPlan* p, int l, int step, int arow0, int rows, hipStream_t stream) {
+  if (p->f32)
+    return mt_gemm_f32_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], step, MT_GEMM_FLAG_RELU, arow0, rows,
+                              1, 0, f32_edge(p->fwd_big[l]), stream);
+  return mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], step, MT_GEMM_FLAG_RELU, arow0, rows, 1, 0,
+                        p->fwd_big[l] ? 256 : 0, stream);
+}
+
 static int mlp_enqueue_steps(const MtMlpPlan* p, int step0, int nsteps, hipStream_t stream, bool first_gather) {
   if (p->n_hidden < 1 || p->n_hidden > MT_MAX_LAYERS) return -10;
+  if (p->f32 && p->Pb != nullptr) return -16;
   const int L = p->n_hidden;
   // The mini-batch of a step is gathered by the optimiser launch of the step before it; whoever starts a run of
   // steps (first_gather) gathers the first one.  The head kernel leaves partial records that the last layer's backward
   // launch adds up (a 256-tile launch cannot carry them, so then the head reduces on its own).
-  const bool head_rides = !p->bwd_big[L - 1];
+  const bool head_rides = p->f32 || !p->bwd_big[L - 1];
   const MtHeadReduceArgs hr = {p->head, p->active_ids, p->head_scratch, p->n_active,
                                (p->max_batch + HL_ROWS - 1) / HL_ROWS, ((p->max_width + 7) / 8) * 8 + 8};
   const MtHeadReduceArgs no_hr = {nullptr, nullptr, nullptr, 0, 0, 0};
-  if (first_gather)
-    MT_TRY(mt_gather_launch(p->gather, p->active_ids, p->n_active, p->max_batch, p->X, p->Y, p->n_rows, p->F,
-                            p->Fpad, p->hb, step0, stream));
+  if (first_gather) MT_TRY(plan_gather(p, step0, stream));
   for (int step = step0; step < step0 + nsteps; ++step) {
-    for (int l = 0; l < L; ++l)
-      MT_TRY(mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], step, MT_GEMM_FLAG_RELU, 0, 0,
-                            1, 0, p->fwd_big[l] ? 256 : 0, stream));
-    if (head_rides)
+    for (int l = 0; l < L; ++l) MT_TRY(plan_forward(p, l, step, 0, 0, stream));
+    if (p->f32)
+      MT_TRY(mt_head_loss_f32_launch(p->head, p->active_ids, p->n_active, p->max_batch, p->max_width, step,
+                                     p->head_scratch, 0, stream));
+    else if (head_rides)
       MT_TRY(mt_head_loss_partials_launch(p->head, p->active_ids, p->n_active, p->max_batch, p->max_width, step,
                                           p->head_scratch, stream));
     else
       MT_TRY(mt_head_loss_launch(p->head, p->active_ids, p->n_active, p->max_batch, p->max_width, step,
                                  p->head_scratch, stream));
-    for (int l = L - 1; l >= 0; --l)     // layer 0 has no input gradient: its dgrad tile list is empty
-      MT_TRY(mt_gemm_bwd_head_launch(p->wgrad_groups[l], p->wgrad_tiles[l], p->wgrad_ntiles[l], p->dgrad_groups[l],
-                                     p->dgrad_tiles[l], l > 0 ? p->dgrad_ntiles[l] : 0, step,
-                                     l == 0 ? p->ksplits0 : p->ksplits, p->gsplit_stride, p->bwd_big[l] ? 256 : 0,
-                                     (l == L - 1 && head_rides) ? hr : no_hr, stream));
+    for (int l = L - 1; l >= 0; --l) {   // layer 0 has no input gradient: its dgrad tile list is empty
+      const int ks = l == 0 ? p->ksplits0 : p->ksplits;
+      const int nd = l > 0 ? p->dgrad_ntiles[l] : 0;
+      const MtHeadReduceArgs rider = (l == L - 1 && head_rides) ? hr : no_hr;
+      if (p->f32)
+        MT_TRY(mt_gemm_f32_bwd_head_launch(p->wgrad_groups[l], p->wgrad_tiles[l], p->wgrad_ntiles[l], p->dgrad_groups[l],
+                                           p->dgrad_tiles[l], nd, step, ks, p->gsplit_stride, f32_edge(p->bwd_big[l]),
+                                           rider, stream));
+      else
+        MT_TRY(mt_gemm_bwd_head_launch(p->wgrad_groups[l], p->wgrad_tiles[l], p->wgrad_ntiles[l], p->dgrad_groups[l],
+                                       p->dgrad_tiles[l], nd, step, ks, p->gsplit_stride, p->bwd_big[l] ? 256 : 0, rider,
+                                       stream));
+    }
     MT_TRY(mt_optim_gather_launch(p->P, p->G, p->M, p->V, p->Pb, p->slot_stride, p->opt, p->active_ids, p->n_active,
                                   p->max_params, p->partials, p->max_blocks, p->use_clip, step, p->ksplits,
                                   p->gsplit_stride, p->gather, p->X, p->Y, p->n_rows, p->F, p->Fpad, p->hb,
@@ -190,8 +225,7 @@ extern "C" void mt_mlp_graph_destroy(void* handle) {
 // Gather the mini-batch of step *counter (the first step of an epoch that is then driven by graph replays).
 extern "C" int mt_mlp_gather_at(const MtMlpPlan* p, int* counter, hipStream_t stream) {
   mt_step_base_tls = counter;
-  const int rc = mt_gather_launch(p->gather, p->active_ids, p->n_active, p->max_batch, p->X, p->Y, p->n_rows, p->F, p->Fpad,
-                                  p->hb, 0, stream);
+  const int rc = plan_gather(p, 0, stream);
   mt_step_base_tls = nullptr;
   return rc;
 }
@@ -207,7 +241,7 @@ extern "C" int mt_mlp_train_steps_at(const MtMlpPlan* p, int* counter, int nstep
   return (int)hipGetLastError();
 }
 
-// Validation sweep: the forward tables of an evaluation plan all read rows of ONE shared bf16 copy of
+// Validation sweep: the forward tables of an evaluation plan all read rows of ONE shared (bf16 or f32) copy of
 // the validation set (layer 0's A pointer), chunk by chunk; the head kernel adds each chunk's error
 // sums into the per-slot f64 metric table.
 extern "C" int mt_mlp_eval(const MtMlpPlan* p, int n_val_rows, int chunk_rows, hipStream_t stream) {
@@ -215,11 +249,9 @@ extern "C" int mt_mlp_eval(const MtMlpPlan* p, int n_val_rows, int chunk_rows, h
   const int L = p->n_hidden;
   for (int r0 = 0; r0 < n_val_rows; r0 += chunk_rows) {
     const int rows = (n_val_rows - r0) < chunk_rows ? (n_val_rows - r0) : chunk_rows;
-    for (int l = 0; l < L; ++l)
-      MT_TRY(mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], 0, MT_GEMM_FLAG_RELU,
-                            l == 0 ? r0 : 0, rows, 1, 0, p->fwd_big[l] ? 256 : 0, stream));
-    MT_TRY(mt_head_eval_launch(p->head, p->active_ids, p->n_active, p->max_width, r0, rows, chunk_rows,
-                               p->head_scratch, stream));
+    for (int l = 0; l < L; ++l) MT_TRY(plan_forward(p, l, 0, l == 0 ? r0 : 0, rows, stream));
+    MT_TRY((p->f32 ? mt_head_eval_f32_launch : mt_head_eval_launch)(p->head, p->active_ids, p->n_active, p->max_width, r0,
+                                                                    rows, chunk_rows, p->head_scratch, stream));
   }
   return 0;
 }

@@ -63,7 +63,7 @@ class MlpPlan(C.Structure):
                 ("head", c_void_p), ("P", c_void_p), ("G", c_void_p), ("M", c_void_p), ("V", c_void_p),
                 ("Pb", c_void_p), ("slot_stride", c_size_t), ("opt", c_void_p), ("partials", c_void_p),
                 ("active_ids", c_void_p), ("head_scratch", c_void_p), ("max_blocks", c_int32), ("ksplits", c_int32),
-                ("gsplit_stride", c_size_t), ("ksplits0", c_int32), ("pad0", c_int32),
+                ("gsplit_stride", c_size_t), ("ksplits0", c_int32), ("f32", c_int32),
                 ("fwd_big", c_int32 * MT_MAX_LAYERS), ("bwd_big", c_int32 * MT_MAX_LAYERS)]
 
 
@@ -149,6 +149,18 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_gemm_bwd_launch.restype = C.c_int
     lib.mt_gather_launch.argtypes = [c_void_p, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p, c_uint32, C.c_int,
                                      C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_gather_f32_launch.argtypes = lib.mt_gather_launch.argtypes
+    lib.mt_gemm_f32_launch.argtypes = [C.c_int, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       c_size_t, C.c_int, c_void_p]
+    lib.mt_gemm_f32_bwd_launch.argtypes = [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int,
+                                           c_size_t, C.c_int, c_void_p]
+    lib.mt_head_loss_f32_launch.argtypes = [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p, C.c_int,
+                                            c_void_p]
+    lib.mt_head_eval_f32_launch.argtypes = [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p,
+                                            c_void_p]
+    for fn in (lib.mt_gather_f32_launch, lib.mt_gemm_f32_launch, lib.mt_gemm_f32_bwd_launch, lib.mt_head_loss_f32_launch,
+               lib.mt_head_eval_f32_launch):
+        fn.restype = C.c_int
     lib.mt_head_loss_launch.argtypes = [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p, c_void_p]
     lib.mt_head_eval_launch.argtypes = [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p,
                                         c_void_p]

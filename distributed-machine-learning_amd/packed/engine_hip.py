@@ -45,6 +45,12 @@ BIG_TILE = 256         # tile edge of the throughput-form GEMM kernels
 BIG_MIN_TILES = int(os.environ.get("MITUNE_BIG_MIN_TILES", "0"))
 KSPLITS_SMALL = int(os.environ.get("MITUNE_KSPLITS_SMALL", str(MAX_KSPLITS)))     # wgrad splits of packs with <= 128 tiles
 GRAPH_STEPS = 25       # steps per captured hipGraph block (3125 = 125 blocks; shorter epochs run the rest directly)
+# Exact-f32 packs: launches with fewer 128-tiles than this use 64x64 tiles instead.  The f32 matrix instruction is 16x
+# slower than the bf16 one, so a 64-tile still hides its staging (16 B/clk/CU) and the finer tiles cut both the padding
+# of narrow layers and the tail of a launch that does not fill the chip.
+F32_SMALL_TILES = int(os.environ.get("MITUNE_F32_SMALL_TILES", "2048"))
+SMALL_TILE = 64
+DTYPES = ("bf16", "f32")
 
 
 def ceil8(x: int) -> int:
@@ -129,8 +135,16 @@ class HipPackEngine(PackEngine):
             raise ValueError("HipPackEngine trains the 'mlp' family")
         if not torch.cuda.is_available():
             raise RuntimeError("HipPackEngine needs a GPU")
+        if trainable.dtype not in DTYPES:
+            raise ValueError(f"PackedTrainable.dtype must be one of {DTYPES}, got {trainable.dtype!r}")
         self.lib = L.load()
         self.t = trainable
+        self.f32 = trainable.dtype == "f32"
+        # element type of activations, activation gradients and of the GEMMs' weight operand: bf16 (MFMA 16x16x32 bf16, f32
+        # accumulation, f32 master weights + a bf16 shadow) or f32 end to end (MFMA 16x16x4 f32: the arithmetic of an
+        # eager f32 training loop, no shadow)
+        self.act_dtype = torch.float32 if self.f32 else torch.bfloat16
+        self.eb = 4 if self.f32 else 2
         self.device = torch.device(device)
         self.seed = int(seed or 0)
         kw = trainable.model_kwargs
@@ -142,11 +156,11 @@ class HipPackEngine(PackEngine):
         self.F = trainable.in_features
         self.Fpad = ceil8(self.F)
         dev = self.device
-        # ---- datasets: f32 training table (gathered + converted per step), bf16 validation table
+        # ---- datasets: f32 training table (gathered + converted per step), validation table in the compute dtype
         self.Xtr = trainable.train[0].to(dev, torch.float32).contiguous()
         self.ytr = trainable.train[1].to(dev, torch.float32).contiguous()
-        xv = torch.zeros(trainable.val[0].shape[0], self.Fpad, device=dev, dtype=torch.bfloat16)
-        xv[:, :self.F] = trainable.val[0].to(dev, torch.bfloat16)
+        xv = torch.zeros(trainable.val[0].shape[0], self.Fpad, device=dev, dtype=self.act_dtype)
+        xv[:, :self.F] = trainable.val[0].to(dev, self.act_dtype)
         self.Xva, self.yva = xv, trainable.val[1].to(dev, torch.float32).contiguous()
         self.n_train, self.n_val = int(self.Xtr.shape[0]), int(self.Xva.shape[0])
         self.val_chunk = int(min(trainable.val_chunk, max(self.n_val, 1)))
@@ -166,12 +180,12 @@ class HipPackEngine(PackEngine):
         self.G = torch.zeros(MAX_KSPLITS * T * self.stride, device=dev, dtype=torch.float32)
         self.M = torch.zeros_like(self.P)
         self.V = torch.zeros_like(self.P)
-        self.Pb = torch.zeros(T * self.stride, device=dev, dtype=torch.bfloat16)
+        self.Pb = None if self.f32 else torch.zeros(T * self.stride, device=dev, dtype=torch.bfloat16)
         self.wp = wp
         self.act_stride = self.rows_max * wp
-        self.X0 = torch.zeros(T * self.rows_max * self.Fpad, device=dev, dtype=torch.bfloat16)
-        self.H = [torch.zeros(T * self.act_stride, device=dev, dtype=torch.bfloat16) for _ in range(self.max_layers)]
-        self.dZ = [torch.zeros(T * self.act_stride, device=dev, dtype=torch.bfloat16) for _ in range(self.max_layers)]
+        self.X0 = torch.zeros(T * self.rows_max * self.Fpad, device=dev, dtype=self.act_dtype)
+        self.H = [torch.zeros(T * self.act_stride, device=dev, dtype=self.act_dtype) for _ in range(self.max_layers)]
+        self.dZ = [torch.zeros(T * self.act_stride, device=dev, dtype=self.act_dtype) for _ in range(self.max_layers)]
         self.ybuf = torch.zeros(T * self.rows_max, device=dev, dtype=torch.float32)
         self.loss_acc = torch.zeros(T, device=dev, dtype=torch.float32)
         self.metrics = torch.zeros(T, 3, device=dev, dtype=torch.float64)
@@ -204,7 +218,11 @@ class HipPackEngine(PackEngine):
 
     def hbm_bytes(self) -> int:
         ts = [self.P, self.G, self.M, self.V, self.Pb, self.X0, self.ybuf, self.Xtr, self.Xva] + self.H + self.dZ
-        return int(sum(t.numel() * t.element_size() for t in ts))
+        return int(sum(t.numel() * t.element_size() for t in ts if t is not None))
+
+    def _refresh_shadow(self, slot: int) -> None:
+        if self.Pb is not None:
+            self._region(self.Pb, slot).copy_(self._region(self.P, slot).to(torch.bfloat16))
 
     def _region(self, slab: torch.Tensor, slot: int) -> torch.Tensor:
         return slab[slot * self.stride:(slot + 1) * self.stride]
@@ -265,7 +283,7 @@ class HipPackEngine(PackEngine):
             s.epoch, s.step = int(state.get("epoch", 0)), int(state.get("step", 0))
         else:
             self._write_params(slot, s.layout, init_mlp_state(spec, self.seed, trial_index), self.P)
-        self._region(self.Pb, slot).copy_(self._region(self.P, slot).to(torch.bfloat16))
+        self._refresh_shadow(slot)
         self.loss_acc[slot] = 0
         self.slots[slot] = s
         self._dirty = True
@@ -288,7 +306,8 @@ class HipPackEngine(PackEngine):
         if spec.hidden_sizes != a.spec.hidden_sizes:
             raise ValueError("an exploit cannot change the architecture")
         for slab in (self.P, self.M, self.V, self.Pb):
-            self._region(slab, dst).copy_(self._region(slab, src))      # device-to-device, stays in HBM
+            if slab is not None:
+                self._region(slab, dst).copy_(self._region(slab, src))      # device-to-device, stays in HBM
         b.spec, b.layout, b.config = spec, SlotLayout(spec, self.Fpad), dict(config)
         b.step = a.step
         self._dirty = True
@@ -330,7 +349,7 @@ class HipPackEngine(PackEngine):
         for sp in range(MAX_KSPLITS):
             off = (sp * self.capacity + slot) * self.stride
             self.G[off:off + self.stride].zero_()
-        self._region(self.Pb, slot).copy_(self._region(self.P, slot).to(torch.bfloat16))
+        self._refresh_shadow(slot)
         self.loss_acc[slot] = 0
         self.slots[slot] = s
         self._dirty = True
@@ -355,17 +374,18 @@ class HipPackEngine(PackEngine):
             self._tables[name] = t
         return t.data_ptr()
 
-    def _act_ptr(self, buf: torch.Tensor, slot: int, elem_bytes: int = 2) -> int:
-        return buf.data_ptr() + slot * self.act_stride * elem_bytes
+    def _act_ptr(self, buf: torch.Tensor, slot: int) -> int:
+        return buf.data_ptr() + slot * self.act_stride * self.eb
 
     def _choose_ksplits(self, ids: Optional[List[int]] = None) -> Tuple[int, int]:
         """(splits for layers >= 1, splits for layer 0) of the wgrad contraction: a launch with too few weight-gradient
         tiles to give every CU one splits the batch dimension instead."""
         per_layer: Dict[int, int] = {}
+        edge = SMALL_TILE if self.f32 else TILE      # exact-f32 packs small enough to think of splitting use 64-tiles
         for slot in (ids if ids is not None else sorted(self.slots)):
             lay = self.slots[slot].layout
             for l, h in enumerate(lay.hidden):
-                per_layer[l] = per_layer.get(l, 0) + ((h + TILE - 1) // TILE) * ((lay.in_dims[l] + TILE - 1) // TILE)
+                per_layer[l] = per_layer.get(l, 0) + ((h + edge - 1) // edge) * ((lay.in_dims[l] + edge - 1) // edge)
 
         def rule(tiles: int) -> int:
             # The GEMM alone gains from splitting up to about 128 tiles (512-wide layers: 4 splits 1.4x faster at 128
@@ -386,8 +406,10 @@ class HipPackEngine(PackEngine):
         self._ksplits, self._ksplits0 = ksplits, ksplits0
         T = self.capacity
         out: Dict[str, Any] = {"n_hidden": Lmax}
-        p_base, pb_base, g_base = self.P.data_ptr(), self.Pb.data_ptr(), self.G.data_ptr()
-        x0_stride = self.rows_max * self.Fpad * 2
+        p_base, g_base = self.P.data_ptr(), self.G.data_ptr()
+        # what the GEMMs read as the weight operand: the f32 masters themselves, or their bf16 shadow
+        w_base, wb = (p_base, 4) if self.f32 else (self.Pb.data_ptr(), 2)
+        x0_stride = self.rows_max * self.Fpad * self.eb
         for l in range(Lmax):
             fwd = np.zeros(T, dtype=L.GEMM_GROUP_DTYPE)
             dg = np.zeros(T, dtype=L.GEMM_GROUP_DTYPE)
@@ -405,14 +427,14 @@ class HipPackEngine(PackEngine):
                     a_in = self.Xva.data_ptr() if eval_mode else self.X0.data_ptr() + slot * x0_stride
                 else:
                     a_in = self._act_ptr(self.H[l - 1], slot)
-                fwd[slot] = (a_in, pb_base + (base + lay.w_off[l]) * 2, self._act_ptr(self.H[l], slot),
+                fwd[slot] = (a_in, w_base + (base + lay.w_off[l]) * wb, self._act_ptr(self.H[l], slot),
                              p_base + (base + lay.b_off[l]) * 4, 0,
                              bsz, h, k_real, k_ld, k_ld, o_ld, 0, steps)
                 fl.append((slot, bsz, h, (k_real + 63) // 64))
                 if eval_mode:
                     continue
                 if l > 0:
-                    dg[slot] = (self._act_ptr(self.dZ[l], slot), pb_base + (base + lay.w_off[l]) * 2,
+                    dg[slot] = (self._act_ptr(self.dZ[l], slot), w_base + (base + lay.w_off[l]) * wb,
                                 self._act_ptr(self.dZ[l - 1], slot), self._act_ptr(self.H[l - 1], slot), 0,
                                 bsz, k_real, h, o_ld, k_ld, k_ld, k_ld, steps)
                     dl.append((slot, bsz, k_real, (h + 63) // 64))
@@ -426,15 +448,22 @@ class HipPackEngine(PackEngine):
             def count(lst, edge):
                 return sum(a * b for _, a, b, _ in tiled(lst, edge))
 
-            # 256-tiles halve the bytes staged per flop; they pay once a launch still has enough of them to fill the chip
-            big_f = BIG_MIN_TILES > 0 and count(fl, BIG_TILE) >= BIG_MIN_TILES
-            big_b = (BIG_MIN_TILES > 0 and (not eval_mode) and ksplits0 == 1
-                     and count(dl, BIG_TILE) + count(wl, BIG_TILE) >= BIG_MIN_TILES)
-            out[f"big_fwd{l}"], out[f"big_bwd{l}"] = int(big_f), int(big_b)
-            ft = balanced_tiles(tiled(fl, BIG_TILE if big_f else TILE))
+            if self.f32:      # tile-edge codes of the plan: 0 = 128, 2 = 64
+                edge_f = SMALL_TILE if count(fl, TILE) < F32_SMALL_TILES else TILE
+                ks_l = ksplits0 if l == 0 else ksplits
+                edge_b = SMALL_TILE if count(dl, TILE) + count(wl, TILE) * ks_l < F32_SMALL_TILES else TILE
+                out[f"big_fwd{l}"], out[f"big_bwd{l}"] = (2 if edge_f == SMALL_TILE else 0), (2 if edge_b == SMALL_TILE else 0)
+            else:
+                # 256-tiles halve the bytes staged per flop; they pay once a launch still has enough of them to fill the chip
+                big_f = BIG_MIN_TILES > 0 and count(fl, BIG_TILE) >= BIG_MIN_TILES
+                big_b = (BIG_MIN_TILES > 0 and (not eval_mode) and ksplits0 == 1
+                         and count(dl, BIG_TILE) + count(wl, BIG_TILE) >= BIG_MIN_TILES)
+                out[f"big_fwd{l}"], out[f"big_bwd{l}"] = int(big_f), int(big_b)
+                edge_f, edge_b = (BIG_TILE if big_f else TILE), (BIG_TILE if big_b else TILE)
+            ft = balanced_tiles(tiled(fl, edge_f))
             out[f"fwd{l}"] = (self._upload(f"{tag}fwd_g{l}", fwd), self._upload(f"{tag}fwd_t{l}", ft), len(ft))
             if not eval_mode:
-                edge = BIG_TILE if big_b else TILE
+                edge = edge_b
                 dt, wt = balanced_tiles(tiled(dl, edge)), balanced_tiles(tiled(wl, edge), ksplits0 if l == 0 else ksplits)
                 out[f"dgrad{l}"] = (self._upload(f"{tag}dg_g{l}", dg), self._upload(f"{tag}dg_t{l}", dt), len(dt))
                 out[f"wgrad{l}"] = (self._upload(f"{tag}wg_g{l}", wg), self._upload(f"{tag}wg_t{l}", wt), len(wt))
@@ -481,7 +510,8 @@ class HipPackEngine(PackEngine):
                           LOSS_CODES[s.spec.loss_function], steps, 0)
         plan.head = self._upload(tag + "head", head)
         plan.P, plan.G, plan.M, plan.V, plan.Pb = (self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
-                                                   self.V.data_ptr(), self.Pb.data_ptr())
+                                                   self.V.data_ptr(), None if self.f32 else self.Pb.data_ptr())
+        plan.f32 = int(self.f32)
         plan.slot_stride = self.stride
         plan.partials = self.partials.data_ptr()
         return plan
@@ -492,7 +522,7 @@ class HipPackEngine(PackEngine):
         gat = np.zeros(T, dtype=L.GATHER_DTYPE)
         opt = np.zeros(T, dtype=L.OPT_DTYPE)
         max_steps = 0
-        x0_stride = self.rows_max * self.Fpad * 2
+        x0_stride = self.rows_max * self.Fpad * self.eb
         for slot in (sorted(self.slots) if slot_ids is None else slot_ids):
             s = self.slots[slot]
             sp = s.spec

@@ -36,11 +36,14 @@ def _run(engine_cls, trainable, configs, slots, epochs, **kw):
     return hist, states
 
 
-def test_hip_engine_tracks_torch_oracle():
+@pytest.mark.parametrize("dtype,rel,abs_frac", [("bf16", 0.08, 0.02), ("f32", 1e-3, 1e-5)])
+def test_hip_engine_tracks_torch_oracle(dtype, rel, abs_frac):
+    """Three epochs of four heterogeneous trials: bf16 MFMA stays within bf16 rounding of the f32 oracle; the exact-f32
+    engine (same arithmetic as the oracle, only the summation order differs) within 1e-3 relative."""
     from mitune.packed import PackedTrainable, TorchPackEngine
     from mitune.packed.engine_hip import HipPackEngine
     train, val = _data()
-    tr = PackedTrainable(train=train, val=val, max_epochs=3, val_chunk=512,
+    tr = PackedTrainable(train=train, val=val, max_epochs=3, val_chunk=512, dtype=dtype,
                          model_kwargs={"max_width": 256, "max_layers": 3, "max_batch": 512})
     cfgs = list(enumerate(CONFIGS))
     slots = [0, 1, 2, 3]
@@ -51,7 +54,7 @@ def test_hip_engine_tracks_torch_oracle():
         for slot in slots:
             a, b = h_hip[e][slot], h_ref[e][slot]
             for k in ("train_loss", "validation_loss", "validation_mse"):
-                assert a[k] == pytest.approx(b[k], rel=0.08, abs=0.02 * var_y), (e, slot, k, a, b)
+                assert a[k] == pytest.approx(b[k], rel=rel, abs=abs_frac * var_y), (e, slot, k, a, b)
     # the model actually learns (bf16 compute does not stall training)
     assert h_hip[-1][0]["validation_mse"] < 0.5 * var_y
     # exported checkpoint loads into the plain single-trial module
@@ -63,12 +66,22 @@ def test_hip_engine_tracks_torch_oracle():
     assert mse == pytest.approx(h_hip[-1][1]["validation_mse"], rel=0.05)
 
 
-def test_packing_invariance_is_bitwise():
+def test_unknown_dtype_is_refused():
+    from mitune.packed import PackedTrainable
+    from mitune.packed.engine_hip import HipPackEngine
+    train, val = _data(n=500)
+    tr = PackedTrainable(train=train, val=val, dtype="fp8")
+    with pytest.raises(ValueError, match="dtype"):
+        HipPackEngine(tr, device="cuda", capacity=2)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_packing_invariance_is_bitwise(dtype):
     """A trial's weights do not depend on its slot or on which other trials share the pack."""
     from mitune.packed import PackedTrainable
     from mitune.packed.engine_hip import HipPackEngine
     train, val = _data(seed=1)
-    tr = PackedTrainable(train=train, val=val, max_epochs=2, val_chunk=512,
+    tr = PackedTrainable(train=train, val=val, max_epochs=2, val_chunk=512, dtype=dtype,
                          model_kwargs={"max_width": 256, "max_layers": 3, "max_batch": 512})
     _, alone = _run(HipPackEngine, tr, [(7, CONFIGS[1])], [0], 2, device="cuda", capacity=8, seed=5)
     _, packed = _run(HipPackEngine, tr, [(3, CONFIGS[0]), (7, CONFIGS[1]), (9, CONFIGS[3])], [5, 2, 6], 2,

@@ -280,3 +280,210 @@ def test_fused_optimizer_matches_torch(lib, name, code, clip, gsplits):
         torch.testing.assert_close(got, refs[s][0].detach(), rtol=2e-5, atol=2e-6)
         assert torch.equal(Pb[s * stride:s * stride + n], got.to(torch.bfloat16))
         assert torch.all(P[s * stride + n:(s + 1) * stride] == 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Exact-f32 grouped GEMM (v_mfma_f32_16x16x4_f32): same descriptors, f32 operands and outputs, 128- and 64-tiles.
+# Random f32 operands; the reference is a float64 product, so the tolerance only has to cover f32 accumulation.
+def _tiles_edge(L, dims, edge):
+    rows = [(-1, 0, 0)]
+    for g, i, j in dims:
+        for ti in range((i + edge - 1) // edge):
+            for tj in range((j + edge - 1) // edge):
+                rows.append((g, ti, tj))
+    return np.array(rows, dtype=L.TILE_DTYPE)
+
+
+F32_SHAPES = [(256, 128, 64), (512, 512, 512), (200, 72, 40), (128, 64, 8), (384, 256, 192), (130, 136, 520), (96, 42, 20)]
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+@pytest.mark.parametrize("edge", [128, 64])
+@pytest.mark.parametrize("relu", [False, True])
+def test_gemm_f32_forward_nt(lib, relu, edge):
+    if NSTAGE != 2:
+        pytest.skip("the f32 kernels have one pipeline form per tile edge")
+    L, so = lib
+    g = torch.Generator(device="cuda").manual_seed(11)
+    groups = np.zeros(len(F32_SHAPES) + 1, dtype=L.GEMM_GROUP_DTYPE)
+    keep, dims = [], []
+    for gi, (m, n, k) in enumerate(F32_SHAPES):
+        ldk, ldn = _pad8(k), _pad8(n)
+        x = torch.zeros(m, ldk, device="cuda"); x[:, :k] = torch.randn(m, k, device="cuda", generator=g)
+        w = torch.zeros(n, ldk, device="cuda"); w[:, :k] = torch.randn(n, k, device="cuda", generator=g) * 0.2
+        b = torch.randn(n, device="cuda", generator=g)
+        y = torch.full((m, ldn), 7.0, device="cuda")
+        groups[gi] = (x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, m, n, k, ldk, ldk, ldn, 0, 1)
+        keep.append((x, w, b, y)); dims.append((gi, m, n))
+    groups[len(F32_SHAPES)]["active_steps"] = 0
+    tiles = _tiles_edge(L, dims, edge)
+    gt, tt = _up(groups), _up(tiles)
+    L.check(so.mt_gemm_f32_launch(0, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, int(relu), 0, 0, 1, 0, edge, _stream()),
+            "gemm_f32")
+    torch.cuda.synchronize()
+    for (m, n, k), (x, w, b, y) in zip(F32_SHAPES, keep):
+        ref = (x[:, :k].double() @ w[:, :k].double().t() + b.double())
+        if relu:
+            ref = ref.relu()
+        torch.testing.assert_close(y[:, :n].double(), ref, rtol=2e-6, atol=2e-5)
+        rounded = (n + 3) // 4 * 4          # pad columns inside the last 4-chunk are written as zeros
+        assert torch.all(y[:, n:rounded] == 0)
+        assert torch.all(y[:, rounded:] == 7.0)
+
+
+@pytest.mark.parametrize("edge", [128, 64])
+def test_gemm_f32_forward_identity_asymmetric(lib, edge):
+    if NSTAGE != 2:
+        pytest.skip("the f32 kernels have one pipeline form per tile edge")
+    L, so = lib
+    n = 128
+    x = torch.eye(n, device="cuda")
+    w = (torch.arange(n * n, device="cuda").reshape(n, n) % 251).float() + 0.125      # W[j][k]
+    b = torch.zeros(n, device="cuda")
+    y = torch.zeros(n, n, device="cuda")
+    groups = np.zeros(1, dtype=L.GEMM_GROUP_DTYPE)
+    groups[0] = (x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, n, n, n, n, n, n, 0, 1)
+    tiles = _tiles_edge(L, [(0, n, n)], edge)
+    gt, tt = _up(groups), _up(tiles)
+    L.check(so.mt_gemm_f32_launch(0, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, 0, 0, 0, 1, 0, edge, _stream()), "gemm_f32")
+    torch.cuda.synchronize()
+    assert torch.equal(y, w.t())          # exact: every product is x * 1 or x * 0
+
+
+@pytest.mark.parametrize("edge", [128, 64])
+@pytest.mark.parametrize("mask", [False, True])
+def test_gemm_f32_dgrad_nn(lib, mask, edge):
+    if NSTAGE != 2:
+        pytest.skip("the f32 kernels have one pipeline form per tile edge")
+    L, so = lib
+    g = torch.Generator(device="cuda").manual_seed(12)
+    groups = np.zeros(len(F32_SHAPES), dtype=L.GEMM_GROUP_DTYPE)
+    keep, dims = [], []
+    for gi, (m, n, k) in enumerate(F32_SHAPES):      # dX[m,k] = dY[m,n] @ W[n,k]
+        ldk, ldn = _pad8(k), _pad8(n)
+        dy = torch.zeros(m, ldn, device="cuda"); dy[:, :n] = torch.randn(m, n, device="cuda", generator=g)
+        w = torch.zeros(n, ldk, device="cuda"); w[:, :k] = torch.randn(n, k, device="cuda", generator=g) * 0.2
+        h = torch.zeros(m, ldk, device="cuda"); h[:, :k] = torch.randn(m, k, device="cuda", generator=g).relu()
+        dx = torch.full((m, ldk), 7.0, device="cuda")
+        groups[gi] = (dy.data_ptr(), w.data_ptr(), dx.data_ptr(), h.data_ptr(), 0, m, k, n, ldn, ldk, ldk, ldk, 1)
+        keep.append((dy, w, h, dx)); dims.append((gi, m, k))
+    tiles = _tiles_edge(L, dims, edge)
+    gt, tt = _up(groups), _up(tiles)
+    L.check(so.mt_gemm_f32_launch(1, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, int(mask), 0, 0, 1, 0, edge, _stream()),
+            "gemm_f32")
+    torch.cuda.synchronize()
+    for (m, n, k), (dy, w, h, dx) in zip(F32_SHAPES, keep):
+        ref = dy[:, :n].double() @ w[:, :k].double()
+        if mask:
+            ref = ref * (h[:, :k] > 0)
+        torch.testing.assert_close(dx[:, :k].double(), ref, rtol=2e-6, atol=2e-5)
+
+
+@pytest.mark.parametrize("edge", [128, 64])
+@pytest.mark.parametrize("ksplits", [1, 3])
+def test_gemm_f32_wgrad_tn(lib, ksplits, edge):
+    if NSTAGE != 2:
+        pytest.skip("the f32 kernels have one pipeline form per tile edge")
+    L, so = lib
+    g = torch.Generator(device="cuda").manual_seed(13)
+    groups = np.zeros(len(F32_SHAPES), dtype=L.GEMM_GROUP_DTYPE)
+    keep, dims = [], []
+    for gi, (m, n, k) in enumerate(F32_SHAPES):      # dW[n,k] = dY[m,n]^T @ X[m,k];  db[n] = sum_m dY[m,n]
+        ldk, ldn = _pad8(k), _pad8(n)
+        dy = torch.zeros(m, ldn, device="cuda"); dy[:, :n] = torch.randn(m, n, device="cuda", generator=g) * 0.1
+        x = torch.zeros(m, ldk, device="cuda"); x[:, :k] = torch.randn(m, k, device="cuda", generator=g)
+        arena = torch.full((ksplits, 600 * 600), 5.0, device="cuda")
+        dw_all = arena[:, :n * ldk].view(ksplits, n, ldk)
+        dw_all.zero_()
+        db_all = arena[:, 590 * 600:590 * 600 + n]
+        groups[gi] = (dy.data_ptr(), x.data_ptr(), arena.data_ptr(), 0, db_all.data_ptr(), n, k, m, ldn, ldk, ldk, 0, 1)
+        keep.append((dy, x, dw_all, db_all)); dims.append((gi, n, k))
+    tiles = _tiles_edge(L, dims, edge)
+    if ksplits > 1:
+        base = tiles[1:]
+        reps = []
+        for sp in range(ksplits):
+            t = base.copy(); t["ti"] = t["ti"] | (sp << 8); reps.append(t)
+        tiles = np.concatenate([tiles[:1]] + reps)
+    gt, tt = _up(groups), _up(tiles)
+    L.check(so.mt_gemm_f32_launch(2, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, 1, 0, 0, ksplits, 600 * 600, edge, _stream()),
+            "gemm_f32")
+    torch.cuda.synchronize()
+    for (m, n, k), (dy, x, dw_all, db_all) in zip(F32_SHAPES, keep):
+        dw, db = dw_all.double().sum(0), db_all.double().sum(0)
+        ref = dy[:, :n].double().t() @ x[:, :k].double()
+        torch.testing.assert_close(dw[:, :k], ref, rtol=2e-6, atol=2e-5)
+        torch.testing.assert_close(db, dy[:, :n].double().sum(0), rtol=2e-6, atol=2e-5)
+        if dw.shape[1] > k:
+            assert torch.all(dw[:, k:] == 0)
+
+
+def test_gather_f32_rows(lib):
+    if NSTAGE != 2:
+        pytest.skip("not a GEMM test")
+    L, so = lib
+    from mitune.packed.permutation import half_bits, permute, round_keys
+    n, F, Fpad, B = 5000, 10, 16, 96
+    X = torch.randn(n, F, device="cuda"); Y = torch.randn(n, device="cuda")
+    slots = np.zeros(2, dtype=L.GATHER_DTYPE)
+    outs = []
+    for s in range(2):
+        x0 = torch.full((B, Fpad), 9.0, device="cuda"); y = torch.zeros(B, device="cuda")
+        keys = round_keys(11, 100 + s, 2)
+        slots[s] = (x0.data_ptr(), y.data_ptr(), keys, B - 8 * s, 50)
+        outs.append((x0, y, keys))
+    st = _up(slots)
+    ids = torch.arange(2, dtype=torch.int32, device="cuda")
+    L.check(so.mt_gather_f32_launch(st.data_ptr(), ids.data_ptr(), 2, B, X.data_ptr(), Y.data_ptr(), n, F, Fpad,
+                                    half_bits(n), 7, _stream()), "gather_f32")
+    torch.cuda.synchronize()
+    for s, (x0, y, keys) in enumerate(outs):
+        b = B - 8 * s
+        idx = torch.from_numpy(permute(np.arange(7 * b, 7 * b + b, dtype=np.uint32), n, keys)).cuda()
+        assert torch.equal(x0[:b, :F], X[idx])
+        assert torch.all(x0[:b, F:] == 0)
+        assert torch.equal(y[:b], Y[idx])
+
+
+def test_head_loss_f32_activations(lib):
+    if NSTAGE != 2:
+        pytest.skip("not a GEMM test")
+    L, so = lib
+    g = torch.Generator(device="cuda").manual_seed(14)
+    cfgs = [(256, 512), (100, 64), (96, 200)]
+    slots = np.zeros(len(cfgs), dtype=L.HEAD_DTYPE)
+    keep = []
+    for s, (B, W) in enumerate(cfgs):
+        ld = _pad8(W)
+        H = torch.zeros(B, ld, device="cuda"); H[:, :W] = torch.randn(B, W, device="cuda", generator=g).relu()
+        dH = torch.zeros(B, ld, device="cuda")
+        w = torch.randn(W, device="cuda", generator=g) * 0.1; b = torch.randn(1, device="cuda", generator=g)
+        gw = torch.zeros(W, device="cuda"); gb = torch.zeros(1, device="cuda")
+        y = torch.randn(B, device="cuda", generator=g) + 2.0
+        acc = torch.full((1,), 1.0, device="cuda"); met = torch.zeros(3, device="cuda", dtype=torch.float64)
+        slots[s] = (H.data_ptr(), dH.data_ptr(), w.data_ptr(), b.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                    y.data_ptr(), acc.data_ptr(), met.data_ptr(), B, W, ld, 0, 1, 0)
+        keep.append((H, dH, w, b, gw, gb, y, acc, met))
+    st = _up(slots)
+    ids = torch.arange(len(cfgs), dtype=torch.int32, device="cuda")
+    scratch = torch.zeros(int(so.mt_head_scratch_floats(len(cfgs), 256, 512)), device="cuda")
+    L.check(so.mt_head_loss_f32_launch(st.data_ptr(), ids.data_ptr(), len(cfgs), 256, 512, 0, scratch.data_ptr(), 1,
+                                       _stream()), "head_loss_f32")
+    L.check(so.mt_head_eval_f32_launch(st.data_ptr(), ids.data_ptr(), len(cfgs), 512, 0, 0, 256, scratch.data_ptr(),
+                                       _stream()), "head_eval_f32")
+    torch.cuda.synchronize()
+    for (B, W), (H, dH, w, b, gw, gb, y, acc, met) in zip(cfgs, keep):
+        h = H[:, :W].clone().requires_grad_(True)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        out = h @ wr + br
+        l = ((out - y) ** 2).mean()
+        l.backward()
+        torch.testing.assert_close(acc, torch.tensor([1.0 + l.item()], device="cuda"), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(gw, wr.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(gb, br.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(dH[:, :W], (h.grad * (h > 0)).detach(), rtol=1e-5, atol=1e-7)
+        d = (out - y).detach()
+        torch.testing.assert_close(met[1].float(), (d * d).sum(), rtol=1e-4, atol=1e-3)
