@@ -157,6 +157,15 @@ def main():
         sec_per_trial_epoch = 3600.0 / baseline * 256.0 / 640.0 * (args.rows / 1.0e6)
         baseline = 3600.0 * n_trials / (trial_epochs * sec_per_trial_epoch)
     best = analysis.best_result or {}
+    # useful arithmetic of the search: 6 flop per weight per training row (forward, input gradient, weight gradient) and 2
+    # per validation row, for the epochs every trial actually ran
+    n_tr, n_va = int(train[0].shape[0]), int(val[0].shape[0])
+    flop = 0.0
+    for t in analysis.trials:
+        w = [args.features] + [int(t.config[f"width_{i}"]) for i in range(3)] + [1]
+        macs = sum(a * b for a, b in zip(w[:-1], w[1:]))
+        bs = int(t.config["batch_size"])
+        flop += t.training_iteration * macs * (6.0 * (n_tr // bs) * bs + 2.0 * n_va)
 
     second = {}
     if args.dtype == "f32" and not args.no_bf16:      # same search, bf16 MFMA: a labelled second figure, outside the timed region
@@ -188,6 +197,7 @@ def main():
             "elapsed_s": elapsed, "train_s": analysis.stats.get("train_s"), "eval_s": analysis.stats.get("eval_s"),
             "comm_s": analysis.stats.get("comm_s"), "slot_epochs": analysis.stats.get("slot_epochs"),
             "early_stopped": analysis.stats.get("num_stopped_early"),
+            "useful_tflop": flop / 1e12, "useful_tflops_per_s": flop / 1e12 / elapsed,
             "migrations": analysis.stats.get("migrations"), "migrate_s": analysis.stats.get("migrate_s"),
             **second,
         }))

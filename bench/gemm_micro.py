@@ -29,13 +29,13 @@ def up(arr):
 
 
 class Problem:
-    def __init__(self, mode, T, B, W, ksplits=1, edge=128):
+    def __init__(self, mode, T, B, W, ksplits=1, edge=128, dtype=torch.bfloat16):
         g = torch.Generator(device="cuda").manual_seed(0)
         self.mode, self.T, self.B, self.W, self.ksplits = mode, T, B, W, ksplits
-        x = (torch.randn(T, B, W, device="cuda", generator=g)).to(torch.bfloat16)
-        w = (torch.randn(T, W, W, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
-        dy = (torch.randn(T, B, W, device="cuda", generator=g)).to(torch.bfloat16)
-        y = torch.empty(T, B, W, device="cuda", dtype=torch.bfloat16)
+        x = (torch.randn(T, B, W, device="cuda", generator=g)).to(dtype)
+        w = (torch.randn(T, W, W, device="cuda", generator=g) * 0.05).to(dtype)
+        dy = (torch.randn(T, B, W, device="cuda", generator=g)).to(dtype)
+        y = torch.empty(T, B, W, device="cuda", dtype=dtype)
         bias = torch.zeros(T, W, device="cuda")
         # weight and bias gradients share one arena per split, like the engine's gradient slabs do
         self.slab = T * W * W + T * W
@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--ablate", action="store_true", help="also time variants with MFMA / loads / epilogue removed")
     ap.add_argument("--variants", nargs="*", default=None, help="shared objects built from gemm.hip to A/B")
+    ap.add_argument("--f32", action="store_true", help="time the exact-f32 kernels (gemm_f32.hip) with 128- and 64-tiles")
     args = ap.parse_args()
     names = {0: "fwd  NT", 1: "dgrad NN", 2: "wgrad TN"}
     if args.variants:
@@ -113,6 +114,19 @@ def main():
                 print(f"slots {T:4d} {names[mode]} | {line}", flush=True)
         return
     so = L.load()
+    if args.f32:
+        fn = so.mt_gemm_f32_launch
+        for T in args.slots:
+            for mode in (0, 1, 2):
+                for ks in ((1, 4) if mode == 2 else (1,)):
+                    p128 = Problem(mode, T, args.batch, args.width, ks, edge=128, dtype=torch.float32)
+                    p64 = Problem(mode, T, args.batch, args.width, ks, edge=64, dtype=torch.float32)
+                    t128 = min(p128.time(fn, args.iters, 1, 128) for _ in range(3))
+                    t64 = min(p64.time(fn, args.iters, 1, 64) for _ in range(3))
+                    print(f"f32 slots {T:4d}  {names[mode]}  ksplits {ks}  batch {args.batch} width {args.width}  "
+                          f"128-tile {t128:8.2f} us ({p128.flop / t128 / 1e6:6.1f} TF/s, {p128.ntiles} tiles)  "
+                          f"64-tile {t64:8.2f} us ({p64.flop / t64 / 1e6:6.1f} TF/s, {p64.ntiles} tiles)", flush=True)
+        return
     fn = so.mt_gemm_launch
     for T in args.slots:
         for mode in (0, 1, 2):

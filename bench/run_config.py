@@ -10,7 +10,6 @@
 import argparse
 import json
 import os
-import subprocess
 import sys
 import time
 
@@ -51,9 +50,18 @@ def config1(args):
 
 
 def config23(args, trials_per_gpu):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--trials-per-gpu", str(trials_per_gpu),
-           "--steps", str(args.steps), "--warmup", "1"]
-    return json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1])
+    """Configurations 2 and 3 are bench.py itself (one GPU: 256 packed trials; a node: 128 per GPU = 1024 on eight).  It
+    runs in THIS process -- under torchrun every rank is already a member of the job, and a child process would try to
+    join the rendezvous a second time with its parent's rank -- and prints its own JSON line on rank 0."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mitune_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    sys.argv = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--trials-per-gpu", str(trials_per_gpu),
+                "--steps", str(args.steps), "--warmup", "1"] + (["--no-bf16"] if args.no_bf16 else [])
+    bench.main()
+    return None
 
 
 def config4(args):
@@ -153,6 +161,7 @@ def main():
     ap.add_argument("--engine5", default="auto", help="config 5 engine: auto (graph on a GPU) | graph | torch")
     ap.add_argument("--local-dir", default=None)
     ap.add_argument("--verbose", type=int, default=0)
+    ap.add_argument("--no-bf16", action="store_true", help="configs 2/3: skip bench.py's second (bf16) search")
     args = ap.parse_args()
     out = {1: config1, 2: lambda a: config23(a, 256), 3: lambda a: config23(a, 128), 4: config4, 5: config5}[args.config](args)
     if out is not None:

@@ -17,7 +17,6 @@ from typing import List
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmitune_hip.so")
-STAMP = os.path.join(HERE, ".libmitune_hip.stamp")
 ARCH = "gfx950"
 
 
@@ -41,11 +40,28 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+_MARK = b"mt-src-digest:"
+
+
+def library_digest(path: str = LIB) -> str:
+    """Digest of the sources a built library was compiled from, "" when the file is missing or predates the marker.
+    The build passes ``-DMT_SRC_DIGEST=...`` and runtime.hip keeps it as the string ``mt-src-digest:<hex>`` (also returned
+    by ``mt_source_digest()``); it is read here from the file's bytes, without loading the library, so a stale ``.so``
+    next to newer sources can neither pass for current nor stay mapped while it is rebuilt."""
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return ""
+    i = blob.find(_MARK)
+    if i < 0:
+        return ""
+    tail = blob[i + len(_MARK):i + len(_MARK) + 64]
+    return tail.decode("ascii", "replace") if len(tail) == 64 else ""
+
+
 def is_current() -> bool:
-    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
-        return False
-    with open(STAMP) as f:
-        return f.read().strip() == _digest()
+    return library_digest() == _digest()
 
 
 def build(force: bool = False, verbose: bool = True, extra_flags: List[str] | None = None) -> str:
@@ -53,7 +69,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags: List[str] | No
         return LIB
     tmp = f"{LIB}.tmp.{os.getpid()}"          # built aside and renamed: a concurrent reader never maps a half-written file
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-o", tmp] + (extra_flags or []) + sources()
+           "-Wno-unused-result", f'-DMT_SRC_DIGEST="{_digest()}"', "-o", tmp] + (extra_flags or []) + sources()
     if verbose:
         print("[mitune] " + " ".join(cmd).replace(tmp, LIB), flush=True)
     try:
@@ -62,9 +78,6 @@ def build(force: bool = False, verbose: bool = True, extra_flags: List[str] | No
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)
-    with open(STAMP + ".tmp", "w") as f:
-        f.write(_digest())
-    os.replace(STAMP + ".tmp", STAMP)
     return LIB
 
 
@@ -78,7 +91,7 @@ def build_sanitized(verbose: bool = True) -> str:
     out = os.path.join(HERE, "libmitune_hip_asan.so")
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
            "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined", "-Xarch_host",
-           "-fno-omit-frame-pointer", "-o", out] + sources()
+           "-fno-omit-frame-pointer", f'-DMT_SRC_DIGEST="{_digest()}"', "-o", out] + sources()
     if verbose:
         print("[mitune] " + " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

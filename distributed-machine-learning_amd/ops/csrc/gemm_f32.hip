@@ -111,10 +111,14 @@ __device__ __forceinline__ void f32_mma_stage(f32x4 (&acc)[T / 32][T / 32], cons
   }
 }
 
-// Column sums of the MN-major A image (bias gradient): thread -> column (tid % T), 256/T threads share a column.
+// Column sums of the MN-major A image (bias gradient): thread -> column (tid % T); TWO threads share a column (16 kk
+// rows each) for either tile edge, so the summation order -- and with it a trial's bias gradient, bit for bit -- does
+// not depend on which tile edge the size of its pack selected.  Threads >= 2T sit this out.
+#define F32_DB_PARTS 2
 template <int T>
 __device__ __forceinline__ float f32_colsum_stage(const uint8_t* ldsA, int tid) {
-  constexpr int PARTS = F32_THREADS / T, ROWS = F32_BK / PARTS;
+  constexpr int ROWS = F32_BK / F32_DB_PARTS;
+  if (tid >= F32_DB_PARTS * T) return 0.f;
   const int col = tid % T, part = tid / T;
   float s = 0.f;
 #pragma unroll
@@ -243,16 +247,11 @@ __device__ __forceinline__ void f32_gemm_tile(const MtGemmGroup* __restrict__ gr
       }
     }
     if (want_db) {
-      constexpr int PARTS = F32_THREADS / T;
       float* red = reinterpret_cast<float*>(lds);    // all waves are past the last K-step barrier
       red[tid] = db_acc;
       __syncthreads();
-      if (tid < T && i0 + tid < g.I) {
-        float s = red[tid];
-#pragma unroll
-        for (int p = 1; p < PARTS; ++p) s += red[tid + p * T];
-        (reinterpret_cast<float*>(g.aux_out) + (size_t)split * split_stride)[i0 + tid] = s;
-      }
+      if (tid < T && i0 + tid < g.I)
+        (reinterpret_cast<float*>(g.aux_out) + (size_t)split * split_stride)[i0 + tid] = red[tid] + red[tid + T];
     }
     return;
   }

@@ -256,6 +256,13 @@ extern "C" int mt_mlp_eval(const MtMlpPlan* p, int n_val_rows, int chunk_rows, h
   return 0;
 }
 
+// Digest of the source files this library was built from (ops/build.py passes it as -DMT_SRC_DIGEST).
+#ifndef MT_SRC_DIGEST
+#define MT_SRC_DIGEST ""
+#endif
+static const char mt_digest_string[] = "mt-src-digest:" MT_SRC_DIGEST;
+extern "C" const char* mt_source_digest() { return mt_digest_string + 14; }
+
 extern "C" int mt_abi_sizes(int* out) {
   out[0] = (int)sizeof(MtGemmGroup);
   out[1] = (int)sizeof(MtTile);

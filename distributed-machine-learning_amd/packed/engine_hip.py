@@ -167,10 +167,10 @@ class HipPackEngine(PackEngine):
         self.rows_max = max(self.max_batch, self.val_chunk)
         if capacity or trainable.capacity:
             self.capacity = int(capacity or trainable.capacity)
-        else:       # as many slots as the HBM budget allows (288 GB per MI355X), at most one full 256-trial pack
-            from ..utils.hbm import default_capacity
+        else:       # as many slots as the HBM budget allows (288 GB per MI355X): more resident trials amortise the small
+            from ..utils.hbm import default_capacity       # late rounds (1024 per GPU measured 1.6x the trials/hour of 256)
             self.capacity = default_capacity(self.F, self.max_width, self.max_layers, self.rows_max, self.n_train,
-                                             self.n_val, trainable.hbm_budget_gb, hard_cap=256)
+                                             self.n_val, trainable.hbm_budget_gb, dtype_bytes=self.eb)
         # ---- slabs
         wp = ceil8(self.max_width)
         worst = SlotLayout(MLPTrialSpec(self.F, [self.max_width] * self.max_layers), self.Fpad)

@@ -84,6 +84,11 @@ class PackedExecutor(Executor):
         self._queued: List[Event] = []
         self._awaiting: Dict[str, Optional[str]] = {}          # trial_id -> decision (None = not yet)
         self._epoch_time = 0.0
+        # Seconds of search as every rank counts them alike: the sum over rounds of the slowest rank's round time, taken
+        # from the gathered table.  Anything that decides something (time budgets, stop criteria on time fields,
+        # schedulers with a time attribute) reads this, never a rank's own clock: ranks that disagree on a decision
+        # issue different collectives and hang each other.
+        self.replicated_elapsed_s = 0.0
         self._slot_time: Optional[float] = None   # seconds per live trial of the costliest rank, last round (replicated)
         self._retired_last = 0             # slots freed by the previous round's decisions
         self._retired_now = 0
@@ -120,8 +125,20 @@ class PackedExecutor(Executor):
         self._live[trial.trial_id] = trial
         self._t_total.setdefault(trial.trial_id, float(trial.last_result.get("time_total_s", 0.0)))
         trial.placement = {"rank": owner, "slot": slot}
+        state = trial.restore_from
+        if getattr(trial, "restore_pending", False):
+            # A retried or resumed trial continues from its newest checkpoint, which only the rank that owned it then
+            # holds in memory.  Which rank that was is replicated knowledge (``checkpoint_rank``); if the trial now goes
+            # to another rank, the state travels in one broadcast that every rank takes part in.
+            trial.restore_pending = False
+            src = getattr(trial, "checkpoint_rank", None)
+            if self.world > 1 and src is not None and src != owner:
+                state = self.comm.broadcast_object(state if self.rank == src else None, src=src)
         if owner == self.rank:
-            self.engine.load(slot, trial.index, trial.config, state=trial.restore_from)
+            if state is None and trial.checkpoint_iter > 0 and trial.logdir:      # e.g. a rank that never held it
+                cp = ckpt.latest_checkpoint(trial.logdir)
+                state = ckpt.load_checkpoint(cp) if cp else None
+            self.engine.load(slot, trial.index, trial.config, state=state)
         trial.restore_from = None
 
     # ------------------------------------------------------------------ one scheduling round
@@ -162,7 +179,6 @@ class PackedExecutor(Executor):
             raise RankLostError(f"rank {self.rank} of {self.world}: metric exchange after epoch {self.stats['epochs'] + 1} "
                                 f"failed ({type(e).__name__}: {e})") from e
         t3 = time.time()
-        self._epoch_time = t3 - t0
         self.stats["epochs"] += 1
         self.stats["slot_epochs"] += len(local)
         self.stats["train_s"] += t1 - t0
@@ -177,6 +193,9 @@ class PackedExecutor(Executor):
         # the tensor library's intra-op thread pool and one millisecond here
         per_rank = gathered.reshape(self.world, self.capacity + 1, _REC)[:, -1, 1:3].tolist()
         self._slot_time = max((sec / n for sec, n in per_rank if n > 0), default=None)
+        # the round's length as reported to schedulers and stop criteria: the slowest rank's, identical on every rank
+        self._epoch_time = max(sec for sec, _ in per_rank)
+        self.replicated_elapsed_s += self._epoch_time
         rows = gathered.reshape(-1, _REC).numpy()
         rows = rows[rows[:, 0] >= 0]
         rows = rows[np.argsort(rows[:, 0], kind="stable")]
@@ -264,10 +283,13 @@ class PackedExecutor(Executor):
 
     def _checkpoint(self, tr: Trial) -> None:
         owner, slot = self._place[tr.trial_id]
+        tr.checkpoint_iter, tr.checkpoint_rank = tr.training_iteration, owner      # known on every rank
         if owner != self.rank:
+            tr.checkpoint = None          # an older state held here (the trial has moved since) is out of date now
             return
         state = self.engine.export(slot)
-        tr.checkpoint, tr.checkpoint_iter = state, tr.training_iteration
+        state.setdefault("training_iteration", tr.training_iteration)
+        tr.checkpoint = state
         if tr.logdir:
             keep = self.runner.keep_checkpoints_num if self.runner is not None else None
             ckpt.save_checkpoint(tr.logdir, tr.training_iteration, state, keep)

@@ -171,12 +171,18 @@ class BayesOptSearch(Searcher):
         if cfg is None or error or not result or self.metric not in result:
             return
         v = result[self.metric]
-        if v is None or (isinstance(v, float) and math.isnan(v)):
+        try:
+            v = float(v)
+        except (TypeError, ValueError):
             return
-        self.register(cfg, float(v))
+        if not math.isfinite(v):      # a diverged trial (nan, +-inf) would turn the GP's target scaling, and with it every
+            return                    # later acquisition value, into nan
+        self.register(cfg, v)
 
     def register(self, cfg: Dict, value: float) -> None:
-        """Add an observation (the searcher maximises internally; mode=min negates)."""
+        """Add an observation (the searcher maximises internally; mode=min negates).  Non-finite values are dropped."""
+        if not math.isfinite(value):
+            return
         self._x.append(self._encoder.encode(cfg))
         self._y.append(-value if self.mode == "min" else value)
 

@@ -159,18 +159,6 @@ def run(run_or_experiment: Any,
         max_trials = num_samples
     search_alg.set_search_properties(metric, mode, config)
 
-    # --- experiment directory ---------------------------------------------------------------
-    experiment_dir = None
-    if local_dir:
-        local_dir = os.path.expanduser(local_dir)
-        if resume and name is None:
-            cands = sorted(d for d in os.listdir(local_dir) if d.startswith(tname + "_")) if os.path.isdir(local_dir) else []
-            name = cands[-1] if cands else None
-        name = name or f"{tname}_{time.strftime('%Y-%m-%d_%H-%M-%S')}"
-        experiment_dir = os.path.join(local_dir, name)
-        os.makedirs(experiment_dir, exist_ok=True)
-    experiment_id = name or tname
-
     # --- executor ---------------------------------------------------------------------------
     from ..packed.trainable import PackedTrainable      # local import: packed pulls in torch
     if isinstance(executor, Executor):
@@ -180,25 +168,48 @@ def run(run_or_experiment: Any,
             raise ValueError("a PackedTrainable runs on the packed executor")
         from ..packed.executor import PackedExecutor
         ex = PackedExecutor(trainable, scheduler=scheduler, resources_per_trial=resources_per_trial,
-                            max_concurrent=max_concurrent_trials, experiment_id=experiment_id,
+                            max_concurrent=max_concurrent_trials, experiment_id=tname,
                             seed=seed, **executor_kwargs)
     elif executor in (None, "thread"):
-        ex = ThreadExecutor(trainable, resources_per_trial, max_concurrent_trials, experiment_id)
+        ex = ThreadExecutor(trainable, resources_per_trial, max_concurrent_trials, tname)
     elif executor == "process":
-        ex = ProcessExecutor(trainable, resources_per_trial, max_concurrent_trials, experiment_id)
+        ex = ProcessExecutor(trainable, resources_per_trial, max_concurrent_trials, tname)
     else:
         raise ValueError(f"unknown executor {executor!r}")
+    # One process per GPU runs this same function.  Rank 0 is the primary: it names the experiment, owns the loggers
+    # and experiment_state.json; every rank shares the directory (trial owners write their checkpoints into it).
+    rank, world = int(getattr(ex, "rank", 0)), int(getattr(ex, "world", 1))
+    comm = getattr(ex, "comm", None)
+
+    # --- experiment directory ---------------------------------------------------------------
+    experiment_dir = None
+    if local_dir and rank == 0:
+        local_dir = os.path.expanduser(local_dir)
+        if resume and name is None:
+            cands = sorted(d for d in os.listdir(local_dir) if d.startswith(tname + "_")) if os.path.isdir(local_dir) else []
+            name = cands[-1] if cands else None
+        name = name or f"{tname}_{time.strftime('%Y-%m-%d_%H-%M-%S')}"
+    if world > 1:
+        # rank 0's directory and name are THE directory and name: a time-stamped default differs between ranks started a
+        # second apart, and ranks with different trees would checkpoint and resume different searches
+        local_dir, name = comm.broadcast_object((local_dir, name) if rank == 0 else None, src=0)
+    if local_dir:
+        experiment_dir = os.path.join(local_dir, name)
+        os.makedirs(experiment_dir, exist_ok=True)
+    experiment_id = name or tname
+    ex.experiment_id = experiment_id
 
     logger_objs: List[Logger] = []
-    for lg in (loggers if loggers is not None else (DEFAULT_LOGGERS + (TBXLogger,) if experiment_dir else ())):
-        logger_objs.append(lg() if isinstance(lg, type) else lg)
+    if rank == 0:       # result.json / progress.csv / tfevents have one writer
+        for lg in (loggers if loggers is not None else (DEFAULT_LOGGERS + (TBXLogger,) if experiment_dir else ())):
+            logger_objs.append(lg() if isinstance(lg, type) else lg)
 
     runner = TrialRunner(
         ex, search_alg, scheduler, logger_objs, trainable_name=tname, experiment_dir=experiment_dir,
         metric=metric, mode=mode, stop=stop, max_failures=max_failures,
         keep_checkpoints_num=keep_checkpoints_num, checkpoint_at_end=checkpoint_at_end,
         max_trials=max_trials, progress=ProgressReporter(verbose, progress_period_s, metric, mode),
-        time_budget_s=time_budget_s, fail_fast=fail_fast)
+        time_budget_s=time_budget_s, fail_fast=fail_fast, is_primary=(rank == 0))
     if hasattr(ex, "bind_runner"):
         ex.bind_runner(runner)
 

@@ -85,6 +85,28 @@ def _resource_slots(resources_per_trial: Optional[Dict], max_concurrent: Optiona
     return slots, gpu_ids, gpus_per
 
 
+def physical_device_ids(logical: List[int], env: Optional[Dict[str, str]] = None) -> List[str]:
+    """Entries of the parent's own device mask for the logical device indices ``logical``.
+
+    A process started under ``HIP_VISIBLE_DEVICES=4,5`` sees its devices as 0 and 1; a child that should get "device 1"
+    must be started with ``HIP_VISIBLE_DEVICES=5``, not ``1`` -- index 1 of the whole machine belongs to somebody
+    else.  With no mask in force the mapping is the identity.  Entries may be indices or device UUIDs.
+    """
+    env = os.environ if env is None else env
+    mask = env.get("HIP_VISIBLE_DEVICES")
+    if mask is None or mask.strip() == "":
+        mask = env.get("CUDA_VISIBLE_DEVICES")
+    if mask is None or mask.strip() == "":
+        return [str(i) for i in logical]
+    entries = [e.strip() for e in mask.split(",") if e.strip() != ""]
+    out = []
+    for i in logical:
+        if not 0 <= i < len(entries):
+            raise ValueError(f"logical device {i} is outside this process's device mask {mask!r}")
+        out.append(entries[i])
+    return out
+
+
 class ThreadExecutor(Executor):
     def __init__(self, trainable: Callable, resources_per_trial: Optional[Dict] = None,
                  max_concurrent: Optional[int] = None, experiment_id: str = ""):
@@ -95,6 +117,7 @@ class ThreadExecutor(Executor):
         self._replies: Dict[str, "queue.Queue[str]"] = {}
         self._threads: Dict[str, threading.Thread] = {}
         self._lock = threading.Lock()
+        self._shared_flag_before: Optional[bool] = None     # train.graphed.SHARED_GPU_THREADS as found, once changed
 
     def has_capacity(self) -> bool:
         return len(self._threads) < self.slots
@@ -108,8 +131,11 @@ class ThreadExecutor(Executor):
         if 0 < self.gpus_per < 1 and self.gpu_ids:
             import torch
             from ..train import graphed
-            graphed.SHARED_GPU_THREADS = True      # graph capture is not safe while sibling threads use the device
-            return torch.cuda.stream(torch.cuda.Stream())
+            with self._lock:
+                if self._shared_flag_before is None:
+                    self._shared_flag_before = bool(graphed.SHARED_GPU_THREADS)
+                graphed.SHARED_GPU_THREADS = True      # graph capture is not safe while sibling threads use the device;
+            return torch.cuda.stream(torch.cuda.Stream())      # shutdown() puts the flag back
         return contextlib.nullcontext()
 
     def start_trial(self, trial: Trial) -> None:
@@ -167,6 +193,10 @@ class ThreadExecutor(Executor):
         for th in list(self._threads.values()):
             th.join(timeout=5)
         self._threads.clear()
+        if self._shared_flag_before is not None:       # later runs in this process capture graphs again
+            from ..train import graphed
+            graphed.SHARED_GPU_THREADS = self._shared_flag_before
+            self._shared_flag_before = None
 
 
 # --------------------------------------------------------------------------- process executor
@@ -234,7 +264,7 @@ class ProcessExecutor(Executor):
         with ProcessExecutor._env_lock:
             saved = {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
             if mine:
-                ids = ",".join(map(str, mine))
+                ids = ",".join(physical_device_ids(mine))      # through the mask this process itself runs under
                 os.environ["HIP_VISIBLE_DEVICES"] = ids
                 os.environ["CUDA_VISIBLE_DEVICES"] = ids
             try:

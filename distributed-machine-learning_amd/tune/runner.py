@@ -36,7 +36,7 @@ class TrialRunner:
                  stop: StopCriterion = None, max_failures: int = 0, keep_checkpoints_num: Optional[int] = None,
                  checkpoint_at_end: bool = False, max_trials: Optional[int] = None,
                  progress: Optional[Any] = None, state_save_period_s: float = 10.0,
-                 time_budget_s: Optional[float] = None, fail_fast: bool = False):
+                 time_budget_s: Optional[float] = None, fail_fast: bool = False, is_primary: bool = True):
         self.executor, self.searcher = executor, searcher
         self.scheduler = scheduler or FIFOScheduler()
         self.loggers = list(loggers)
@@ -48,6 +48,8 @@ class TrialRunner:
         self.progress = progress
         self.state_save_period_s = state_save_period_s
         self.time_budget_s, self.fail_fast = time_budget_s, fail_fast
+        # one process per GPU runs an identical runner; only the primary (rank 0) writes experiment_state.json
+        self.is_primary = bool(is_primary)
         self.trials: List[Trial] = []
         self._by_id: Dict[str, Trial] = {}
         self._pending_q: "collections.deque[Trial]" = collections.deque()    # PENDING trials in arrival order
@@ -179,7 +181,12 @@ class TrialRunner:
             self.save_state()
         if self.progress is not None:
             self.progress.maybe_report(self)
-        if self.time_budget_s is not None and now - self._t0 > self.time_budget_s:
+        # A multi-rank executor supplies a clock all ranks agree on (sum of gathered round times); a rank's own clock
+        # would end the search on one rank a round earlier than on another.
+        elapsed = getattr(self.executor, "replicated_elapsed_s", None)
+        if elapsed is None:
+            elapsed = now - self._t0
+        if self.time_budget_s is not None and elapsed > self.time_budget_s:
             self._searcher_done = True
             for t in self.trials:
                 if t.status in (PENDING, PAUSED):
@@ -275,6 +282,7 @@ class TrialRunner:
             return
         if decision == PAUSE:
             trial.restore_from = trial.checkpoint
+            trial.restore_pending = True
             self._set_status(trial, PAUSED)
             return
         self._finish(trial, TERMINATED)
@@ -290,13 +298,14 @@ class TrialRunner:
             raise TuneError(f"trial {trial.trial_id} failed (fail_fast):\n{ev.error}")
         if self.max_failures < 0 or trial.num_failures <= self.max_failures:
             trial.restore_from = trial.checkpoint
+            trial.restore_pending = True          # (a multi-rank executor fetches the state from the rank that holds it)
             self._set_status(trial, PENDING)      # retried from its newest checkpoint
             return
         self._finish(trial, ERROR)
 
     # ------------------------------------------------------------------ persistence
     def save_state(self) -> None:
-        if not self.experiment_dir:
+        if not self.experiment_dir or not self.is_primary:
             return
         os.makedirs(self.experiment_dir, exist_ok=True)
         state = {

@@ -26,19 +26,24 @@ class PackFootprint:
 
 
 def mlp_pack_footprint(in_features: int, max_width: int, max_layers: int, max_rows: int, n_train: int, n_val: int,
-                       gradient_slabs: int = 4) -> PackFootprint:
+                       gradient_slabs: int = 4, dtype_bytes: int = 2) -> PackFootprint:
+    """``dtype_bytes``: 2 for bf16 packs (activations bf16, plus a bf16 parameter shadow), 4 for exact-f32 packs (f32
+    activations, no shadow)."""
     fpad = (in_features + 7) // 8 * 8
     wp = (max_width + 7) // 8 * 8
     params = max_width * fpad + max_width + (max_layers - 1) * (max_width * wp + max_width) + wp + 8
     params = (params + 63) // 64 * 64
-    slabs = params * (4 + 4 + 4 + 2 + 4 * gradient_slabs)            # P, M, V, Pb, G[splits]
-    acts = max_rows * (fpad * 2 + 4) + 2 * max_layers * max_rows * wp * 2
+    shadow = 2 if dtype_bytes == 2 else 0
+    slabs = params * (4 + 4 + 4 + shadow + 4 * gradient_slabs)       # P, M, V, Pb, G[splits]
+    acts = max_rows * (fpad * dtype_bytes + 4) + 2 * max_layers * max_rows * wp * dtype_bytes
     scratch = (max_rows // 32 + 1) * (wp + 8) * 4 + ((params + 2047) // 2048) * 4
-    fixed = n_train * (in_features * 4 + 4) + n_val * (fpad * 2 + 4)
+    fixed = n_train * (in_features * 4 + 4) + n_val * (fpad * dtype_bytes + 4)
     return PackFootprint(per_slot_bytes=slabs + acts + scratch, fixed_bytes=fixed)
 
 
 def default_capacity(in_features: int, max_width: int, max_layers: int, max_rows: int, n_train: int, n_val: int,
-                     budget_gb: float = 240.0, hard_cap: int = 1024) -> int:
-    fp = mlp_pack_footprint(in_features, max_width, max_layers, max_rows, n_train, n_val)
+                     budget_gb: float = 240.0, hard_cap: int = 1024, dtype_bytes: int = 2) -> int:
+    """Slots the budget allows, at most ``hard_cap``: the engine allocates every slot's slabs up front, and beyond about a
+    thousand resident trials per GPU the late rounds of a search are amortised already."""
+    fp = mlp_pack_footprint(in_features, max_width, max_layers, max_rows, n_train, n_val, dtype_bytes=dtype_bytes)
     return max(1, min(hard_cap, fp.slots_for(budget_gb * 10 ** 9)))

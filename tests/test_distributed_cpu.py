@@ -284,3 +284,91 @@ def test_four_ranks_stay_balanced_through_an_asha_search():
     still, stats0 = sim.run(4, 32, 8, gap=0)
     assert stats0["migrations"] == 0 and int((still.max(0) - still.min(0)).max()) > 1
     assert still.sum(0).tolist() == live.sum(0).tolist()                  # the moves change where, never what
+
+
+# ----------------------------------------------------------------------------------------- rank-aware run / resume
+def _resume_worker(rank, world, port, out_dir, phase):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from mitune.packed.engine import TorchPackEngine
+    from mitune.parallel.comm import TorchDistComm
+
+    class Interrupted(RuntimeError):
+        pass
+
+    class CrashingEngine(TorchPackEngine):
+        epochs_done = 0
+
+        def train_epoch(self):
+            if phase == "crash" and self.epochs_done == 2:
+                raise Interrupted("power cut")            # every rank, same round: the whole job goes down
+            super().train_epoch()
+            self.epochs_done += 1
+
+    comm = TorchDistComm(backend="gloo", rank=rank, world_size=world, timeout_s=60.0)
+    train, val = _data()
+    tr = PackedTrainable(train=train, val=val, max_epochs=4, engine="torch", capacity=3, name="resumable",
+                         checkpoint_freq=1)
+    ex = PackedExecutor(tr, comm=comm, device=torch.device("cpu"), capacity=3, seed=0, engine=CrashingEngine(tr, "cpu", 3, 0))
+    sched = ASHAScheduler(metric="validation_loss", mode="min", max_t=4, reduction_factor=2)
+    # only rank 0 names a directory and every rank passes a different experiment name: rank 0's win
+    kw = dict(local_dir=os.path.join(out_dir, "exp") if rank == 0 else None, name="resumable" if rank == 0 else f"r{rank}")
+    if phase == "reference":
+        kw = dict(local_dir=os.path.join(out_dir, "ref"), name="resumable")
+    try:
+        an = mitune.run(tr, config=SPACE, num_samples=8, scheduler=sched, executor=ex, seed=0, verbose=0,
+                        resume=(phase == "resume"), **kw)
+        res = {t.trial_id: (t.training_iteration, t.last_result["validation_loss"]) for t in an.trials}
+    except Interrupted:
+        res = "interrupted"
+    with open(os.path.join(out_dir, f"{phase}{rank}.json"), "w") as f:
+        json.dump(res, f)
+    comm.close()
+
+
+def test_two_rank_search_resumes_after_a_crash_like_an_uninterrupted_one(tmp_path):
+    def spawn(phase):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_resume_worker, args=(2, port, str(tmp_path), phase), nprocs=2, join=True)
+        return [json.load(open(tmp_path / f"{phase}{r}.json")) for r in range(2)]
+
+    assert spawn("crash") == ["interrupted", "interrupted"]
+    exp = tmp_path / "exp" / "resumable"
+    assert sorted(os.listdir(tmp_path / "exp")) == ["resumable"]           # one tree: rank 0's directory and name
+    state = json.load(open(exp / "experiment_state.json"))
+    assert any(t["status"] == "RUNNING" for t in state["trials"])
+    # trials owned by rank 1 were checkpointed into the shared tree too
+    owners = {t["trial_id"]: t.get("placement", {}).get("rank") for t in state["trials"]}
+    with_ckpt = [d for d in os.listdir(exp) if os.path.isdir(exp / d) and any(x.startswith("checkpoint_") for x in os.listdir(exp / d))]
+    assert len(with_ckpt) >= 2 and set(owners.values()) >= {0, 1}
+    # result.json has one writer: no duplicated lines
+    for d in with_ckpt:
+        lines = [json.loads(ln)["training_iteration"] for ln in open(exp / d / "result.json")]
+        assert lines == sorted(set(lines)), (d, lines)
+    a, b = spawn("resume")
+    assert a == b
+    ref, _ = spawn("reference")
+    assert a == ref                                                          # same trajectories, same survivors
+
+
+def test_decisions_that_depend_on_time_use_the_replicated_clock():
+    """One rank's wall clock is hours ahead: a time budget must still end the search in the same round on both ranks
+    (before, the fast clock's rank stopped creating trials and the next collective hung)."""
+    class SkewedExecutor(PackedExecutor):
+        def bind_runner(self, runner):
+            super().bind_runner(runner)
+            if self.rank == 1:
+                runner._t0 -= 36_000.0
+
+    def fn(comm):
+        train, val = _data()
+        tr = PackedTrainable(train=train, val=val, max_epochs=2, engine="torch", capacity=2)
+        ex = SkewedExecutor(tr, comm=comm, device=torch.device("cpu"), capacity=2, seed=0)
+        an = mitune.run(tr, config=SPACE, num_samples=8, executor=ex, seed=0, verbose=0, time_budget_s=3600.0)
+        return ([(t.trial_id, t.training_iteration, t.last_result.get("time_total_s")) for t in an.trials],
+                ex.replicated_elapsed_s)
+
+    (r0, e0), (r1, e1) = _run_ranks(2, fn)
+    assert r0 == r1 and e0 == e1 and e0 > 0
+    assert len(r0) == 8 and all(it == 2 for _, it, _ in r0)                  # the budget was nowhere near spent

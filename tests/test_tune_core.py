@@ -385,3 +385,29 @@ def test_pbt_with_function_trainables_restarts_from_donor_checkpoint():
     assert an.stats["num_restarts"] >= 1
     assert any(start > 0 for _, start in seen)               # someone resumed from a donor checkpoint
     assert min(t.last_result["score"] for t in an.trials) > 0.1 * 8   # the weak trial was lifted by exploiting
+
+
+def test_bayesopt_ignores_non_finite_observations():
+    from mitune import tune
+    from mitune.search.bayesopt import BayesOptSearch
+    s = BayesOptSearch(metric="loss", mode="min", random_search_steps=3, seed=0)
+    s.set_search_properties("loss", "min", {"x": tune.uniform(0.0, 1.0)})
+    for i, v in enumerate([0.5, float("inf"), float("-inf"), float("nan"), 0.2, 0.9, 0.4]):
+        cfg = s.suggest(f"t{i}")
+        s.on_trial_complete(f"t{i}", {"loss": v})
+    assert len(s._y) == 4
+    for i in range(7, 12):                       # GP phase: every suggestion is a finite point of the space
+        cfg = s.suggest(f"t{i}")
+        assert 0.0 <= cfg["x"] <= 1.0
+        s.on_trial_complete(f"t{i}", {"loss": (cfg["x"] - 0.3) ** 2})
+
+
+def test_process_executor_maps_devices_through_the_parents_mask():
+    from mitune.tune.executor import physical_device_ids
+    assert physical_device_ids([0, 1], env={}) == ["0", "1"]
+    assert physical_device_ids([0, 1], env={"HIP_VISIBLE_DEVICES": "4,5"}) == ["4", "5"]
+    assert physical_device_ids([1], env={"CUDA_VISIBLE_DEVICES": "2, 7"}) == ["7"]
+    assert physical_device_ids([1], env={"HIP_VISIBLE_DEVICES": "GPU-aa,GPU-bb", "CUDA_VISIBLE_DEVICES": "0,1"}) == ["GPU-bb"]
+    import pytest
+    with pytest.raises(ValueError):
+        physical_device_ids([2], env={"HIP_VISIBLE_DEVICES": "4,5"})

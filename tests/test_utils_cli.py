@@ -159,3 +159,30 @@ def test_tensorboard_event_file_round_trip(tmp_path):
     losses = [(s, v) for s, tag, v in sc if tag == "ray/tune/loss"]
     assert losses == [(1, 2.0), (2, 4.0), (3, 6.0)]
     assert any(tag == "ray/tune/time_total_s" for _, tag, _ in sc)
+
+
+def test_sanitizer_build_screens_launchers_and_plan_walk(tmp_path):
+    """Loads ``libmitune_hip_asan.so`` (host half under AddressSanitizer + UBSan) into an equally instrumented driver that
+    exercises argument validation, scratch sizing and the step driver's walk over a plan allocated exactly to size."""
+    import ctypes
+    import os
+    import shutil
+    import subprocess
+    from mitune.ops import build, lib as L
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not (os.path.exists(clang) and os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no ROCm toolchain on this machine")
+    asan = os.path.join(build.HERE, "libmitune_hip_asan.so")
+    if build.library_digest(asan) != build._digest():
+        build.build_sanitized(verbose=False)              # about a minute, once per source change
+    assert build.library_digest(asan) == build._digest()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "asan_driver")
+    subprocess.run([clang, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                    os.path.join(root, "tests", "native", "asan_driver.cpp"), "-o", exe, "-L" + build.HERE,
+                    "-lmitune_hip_asan", "-Wl,-rpath," + build.HERE, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([exe, str(L.MlpPlan.ksplits.offset), str(L.MlpPlan.ksplits0.offset)], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0 and "ASAN_DRIVER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
