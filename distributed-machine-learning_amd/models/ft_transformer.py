@@ -84,7 +84,7 @@ class FTTransformer(nn.Module):
         for blk in self.blocks:
             t = blk(t)
         cls = t[:, -1, :]
-        return self.head(F.relu(self.head_norm(cls.float()))).squeeze(-1)
+        return linear(F.relu(self.head_norm(cls.float())), self.head.weight, self.head.bias).squeeze(-1)
 
     @classmethod
     def from_config(cls, config: Dict, n_features: int) -> "FTTransformer":

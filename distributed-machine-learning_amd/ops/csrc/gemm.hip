@@ -169,7 +169,7 @@ __device__ __forceinline__ void gemm_tile(const MtGemmGroup* __restrict__ groups
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int split = (MODE == 2) ? (tile.ti >> 8) : 0;
-  const int i0 = (tile.ti & 0xFF) * BM, j0 = tile.tj * BN;
+  const int i0 = (MODE == 2 ? (tile.ti & 0xFF) : (int)tile.ti) * BM, j0 = tile.tj * BN;   // only wgrad tiles carry a split index
   if (i0 >= g.I || j0 >= g.J) return;
   const uint16_t* A = reinterpret_cast<const uint16_t*>(g.A);
   const uint16_t* B = reinterpret_cast<const uint16_t*>(g.B);
@@ -707,5 +707,57 @@ extern "C" int mt_wgrad_single_launch(const void* dY, const void* X, float* C, f
   else
     hipLaunchKernelGGL(mt_wgrad_single_kernel<2>, dim3(nblocks), dim3(NTHREADS), 0, stream, g, tiles_i, ksplits,
                        split_stride, flags);
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Stand-alone dense-layer GEMMs for modules that are not part of a grouped pack (Transformer projections under bf16
+// autocast): the same tile code, the single group passed by value and the tile coordinates taken from blockIdx, so no
+// descriptor table is uploaded per call (these run inside autograd, under hipGraph capture).  The BLAS library's
+// kernels for these shapes are "stream-K" kernels whose workgroups wait on each other inside one launch; two of them
+// launched from different HIP streams share the CUs and can starve each other for good.  These kernels have no
+// workgroup-to-workgroup dependency, so any number of streams may run them side by side.
+//   mode 0: C[M][N] = A[M][K] . B[N][K]^T (+ bias f32[N]) (ReLU if flags & 1)        forward
+//   mode 1: C[M][N] = A[M][K] . B[K][N]                                              input gradient (A = dY, B = W)
+// Block -> tile: consecutive blocks walk the column tiles of one row panel (they share the A panel in L2), and with
+// the number of column tiles padded to a multiple of 8 a row panel's tiles stay on one XCD.
+template <int MODE, int NSTAGE>
+__global__ __launch_bounds__(NTHREADS) void mt_gemm_single_kernel(MtGemmGroup g, int tiles_i, int tiles_j, int flags) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * STAGE_BYTES];
+  const int b = blockIdx.x;
+  // XCD-aware order: block b runs on XCD b % 8; give every XCD whole row panels (tiles_j consecutive column tiles)
+  const int n = tiles_i * tiles_j;
+  const int per = (n + 7) / 8;
+  const int t = (b % 8) * per + b / 8;
+  if (t >= n) return;
+  MtTile tile;
+  tile.group = 0;
+  tile.ti = (int16_t)(t / tiles_j);
+  tile.tj = (int16_t)(t % tiles_j);
+  gemm_tile<MODE, NSTAGE>(&g, tile, 0, flags, 0, 0, 1, 0, lds);
+}
+
+extern "C" int mt_gemm_single_launch(int mode, const void* A, const void* B, void* C, const void* aux, int M, int N, int K,
+                                     int lda, int ldb, int ldc, int flags, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if ((lda & 7) || (ldb & 7) || (ldc & 7) || (mode != 0 && mode != 1)) return -2;
+  const int tiles_i = (M + BM - 1) / BM, tiles_j = (N + BN - 1) / BN;
+  if (tiles_i > 32767 || tiles_j > 32767) return -2;
+  MtGemmGroup g;
+  g.A = A; g.B = B; g.C = C; g.aux = aux; g.aux_out = nullptr;
+  g.I = M; g.J = N; g.KK = K;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = 0;
+  g.active_steps = 1;
+  const int n = tiles_i * tiles_j;
+  const int nblocks = ((n + 7) / 8) * 8;
+  dim3 grid(nblocks), block(NTHREADS);
+  const bool deep = n <= 320;
+  if (mode == 0) {
+    if (deep) hipLaunchKernelGGL((mt_gemm_single_kernel<0, 4>), grid, block, 0, stream, g, tiles_i, tiles_j, flags);
+    else hipLaunchKernelGGL((mt_gemm_single_kernel<0, 2>), grid, block, 0, stream, g, tiles_i, tiles_j, flags);
+  } else {
+    if (deep) hipLaunchKernelGGL((mt_gemm_single_kernel<1, 4>), grid, block, 0, stream, g, tiles_i, tiles_j, 0);
+    else hipLaunchKernelGGL((mt_gemm_single_kernel<1, 2>), grid, block, 0, stream, g, tiles_i, tiles_j, 0);
+  }
   return (int)hipGetLastError();
 }

@@ -158,7 +158,7 @@ __device__ __forceinline__ void f32_gemm_tile(const MtGemmGroup* __restrict__ gr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int split = (MODE == 2) ? (tile.ti >> 8) : 0;
-  const int i0 = (tile.ti & 0xFF) * T, j0 = tile.tj * T;
+  const int i0 = (MODE == 2 ? (tile.ti & 0xFF) : (int)tile.ti) * T, j0 = tile.tj * T;   // only wgrad tiles carry a split index
   if (i0 >= g.I || j0 >= g.J) return;
   const float* A = reinterpret_cast<const float*>(g.A);
   const float* B = reinterpret_cast<const float*>(g.B);
@@ -366,4 +366,51 @@ extern "C" int mt_gemm_f32_bwd_launch(const MtGemmGroup* wgroups, const MtTile* 
   MtHeadReduceArgs none = {nullptr, nullptr, nullptr, 0, 0, 0};
   return mt_gemm_f32_bwd_head_launch(wgroups, wtiles, n_wtiles, dgroups, dtiles, n_dtiles, step, ksplits, split_stride,
                                      tile_edge, none, stream);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Stand-alone f32 dense-layer GEMMs (one group by value, tile from blockIdx), the f32 twin of mt_gemm_single_launch in
+// gemm.hip: forward (mode 0, bias + optional ReLU), input gradient (mode 1) and weight gradient (mode 2, bias gradient
+// = column sums of dY when db is given; contraction over the rows, no split).  64-tiles unless the launch has enough
+// 128-tiles to fill the chip twice.
+template <int MODE, int NSTAGE, int T>
+__global__ __launch_bounds__(F32_THREADS) void mt_gemm_f32_single_kernel(MtGemmGroup g, int tiles_i, int tiles_j, int flags) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * 2 * T * 128];
+  const int b = blockIdx.x;
+  const int n = tiles_i * tiles_j;
+  const int per = (n + 7) / 8;
+  const int t = (b % 8) * per + b / 8;
+  if (t >= n) return;
+  MtTile tile;
+  tile.group = 0;
+  tile.ti = (int16_t)(t / tiles_j);
+  tile.tj = (int16_t)(t % tiles_j);
+  f32_gemm_tile<MODE, NSTAGE, T>(&g, tile, 0, flags, 0, 0, 1, 0, lds);
+}
+
+extern "C" int mt_gemm_f32_single_launch(int mode, const void* A, const void* B, void* C, const void* aux, void* aux_out,
+                                         int I, int J, int KK, int lda, int ldb, int ldc, int flags, hipStream_t stream) {
+  if (I <= 0 || J <= 0 || KK <= 0) return 0;
+  if ((lda & 3) || (ldb & 3) || (ldc & 3) || mode < 0 || mode > 2) return -2;
+  const int n128 = ((I + 127) / 128) * ((J + 127) / 128);
+  const int T = n128 >= 512 ? 128 : 64;
+  const int tiles_i = (I + T - 1) / T, tiles_j = (J + T - 1) / T;
+  if (tiles_i > (mode == 2 ? 255 : 32767) || tiles_j > 32767) return -2;
+  MtGemmGroup g;
+  g.A = A; g.B = B; g.C = C; g.aux = aux; g.aux_out = aux_out;
+  g.I = I; g.J = J; g.KK = KK;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = 0;
+  g.active_steps = 1;
+  const int nblocks = ((tiles_i * tiles_j + 7) / 8) * 8;
+  dim3 grid(nblocks), block(F32_THREADS);
+#define MT_F32_SINGLE(M_) \
+  do { \
+    if (T == 128) hipLaunchKernelGGL((mt_gemm_f32_single_kernel<M_, 2, 128>), grid, block, 0, stream, g, tiles_i, tiles_j, flags); \
+    else hipLaunchKernelGGL((mt_gemm_f32_single_kernel<M_, 3, 64>), grid, block, 0, stream, g, tiles_i, tiles_j, flags); \
+  } while (0)
+  if (mode == 0) MT_F32_SINGLE(0);
+  else if (mode == 1) MT_F32_SINGLE(1);
+  else MT_F32_SINGLE(2);
+#undef MT_F32_SINGLE
+  return (int)hipGetLastError();
 }

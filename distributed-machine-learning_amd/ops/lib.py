@@ -198,6 +198,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_posenc_bwd_launch.argtypes = [c_void_p] * 2 + [C.c_long, C.c_int, c_void_p, c_float, c_void_p]
     lib.mt_wgrad_single_launch.argtypes = [c_void_p] * 4 + [C.c_int] * 4 + [c_size_t, c_void_p]
     lib.mt_wgrad_single_launch.restype = C.c_int
+    lib.mt_gemm_single_launch.argtypes = [C.c_int] + [c_void_p] * 4 + [C.c_int] * 7 + [c_void_p]
+    lib.mt_gemm_f32_single_launch.argtypes = [C.c_int] + [c_void_p] * 5 + [C.c_int] * 7 + [c_void_p]
+    lib.mt_gemm_single_launch.restype = lib.mt_gemm_f32_single_launch.restype = C.c_int
     lib.mt_small_linear_bwd_launch.argtypes = [c_void_p] * 6 + [C.c_int] * 3 + [c_void_p]
     lib.mt_small_linear_bwd_launch.restype = C.c_int
     lib.mt_small_linear_bwd_tiled_launch.argtypes = [c_void_p] * 6 + [C.c_int] * 4 + [c_void_p]

@@ -59,7 +59,36 @@ def _shadow(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return getattr(t, "_mt_bf16", None) if t is not None else None
 
 
+OWN_GEMM = os.environ.get("MITUNE_OWN_GEMM", "1") != "0"      # 0: dense forward / input gradient back on the BLAS library
+
+
+def _bf16_autocast() -> bool:
+    return torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``x @ weight.T + bias`` on this package's own MFMA kernels whenever the operands allow 16-byte rows, so that a
+    training step launches no BLAS-library GEMM at all: forward, input gradient and weight gradient of bf16-autocast
+    layers on the bf16 tile kernel (``DenseBF16``), of f32 layers on the exact-f32 tile kernel (``DenseF32``) or, for
+    small f32 layers, on the fused one-launch backward (``SmallLinear``)."""
+    out_f, in_f = weight.shape
+    if x.is_cuda and OWN_GEMM and x.numel() > 0:
+        if out_f == 1 and torch.is_autocast_enabled():
+            # a scalar head under autocast: a row-wise dot product in f32 (one multiply + one row reduction), not a GEMV
+            with torch.autocast("cuda", enabled=False):
+                y = (x.float() * weight.float().reshape(-1)).sum(-1, keepdim=True)
+                return y if bias is None else y + bias.float()
+        if _bf16_autocast() and out_f % 8 == 0 and in_f % 8 == 0 and weight.dtype == torch.float32:
+            xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+            return DenseBF16.apply(xb, weight, bias, _shadow(weight))
+        if (not torch.is_autocast_enabled() and x.dtype == torch.float32 and weight.dtype == torch.float32
+                and (bias is None or bias.dtype == torch.float32)):
+            if _small_eligible(x, weight, bias):
+                return SmallLinear.apply(x, weight, bias)
+            if out_f % 4 == 0 and in_f % 4 == 0:
+                return DenseF32.apply(x, weight, bias)
+            if _small_inference(x, weight, bias):
+                return SmallLinear.forward(_NoCtx(), x, weight, bias)
     if _eligible(x, weight):
         xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
         return SplitKLinear.apply(xb, weight, bias, _shadow(weight), _shadow(bias))
@@ -75,6 +104,124 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return F.linear(x, weight, bias)
 
 
+def _wgrad_bf16(dyc: torch.Tensor, xc: torch.Tensor, out_f: int, in_f: int, has_bias: bool):
+    """dW [out, in] and db [out] (f32) of a bf16 layer: split-K tiles over the rows, ordered slab sum."""
+    from . import lib as L
+    so = L.load()
+    M = xc.shape[0]
+    tiles = ((out_f + 127) // 128) * ((in_f + 127) // 128)
+    ksplits = max(1, min(127, (M + 63) // 64, (SPLIT_TARGET + tiles - 1) // tiles))     # 127: split index field
+    slab = (out_f * in_f + out_f + 63) // 64 * 64
+    arena = torch.empty(ksplits, slab, device=xc.device, dtype=torch.float32)
+    db_ptr = arena.data_ptr() + out_f * in_f * 4 if has_bias else None
+    L.check(so.mt_wgrad_single_launch(dyc.data_ptr(), xc.data_ptr(), arena.data_ptr(), db_ptr, M, out_f, in_f,
+                                      ksplits, slab, L.raw_stream(xc.device)),
+            "mt_wgrad_single_launch")
+    total = arena.sum(0) if ksplits > 1 else arena[0]
+    dw = total[:out_f * in_f].view(out_f, in_f)
+    db = total[out_f * in_f:out_f * in_f + out_f] if has_bias else None
+    return dw, db
+
+
+class DenseBF16(torch.autograd.Function):
+    """A dense layer under bf16 autocast, all three GEMMs on the 128x128 bf16 MFMA tile kernel of ``csrc/gemm.hip``.
+
+    ``x`` arrives in bf16; the weight operand is the bf16 shadow the flat optimiser keeps (``w16``) or a cast of the f32
+    master; the bias is added in f32 from the master before the output is rounded to bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16=None):
+        from . import lib as L
+        so = L.load()
+        out_f, in_f = weight.shape
+        with torch.autocast("cuda", enabled=False):
+            wb = w16 if w16 is not None else weight.detach().to(torch.bfloat16)
+            xc = x.reshape(-1, in_f)
+            if not xc.is_contiguous():
+                xc = xc.contiguous()
+            bf = None if bias is None else (bias.detach() if bias.dtype == torch.float32 else bias.detach().float())
+            y = torch.empty(xc.shape[0], out_f, device=x.device, dtype=torch.bfloat16)
+            L.check(so.mt_gemm_single_launch(0, xc.data_ptr(), wb.data_ptr(), y.data_ptr(),
+                                             bf.data_ptr() if bf is not None else None, xc.shape[0], out_f, in_f,
+                                             in_f, in_f, out_f, 0, L.raw_stream(x.device)), "mt_gemm_single_launch")
+        ctx.save_for_backward(xc, wb)
+        ctx.has_bias = bias is not None
+        ctx.x_shape = x.shape
+        return y.view(x.shape[:-1] + (out_f,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        so = L.load()
+        xc, wb = ctx.saved_tensors
+        out_f, in_f = wb.shape
+        with torch.autocast("cuda", enabled=False):
+            dyc = dy.reshape(-1, out_f)
+            if dyc.dtype != torch.bfloat16:
+                dyc = dyc.to(torch.bfloat16)
+            if not dyc.is_contiguous():
+                dyc = dyc.contiguous()
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(xc.shape[0], in_f, device=dy.device, dtype=torch.bfloat16)
+                L.check(so.mt_gemm_single_launch(1, dyc.data_ptr(), wb.data_ptr(), dx.data_ptr(), None, xc.shape[0], in_f,
+                                                 out_f, out_f, in_f, in_f, 0, L.raw_stream(dy.device)),
+                        "mt_gemm_single_launch")
+                dx = dx.view(ctx.x_shape)
+            dw, db = _wgrad_bf16(dyc, xc, out_f, in_f, ctx.has_bias)
+        return dx, dw, db, None
+
+
+class DenseF32(torch.autograd.Function):
+    """An f32 dense layer on the exact-f32 MFMA tile kernel of ``csrc/gemm_f32.hip`` (forward, input gradient, and weight
+    + bias gradient in one launch each)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import lib as L
+        so = L.load()
+        out_f, in_f = weight.shape
+        xc = x.reshape(-1, in_f)
+        if not xc.is_contiguous():
+            xc = xc.contiguous()
+        wc = weight.detach()
+        if not wc.is_contiguous():
+            wc = wc.contiguous()
+        y = torch.empty(xc.shape[0], out_f, device=x.device, dtype=torch.float32)
+        L.check(so.mt_gemm_f32_single_launch(0, xc.data_ptr(), wc.data_ptr(), y.data_ptr(),
+                                             bias.data_ptr() if bias is not None else None, None, xc.shape[0], out_f, in_f,
+                                             in_f, in_f, out_f, 0, L.raw_stream(x.device)), "mt_gemm_f32_single_launch")
+        ctx.save_for_backward(xc, wc)
+        ctx.has_bias = bias is not None
+        ctx.x_shape = x.shape
+        return y.view(x.shape[:-1] + (out_f,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        so = L.load()
+        xc, wc = ctx.saved_tensors
+        out_f, in_f = wc.shape
+        dyc = dy.reshape(-1, out_f)
+        if dyc.dtype != torch.float32:
+            dyc = dyc.float()
+        if not dyc.is_contiguous():
+            dyc = dyc.contiguous()
+        M, dev = xc.shape[0], dy.device
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, in_f, device=dev, dtype=torch.float32)
+            L.check(so.mt_gemm_f32_single_launch(1, dyc.data_ptr(), wc.data_ptr(), dx.data_ptr(), None, None, M, in_f, out_f,
+                                                 out_f, in_f, in_f, 0, L.raw_stream(dev)), "mt_gemm_f32_single_launch")
+            dx = dx.view(ctx.x_shape)
+        dw = torch.empty(out_f, in_f, device=dev, dtype=torch.float32)
+        db = torch.empty(out_f, device=dev, dtype=torch.float32) if ctx.has_bias else None
+        L.check(so.mt_gemm_f32_single_launch(2, dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), None,
+                                             db.data_ptr() if db is not None else None, out_f, in_f, M, out_f, in_f, in_f,
+                                             1 if db is not None else 0, L.raw_stream(dev)), "mt_gemm_f32_single_launch")
+        return dx, dw, db
+
+
 class _NoCtx:
     def save_for_backward(self, *a):
         pass
@@ -82,7 +229,7 @@ class _NoCtx:
 
 def _small_inference(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
     """The same small f32 layers when no gradient is recorded (validation passes): the forward kernel alone."""
-    if torch.is_grad_enabled() or not x.is_cuda or torch.is_autocast_enabled() or not SmallLinear.OWN_FORWARD:
+    if torch.is_grad_enabled() or not x.is_cuda or torch.is_autocast_enabled() or not (SmallLinear.OWN_FORWARD or OWN_GEMM):
         return False
     if x.dtype != torch.float32 or weight.dtype != torch.float32 or (bias is not None and bias.dtype != torch.float32):
         return False
@@ -103,11 +250,21 @@ class SmallLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        if not SmallLinear.OWN_FORWARD:
-            return F.linear(x, weight, bias)
         from . import lib as L
-        so = L.load()
         out_f, in_f = weight.shape
+        if OWN_GEMM and out_f % 4 == 0 and in_f % 4 == 0:       # 16-byte rows: the 64-tile exact-f32 MFMA kernel
+            so = L.load()
+            xc = x.reshape(-1, in_f).contiguous()
+            wc = weight.detach().contiguous()
+            y = torch.empty(xc.shape[0], out_f, device=x.device, dtype=torch.float32)
+            L.check(so.mt_gemm_f32_single_launch(0, xc.data_ptr(), wc.data_ptr(), y.data_ptr(),
+                                                 bias.data_ptr() if bias is not None else None, None, xc.shape[0], out_f,
+                                                 in_f, in_f, in_f, out_f, 0, L.raw_stream(x.device)),
+                    "mt_gemm_f32_single_launch")
+            return y.view(x.shape[:-1] + (out_f,))
+        if not (SmallLinear.OWN_FORWARD or OWN_GEMM):
+            return F.linear(x, weight, bias)
+        so = L.load()
         xc = x.reshape(-1, in_f).contiguous()
         wc = weight.contiguous()
         y = torch.empty(xc.shape[0], out_f, device=x.device, dtype=torch.float32)

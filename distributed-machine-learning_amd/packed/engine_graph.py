@@ -18,11 +18,25 @@ captured too and replayed right behind its last training step, so an epoch of th
 validation of every slot -- is one stretch of asynchronous replays and ONE host synchronisation (eager validation cost
 about 2 ms of host time per slot and epoch with the GPU idle meanwhile).
 
-Concurrent issue is confined to the regime it was built for and verified in: f32 models whose step touches at most
-``SMALL_STEP_ROWS`` token rows (launch-latency-bound kernels of a few workgroups each).  Packs outside it -- bf16
-autocast, or long token dimensions whose library GEMMs fill the chip on their own -- are issued on one stream, slot
-after slot: there overlap has nothing to win, and three FT-Transformer slots (bf16, 66 560 token rows per step)
-issued over several streams never completed on the test machine.
+Concurrent issue is the default only in the regime where it pays: steps that touch at most ``SMALL_STEP_ROWS`` token
+rows (launch-latency-bound kernels of a few workgroups each).  Packs with long token dimensions, whose GEMMs fill the
+chip on their own, are issued on one stream, slot after slot, unless ``model_kwargs["streams"]`` asks otherwise.
+
+Why big packs once stalled on several streams, and what makes them safe now.  Three bf16 FT-Transformer slots (66 560
+token rows per step) replayed over three streams used to stop for good after a dozen steps: every stream idle, the host
+blocked in a graph launch or in the final synchronisation.  ``bench/hang_repro.py`` reproduces it and bisects it
+(``profiles/r2_multistream_stall.txt``): it happens with 2 or 3 slots, in bf16 and in f32, eagerly-built or replayed, with
+the host held to 1, 4 or 16 replays ahead of each stream or not held at all, with 4 or 16 hardware queues -- and only
+while the dense layers run on the BLAS library.  For these shapes the library picks "stream-K" GEMM kernels (``SK3`` in
+their names), whose workgroups wait inside the launch for partial tiles of sibling workgroups and therefore need the
+whole launch resident; two such launches from different streams split the CUs between them and each waits for
+workgroups that the other keeps from being scheduled.  The small-kernel regime never met them (its GEMMs are plain
+tiles).  Dense layers now run on this package's own tile kernels (``ops/linear.py``: no workgroup ever waits for
+another), with which the same pack completes on any number of streams (156 steps x 3 slots in 1.8 s, unbounded
+run-ahead).  With ``MITUNE_OWN_GEMM=0`` (library GEMMs) a pack outside the small-kernel regime is refused several
+streams.  Independently of that, the host is kept at most ``IN_FLIGHT`` replays ahead of each stream it feeds (an event
+ring per stream), which bounds the queue depth at no cost: in the small regime the device drains replays as fast as
+one thread enqueues them.
 
 PBT exploits inside a pack are slab-to-slab copies (weights + both moment slabs + step counter); the captured graph
 of the receiving slot stays valid because it only holds pointers.
@@ -44,7 +58,32 @@ from ..train.graphed import FlatOptimizer, FlatParams, GraphedTrainer
 from ..train.losses import MAPE_EPS, elementwise_loss, get_criterion
 
 DEFAULT_STREAMS = 4      # = the runtime's hardware queues per process; which streams exactly: packed/streams.py
-SMALL_STEP_ROWS = 4096   # batch x tokens up to which slots are issued concurrently
+SMALL_STEP_ROWS = 4096   # batch x tokens up to which slots are issued concurrently by default
+IN_FLIGHT = int(os.environ.get("MITUNE_IN_FLIGHT", "8"))      # graph replays the host may be ahead of any one stream while it feeds several
+
+
+class _FlowControl:
+    """Bounds how far the host runs ahead of each of several streams: ``admit(j)`` before enqueueing work on stream
+    ``j`` waits until all but the newest ``depth - 1`` pieces of work enqueued there have finished; ``sent(j, stream)``
+    marks the piece just enqueued."""
+
+    def __init__(self, n_streams: int, depth: int = IN_FLIGHT):
+        self.depth = max(1, int(depth))
+        self.rings: List[List[torch.cuda.Event]] = [[] for _ in range(n_streams)]
+        self.count = [0] * n_streams
+
+    def admit(self, j: int) -> None:
+        k = self.count[j]
+        if k >= self.depth:
+            self.rings[j][k % self.depth].synchronize()
+
+    def sent(self, j: int, stream: torch.cuda.Stream) -> None:
+        k = self.count[j]
+        ring = self.rings[j]
+        if len(ring) < self.depth:
+            ring.append(torch.cuda.Event())
+        ring[k % self.depth].record(stream)
+        self.count[j] = k + 1
 
 
 class GraphPackEngine(TorchPackEngine):
@@ -65,6 +104,8 @@ class GraphPackEngine(TorchPackEngine):
         self.prepared_total = 0
         n = int(trainable.model_kwargs.get("streams", os.environ.get("MITUNE_GRAPH_STREAMS", DEFAULT_STREAMS)))
         self._n_streams = max(1, min(n, 16))
+        # an explicit request for streams is honoured for every pack; the default keeps big-kernel packs on one stream
+        self._streams_forced = "streams" in trainable.model_kwargs or os.environ.get("MITUNE_GRAPH_FORCE_STREAMS") == "1"
         self._streams: List[torch.cuda.Stream] = []     # picked at the first concurrent epoch (packed/streams.py)
         self._calibrated = False
 
@@ -195,10 +236,16 @@ class GraphPackEngine(TorchPackEngine):
         return int(X.shape[1]) if X.dim() >= 2 else 1       # sequence length, or one token per tabular feature
 
     def _issue_streams(self, order, samples_per_launch: int, bound: int = SMALL_STEP_ROWS) -> List[torch.cuda.Stream]:
-        """Streams the slots in ``order`` are spread over: several only in the small-kernel f32 regime."""
+        """Streams the slots in ``order`` are spread over: several in the small-kernel regime, or when asked for."""
         small = samples_per_launch * self._tokens_per_sample() <= bound
-        if self.amp or not small or self._n_streams < 2 or len(order) < 2:
+        if not (small or self._streams_forced) or self._n_streams < 2 or len(order) < 2:
             return [torch.cuda.current_stream(self.device)]
+        if not small:
+            from ..ops import linear as _lin
+            if not _lin.OWN_GEMM:
+                raise ValueError("several streams were requested for a pack of large steps while MITUNE_OWN_GEMM=0 routes "
+                                 "its dense layers to the BLAS library: the library's stream-K GEMM kernels deadlock when "
+                                 "launched from several streams at once; drop 'streams' or keep the own GEMM kernels on")
         if not self._calibrated:
             self._calibrate_streams()
         return self._streams
@@ -254,14 +301,19 @@ class GraphPackEngine(TorchPackEngine):
                 if ride:
                     tr.eval_graph.replay()
         else:
+            flow = _FlowControl(ns)
             for i in range(max(b for _, _, b in plan) + 1):
                 for j, (_, tr, batches) in enumerate(plan):
-                    if i < batches:
-                        with torch.cuda.stream(streams[j % ns]):
+                    if i > batches or (i == batches and not ride):
+                        continue
+                    q = j % ns
+                    flow.admit(q)                       # never more than IN_FLIGHT replays ahead of a stream
+                    with torch.cuda.stream(streams[q]):
+                        if i < batches:
                             tr.step_once(i)
-                    elif i == batches and ride:
-                        with torch.cuda.stream(streams[j % ns]):
+                        else:
                             tr.eval_graph.replay()
+                    flow.sent(q, streams[q])
         self._fan_in(cur, streams)
         parts = [torch.stack([tr.epoch_loss(b) for _, tr, b in plan]).double()]
         if ride:
@@ -296,14 +348,19 @@ class GraphPackEngine(TorchPackEngine):
             streams = self._issue_streams(order, min(n, self.t.val_chunk), 4 * SMALL_STEP_ROWS)
             cur = self._fan_out(streams)
             ns = len(streams)
+            flow = _FlowControl(ns) if ns > 1 else None
             for j, slot in enumerate(order):
                 tr = self._trainers[slot]
+                if flow is not None:
+                    flow.admit(j % ns)
                 with torch.cuda.stream(streams[j % ns]):
                     if tr.eval_graph is not None:
                         tr.eval_graph.replay()
                         acc[j].copy_(tr.eval_acc)
                     else:
                         self._eval_into(self.slots[slot], acc[j])
+                if flow is not None:
+                    flow.sent(j % ns, streams[j % ns])
             self._fan_in(cur, streams)
             rows = acc.tolist()                                                        # one synchronisation
         return {slot: {"train_loss": self.slots[slot].train_loss, "validation_loss": r[0] / n,

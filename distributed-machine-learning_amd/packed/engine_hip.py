@@ -604,10 +604,16 @@ class HipPackEngine(PackEngine):
                 L.check(self.lib.mt_mlp_gather_at(C.byref(ch.plan), ch.counter.data_ptr(), st.cuda_stream),
                         "mt_mlp_gather_at")
             blocks = [ch.steps // GRAPH_STEPS for ch in self._chains]
+            # the host stays at most a few blocks ahead of every chain: a host that enqueues graph launches far ahead of
+            # several busy streams can wedge the runtime's submission path (packed/engine_graph.py has the measurements)
+            from .engine_graph import _FlowControl
+            flow = _FlowControl(len(pairs), depth=4)
             for b in range(max(blocks)):       # interleaved so that no chain gets a head start
-                for (ch, st), nb in zip(pairs, blocks):
+                for c, ((ch, st), nb) in enumerate(zip(pairs, blocks)):
                     if b < nb:
+                        flow.admit(c)
                         L.check(self.lib.mt_mlp_graph_replay(ch.graph, 1, st.cuda_stream), "mt_mlp_graph_replay")
+                        flow.sent(c, st)
             for (ch, st), nb in zip(pairs, blocks):
                 L.check(self.lib.mt_mlp_train_steps_at(C.byref(ch.plan), ch.counter.data_ptr(),
                                                        ch.steps - nb * GRAPH_STEPS, st.cuda_stream),

@@ -283,3 +283,65 @@ def test_small_linear_is_not_used_under_autocast_or_for_large_layers():
     assert "SmallLinear" in type(linear(x, w).grad_fn).__name__
     with torch.no_grad():
         assert linear(x, w).grad_fn is None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Dense layers on the package's own GEMM kernels (no BLAS library call in a training step)
+@pytest.mark.parametrize("rows,in_f,out_f", [(66560, 192, 576), (1024, 192, 256), (4096, 256, 192), (300, 64, 72), (66560, 256, 192)])
+def test_dense_bf16_matches_library_linear(rows, in_f, out_f):
+    from mitune.ops.linear import DenseBF16, linear
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(rows, in_f, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(out_f, in_f, device="cuda", generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(out_f, device="cuda", generator=g).requires_grad_(True)
+    dy = torch.randn(rows, out_f, device="cuda", generator=g).to(torch.bfloat16)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = linear(x.view(rows // 4, 4, in_f) if rows % 4 == 0 else x, w, b)
+    assert y.dtype == torch.bfloat16 and isinstance(y.grad_fn, DenseBF16._backward_cls)
+    y.backward(dy.view_as(y))
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)      # the kernel multiplies bf16-rounded weights
+    br = b.detach().clone().requires_grad_(True)
+    yr = xr @ wr.t() + br
+    yr.backward(dy.float())
+    torch.testing.assert_close(y.float().reshape(rows, out_f), yr, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(x.grad.float(), xr.grad, rtol=2e-2, atol=2e-2)
+    scale = float(wr.grad.abs().max())
+    torch.testing.assert_close(w.grad, wr.grad, rtol=1e-2, atol=1e-3 * scale)
+    torch.testing.assert_close(b.grad, br.grad, rtol=1e-2, atol=1e-3 * float(br.grad.abs().max()))
+
+
+@pytest.mark.parametrize("rows,in_f,out_f", [(40000, 128, 384), (3072, 512, 2048), (3072, 2048, 512), (70000, 64, 64), (40001, 68, 36)])
+def test_dense_f32_matches_float64_reference(rows, in_f, out_f):
+    from mitune.ops.linear import DenseF32, linear
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(rows, in_f, device="cuda", generator=g).requires_grad_(True)
+    w = (torch.randn(out_f, in_f, device="cuda", generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(out_f, device="cuda", generator=g).requires_grad_(True)
+    dy = torch.randn(rows, out_f, device="cuda", generator=g)
+    y = linear(x, w, b)
+    assert isinstance(y.grad_fn, DenseF32._backward_cls)
+    y.backward(dy)
+    xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yr = xr @ wr.t() + br
+    yr.backward(dy.double())
+    torch.testing.assert_close(y.double(), yr, rtol=1e-5, atol=5e-5)          # f32 accumulation over up to 2048 terms
+    torch.testing.assert_close(x.grad.double(), xr.grad, rtol=1e-5, atol=5e-5)
+    torch.testing.assert_close(w.grad.double(), wr.grad, rtol=1e-5, atol=1e-5 * float(wr.grad.abs().max()))
+    torch.testing.assert_close(b.grad.double(), br.grad, rtol=1e-5, atol=1e-5 * float(br.grad.abs().max()))
+
+
+def test_small_unaligned_f32_layer_stays_on_own_kernels():
+    """in_features = 10 (the sample model's input projection): rows are not 16-byte aligned, so the small-layer kernels
+    take forward and backward; the result still matches a float64 reference."""
+    from mitune.ops.linear import SmallLinear, linear
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(32, 50, 10, device="cuda", generator=g)
+    w = (torch.randn(64, 10, device="cuda", generator=g) * 0.3).requires_grad_(True)
+    b = torch.randn(64, device="cuda", generator=g).requires_grad_(True)
+    y = linear(x, w, b)
+    assert isinstance(y.grad_fn, SmallLinear._backward_cls)
+    y.sum().backward()
+    ref = x.double() @ w.detach().double().t() + b.detach().double()
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(w.grad.double(), x.double().reshape(-1, 10).sum(0).expand(64, 10), rtol=1e-5, atol=1e-4)
