@@ -89,9 +89,9 @@ def config4(args):
     for i, (lr, bs) in enumerate([(3e-4, 8192), (1e-3, 16384)][: args.trials]):
         cfg = {"hidden_sizes": [args.width] * 3, "batch_size": bs, "learning_rate": lr, "optimizer": "adamw"}
         tr = DPTrainer(cfg, Xtr, ytr, Xva, yva, comm=comm, seed=0, trial_index=i)
-        steps = min(args.dp_steps, Xtr.shape[0] // tr.local_batch)
-        keep = tr.X
-        tr.X, tr.y = tr.X[: steps * tr.local_batch], tr.y[: steps * tr.local_batch]
+        steps = min(args.dp_steps, tr.steps_per_epoch)
+        full_epoch = tr.steps_per_epoch
+        tr.steps_per_epoch = steps                 # a timed slice of the epoch (the same number of steps on every rank)
         comm.barrier()
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
@@ -100,12 +100,12 @@ def config4(args):
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
-        tr.X = keep
+        tr.steps_per_epoch = full_epoch
         m = tr.evaluate()
         flop = 6.0 * (256 * args.width + 2 * args.width ** 2 + args.width) * bs * steps
         results.append({"lr": lr, "global_batch": bs, "steps": steps, "ms_per_step": el / steps * 1e3,
                         "samples_per_s": bs * steps / el, "tflops": flop / el / 1e12, "train_loss": loss,
-                        "validation_mse": m["validation_mse"],
+                        "validation_mse": m["validation_mse"], "engine": "hip-dp" if tr.engine is not None else "torch",
                         "allreduce_gb_per_step": tr.reducer.bytes_reduced / 1e9 / max(steps, 1),
                         "epoch_seconds_full_table": args.rows * 0.98 / (bs * steps / el)})
     comm.close()

@@ -718,7 +718,7 @@ extern "C" int mt_wgrad_single_launch(const void* dY, const void* X, float* C, f
 // launched from different HIP streams share the CUs and can starve each other for good.  These kernels have no
 // workgroup-to-workgroup dependency, so any number of streams may run them side by side.
 //   mode 0: C[M][N] = A[M][K] . B[N][K]^T (+ bias f32[N]) (ReLU if flags & 1)        forward
-//   mode 1: C[M][N] = A[M][K] . B[K][N]                                              input gradient (A = dY, B = W)
+//   mode 1: C[M][N] = A[M][K] . B[K][N]  (zeroed where aux[M][ldaux] <= 0 if flags & 1)  input gradient (A = dY, B = W)
 // Block -> tile: consecutive blocks walk the column tiles of one row panel (they share the A panel in L2), and with
 // the number of column tiles padded to a multiple of 8 a row panel's tiles stay on one XCD.
 template <int MODE, int NSTAGE>
@@ -738,15 +738,16 @@ __global__ __launch_bounds__(NTHREADS) void mt_gemm_single_kernel(MtGemmGroup g,
 }
 
 extern "C" int mt_gemm_single_launch(int mode, const void* A, const void* B, void* C, const void* aux, int M, int N, int K,
-                                     int lda, int ldb, int ldc, int flags, hipStream_t stream) {
+                                     int lda, int ldb, int ldc, int ldaux, int flags, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if ((lda & 7) || (ldb & 7) || (ldc & 7) || (mode != 0 && mode != 1)) return -2;
+  if (mode == 1 && (flags & MT_GEMM_FLAG_MASK) && (aux == nullptr || (ldaux & 7))) return -2;
   const int tiles_i = (M + BM - 1) / BM, tiles_j = (N + BN - 1) / BN;
   if (tiles_i > 32767 || tiles_j > 32767) return -2;
   MtGemmGroup g;
   g.A = A; g.B = B; g.C = C; g.aux = aux; g.aux_out = nullptr;
   g.I = M; g.J = N; g.KK = K;
-  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = 0;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.active_steps = 1;
   const int n = tiles_i * tiles_j;
   const int nblocks = ((n + 7) / 8) * 8;
@@ -756,8 +757,8 @@ extern "C" int mt_gemm_single_launch(int mode, const void* A, const void* B, voi
     if (deep) hipLaunchKernelGGL((mt_gemm_single_kernel<0, 4>), grid, block, 0, stream, g, tiles_i, tiles_j, flags);
     else hipLaunchKernelGGL((mt_gemm_single_kernel<0, 2>), grid, block, 0, stream, g, tiles_i, tiles_j, flags);
   } else {
-    if (deep) hipLaunchKernelGGL((mt_gemm_single_kernel<1, 4>), grid, block, 0, stream, g, tiles_i, tiles_j, 0);
-    else hipLaunchKernelGGL((mt_gemm_single_kernel<1, 2>), grid, block, 0, stream, g, tiles_i, tiles_j, 0);
+    if (deep) hipLaunchKernelGGL((mt_gemm_single_kernel<1, 4>), grid, block, 0, stream, g, tiles_i, tiles_j, flags);
+    else hipLaunchKernelGGL((mt_gemm_single_kernel<1, 2>), grid, block, 0, stream, g, tiles_i, tiles_j, flags);
   }
   return (int)hipGetLastError();
 }

@@ -67,6 +67,20 @@ class MlpPlan(C.Structure):
                 ("fwd_big", c_int32 * MT_MAX_LAYERS), ("bwd_big", c_int32 * MT_MAX_LAYERS)]
 
 
+class DpPlan(C.Structure):
+    """Mirror of ``MtDpPlan`` (csrc/dp.hip): one data-parallel MLP trial's step, as the C++ driver walks it."""
+    _fields_ = [("n_hidden", c_int32), ("batch", c_int32), ("F", c_int32), ("hb", c_int32), ("n_rows", c_uint32),
+                ("world", c_int32), ("widths", c_int32 * MT_MAX_LAYERS), ("ksplits", c_int32 * MT_MAX_LAYERS),
+                ("w_off", C.c_int64 * (MT_MAX_LAYERS + 1)), ("b_off", C.c_int64 * (MT_MAX_LAYERS + 1)),
+                ("bucket_lo", C.c_int64 * (MT_MAX_LAYERS + 1)), ("bucket_hi", C.c_int64 * (MT_MAX_LAYERS + 1)),
+                ("numel", C.c_int64), ("X", c_void_p), ("Y", c_void_p), ("X0", c_void_p), ("ybuf", c_void_p),
+                ("H", c_void_p * MT_MAX_LAYERS), ("dZ", c_void_p * MT_MAX_LAYERS),
+                ("P", c_void_p), ("W", c_void_p), ("G32", c_void_p), ("Gb", c_void_p), ("M", c_void_p), ("V", c_void_p),
+                ("head", c_void_p), ("opt", c_void_p), ("ids", c_void_p), ("head_scratch", c_void_p),
+                ("all_reduce", c_void_p), ("comm", c_void_p), ("nccl_bf16", c_int32), ("nccl_avg", c_int32),
+                ("comm_stream", c_void_p), ("ready", c_void_p * (MT_MAX_LAYERS + 1)), ("reduced", c_void_p)]
+
+
 HM_MAXL = 5
 
 
@@ -198,9 +212,14 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_posenc_bwd_launch.argtypes = [c_void_p] * 2 + [C.c_long, C.c_int, c_void_p, c_float, c_void_p]
     lib.mt_wgrad_single_launch.argtypes = [c_void_p] * 4 + [C.c_int] * 4 + [c_size_t, c_void_p]
     lib.mt_wgrad_single_launch.restype = C.c_int
-    lib.mt_gemm_single_launch.argtypes = [C.c_int] + [c_void_p] * 4 + [C.c_int] * 7 + [c_void_p]
+    lib.mt_gemm_single_launch.argtypes = [C.c_int] + [c_void_p] * 4 + [C.c_int] * 8 + [c_void_p]
     lib.mt_gemm_f32_single_launch.argtypes = [C.c_int] + [c_void_p] * 5 + [C.c_int] * 7 + [c_void_p]
     lib.mt_gemm_single_launch.restype = lib.mt_gemm_f32_single_launch.restype = C.c_int
+    if lib.mt_dp_plan_sizeof() != C.sizeof(DpPlan):
+        raise KernelLibraryError(f"MtDpPlan is {lib.mt_dp_plan_sizeof()} bytes in the library, {C.sizeof(DpPlan)} in lib.py")
+    lib.mt_dp_train_steps.argtypes = [C.POINTER(DpPlan), c_void_p, C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_dp_eval.argtypes = [C.POINTER(DpPlan), c_void_p, C.c_int, C.c_int, c_void_p]
+    lib.mt_dp_train_steps.restype = lib.mt_dp_eval.restype = C.c_int
     lib.mt_small_linear_bwd_launch.argtypes = [c_void_p] * 6 + [C.c_int] * 3 + [c_void_p]
     lib.mt_small_linear_bwd_launch.restype = C.c_int
     lib.mt_small_linear_bwd_tiled_launch.argtypes = [c_void_p] * 6 + [C.c_int] * 4 + [c_void_p]

@@ -143,7 +143,7 @@ class DenseBF16(torch.autograd.Function):
             y = torch.empty(xc.shape[0], out_f, device=x.device, dtype=torch.bfloat16)
             L.check(so.mt_gemm_single_launch(0, xc.data_ptr(), wb.data_ptr(), y.data_ptr(),
                                              bf.data_ptr() if bf is not None else None, xc.shape[0], out_f, in_f,
-                                             in_f, in_f, out_f, 0, L.raw_stream(x.device)), "mt_gemm_single_launch")
+                                             in_f, in_f, out_f, 0, 0, L.raw_stream(x.device)), "mt_gemm_single_launch")
         ctx.save_for_backward(xc, wb)
         ctx.has_bias = bias is not None
         ctx.x_shape = x.shape
@@ -165,7 +165,7 @@ class DenseBF16(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty(xc.shape[0], in_f, device=dy.device, dtype=torch.bfloat16)
                 L.check(so.mt_gemm_single_launch(1, dyc.data_ptr(), wb.data_ptr(), dx.data_ptr(), None, xc.shape[0], in_f,
-                                                 out_f, out_f, in_f, in_f, 0, L.raw_stream(dy.device)),
+                                                 out_f, out_f, in_f, in_f, 0, 0, L.raw_stream(dy.device)),
                         "mt_gemm_single_launch")
                 dx = dx.view(ctx.x_shape)
             dw, db = _wgrad_bf16(dyc, xc, out_f, in_f, ctx.has_bias)

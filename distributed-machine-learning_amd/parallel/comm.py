@@ -82,6 +82,16 @@ class LocalComm(Comm):
         return obj
 
 
+def single_node_bootstrap(world_size: int) -> None:
+    """RCCL's bootstrap (the TCP side channel that sets a communicator up) picks a network interface by itself; in a
+    container whose host name does not resolve, or whose outward interface is filtered, that handshake times out.  When
+    every rank of the job is on this node (the launcher's LOCAL_WORLD_SIZE equals the world size, or there is one rank)
+    the loopback interface is the right one; an explicit NCCL_SOCKET_IFNAME always wins."""
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", world_size) or world_size)
+    if world_size <= 1 or local >= world_size:
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+
+
 class TorchDistComm(Comm):
     """``torch.distributed`` process group (RCCL when the backend is "nccl")."""
 
@@ -106,6 +116,7 @@ class TorchDistComm(Comm):
             kw = {}
             if backend == "nccl":
                 kw["device_id"] = device
+                single_node_bootstrap(world_size)
             dist.init_process_group(backend=backend, init_method=init_method or "env://", rank=rank,
                                     world_size=world_size, timeout=datetime.timedelta(seconds=timeout_s), **kw)
             self._own = True

@@ -7,13 +7,16 @@ batch, and gradients are averaged with RCCL all-reduce over xGMI.
 
 MI355X-first choices:
 
-* parameters, gradients and optimiser moments are FLAT slabs; the model's tensors are views into them.
-  On a GPU the weights the GEMMs read are the bf16 shadow slab, gradients are produced in bf16 straight
-  into the flat gradient slab, and the fused HIP optimiser (``ops/csrc/optim.hip``) consumes bf16
-  gradients, updates the f32 master slab and refreshes the bf16 shadow in one pass;
-* gradients are reduced in BUCKETS, one per layer, each launched asynchronously from an autograd hook
-  the moment that layer's gradients exist, so the all-reduce of layer l overlaps the backward GEMMs of
-  layers < l.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce moves
+* parameters, gradients and optimiser moments are FLAT slabs.  On a GPU (``HipDPEngine``) a whole optimiser step is
+  enqueued by the C++ driver ``ops/csrc/dp.hip``: keyed gather of bf16 rows, every GEMM on this package's bf16 MFMA
+  tile kernels (forward + bias + ReLU, split-K weight gradient + bias gradient, input gradient + ReLU mask), fused
+  head + loss, per-layer bf16 gradient buckets, and the fused optimiser that consumes bf16 gradients, updates the f32
+  masters and refreshes the bf16 shadow in one pass -- no autograd, no library GEMM, no Python between kernels;
+* gradients are reduced in BUCKETS, one per layer: the moment a layer's weight gradient is in its bucket, the bucket's
+  ``ncclAllReduce`` is enqueued on a communication stream (a direct RCCL communicator, ``parallel/rccl.py``), so the
+  all-reduce of layer l overlaps the input-gradient GEMM of layer l and the whole backward of layers < l; the
+  optimiser waits on one event.  On the CPU (tests, gloo) the same schedule runs as autograd hooks + asynchronous
+  ``torch.distributed`` all-reduces.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce moves
   2 * (n-1)/n * bytes per link, i.e. ~1.5 ms for one 8192 x 8192 bf16 bucket -- about one layer's backward,
   which is why per-layer buckets (not one big late bucket, not many tiny ones) are the right size here;
 * bf16 buckets halve the bytes on the links compared with f32 gradients.
@@ -26,6 +29,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import time
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -147,13 +151,23 @@ class DPTrainer:
         if self.global_batch % self.comm.world_size:
             raise ValueError("batch_size must be divisible by the number of ranks")
         self.local_batch = self.global_batch // self.comm.world_size
+        # Shards differ by a row (shard_rows gives +-1), and every rank must take the same number of steps -- each step is
+        # a fixed sequence of collectives.  The step count comes from the smallest shard, agreed on once.
+        n_min = torch.tensor([int(X.shape[0])], dtype=torch.int64, device=self.device if self.gpu else "cpu")
+        if self.comm.world_size > 1:
+            self.comm.all_reduce(n_min, op="min")
+        self.steps_per_epoch = int(n_min.item()) // self.local_batch
         self.epoch, self.step = 0, 0
         self.stats = {"steps": 0, "train_s": 0.0}
+        self.engine = None
+        if self.gpu and self.spec.gradient_clipping <= 0 and int(X.shape[1]) % 8 == 0 \
+                and all(h % 8 == 0 for h in self.spec.hidden_sizes) and len(self.spec.hidden_sizes) <= 8:
+            self.engine = HipDPEngine(self)
         if self.gpu:
             from ..ops import lib as L
             self.L, self.lib = L, L.load()
-            self.M = torch.zeros_like(self.model.P)
-            self.V = torch.zeros_like(self.model.P)
+            self.M = torch.zeros_like(self.model.P) if self.engine is None else self.engine.M
+            self.V = torch.zeros_like(self.model.P) if self.engine is None else self.engine.V
             self.ids = torch.zeros(1, dtype=torch.int32, device=self.device)
             self._hp_t = None
         else:
@@ -186,7 +200,17 @@ class DPTrainer:
     def train_epoch(self) -> float:
         t0 = time.time()
         n_local = int(self.X.shape[0])
-        steps = n_local // self.local_batch
+        steps = self.steps_per_epoch
+        if self.engine is not None:
+            mean = self.engine.train_epoch(steps)
+            self.reducer.bytes_reduced = self.engine.bytes_reduced
+            self.step += steps
+            self.epoch += 1
+            self.stats["steps"] += steps
+            self.stats["train_s"] += time.time() - t0
+            if self.comm.world_size > 1:
+                self.comm.all_reduce(mean, op="avg")
+            return float(mean)
         keys = round_keys(self.seed, self.trial_index * 1009 + self.comm.rank, self.epoch)
         perm = torch.from_numpy(permute(np.arange(steps * self.local_batch, dtype=np.uint32), n_local, keys)).to(self.device)
         loss_sum = torch.zeros((), device=self.device, dtype=torch.float32)
@@ -217,6 +241,14 @@ class DPTrainer:
     def evaluate(self, chunk: int = 65536) -> Dict[str, float]:
         """Validation metrics over the union of all ranks' validation shards (sample-weighted)."""
         acc = torch.zeros(4, device=self.device, dtype=torch.float64)
+        if self.engine is not None:
+            acc[:3] = self.engine.evaluate()
+            acc[3] = float(self.Xval.shape[0])
+            if self.comm.world_size > 1:
+                self.comm.all_reduce(acc, op="sum")
+            n = max(float(acc[3]), 1.0)
+            return {"validation_loss": float(acc[0]) / n, "validation_mse": float(acc[1]) / n,
+                    "validation_mape": 100.0 * float(acc[2]) / n}
         for c0 in range(0, int(self.Xval.shape[0]), chunk):
             x, y = self.Xval[c0:c0 + chunk], self.yval[c0:c0 + chunk]
             o = self.model.forward(x).float()
@@ -230,6 +262,126 @@ class DPTrainer:
         n = max(float(acc[3]), 1.0)
         return {"validation_loss": float(acc[0]) / n, "validation_mse": float(acc[1]) / n,
                 "validation_mape": 100.0 * float(acc[2]) / n}
+
+
+class HipDPEngine:
+    """The GPU side of a ``DPTrainer``: slabs, activation buffers, descriptor tables and the plan that
+    ``ops/csrc/dp.hip`` walks.  It shares the f32 master slab ``P`` with the trainer's ``FlatMLP`` (so ``state_dict``
+    keeps working) and takes over its bf16 shadow."""
+
+    EVAL_CHUNK = 16384
+
+    def __init__(self, tr: "DPTrainer"):
+        from ..ops import lib as L
+        from ..packed.permutation import half_bits
+        from ..train.losses import LOSS_CODES
+        self.tr, self.L, self.lib = tr, L, L.load()
+        dev, m, sp = tr.device, tr.model, tr.spec
+        self.device = dev
+        hidden = list(sp.hidden_sizes)
+        nl = len(hidden)
+        self.F = int(tr.X.shape[1])
+        b = tr.local_batch
+        rows_max = max(b, min(self.EVAL_CHUNK, max(int(tr.Xval.shape[0]), 1)))
+        self.eval_chunk = rows_max
+        n = _round_up(m.numel, 8)
+        self.numel = n
+        # wgrad splits per layer: enough workgroups to fill the chip when a layer has few 128x128 tiles
+        ks = []
+        dims_in = [self.F] + hidden[:-1]
+        for h, k in zip(hidden, dims_in):
+            tiles = ((h + 127) // 128) * ((k + 127) // 128)
+            ks.append(max(1, min(8, (b + 63) // 64, (512 + tiles - 1) // tiles)))
+        self.P, self.W = m.P, m.W
+        if n != m.numel:
+            raise ValueError("flat slab length must be a multiple of 8")      # FlatMLP rounds every tensor up to 8
+        self.G32 = torch.zeros(max(ks) * n, device=dev, dtype=torch.float32)
+        self.Gb = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+        self.M, self.V = torch.zeros_like(self.P), torch.zeros_like(self.P)
+        self.X0 = torch.zeros(b * self.F, device=dev, dtype=torch.bfloat16)
+        self.ybuf = torch.zeros(b, device=dev, dtype=torch.float32)
+        self.H = [torch.zeros(rows_max * h, device=dev, dtype=torch.bfloat16) for h in hidden]
+        self.dZ = [torch.zeros(b * h, device=dev, dtype=torch.bfloat16) for h in hidden]
+        self.loss_acc = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.metrics = torch.zeros(3, device=dev, dtype=torch.float64)
+        self.ids = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scratch = torch.zeros(int(self.lib.mt_head_scratch_floats(1, rows_max, max(hidden))), device=dev)
+        hw_off, hb_off = m.offsets[nl][0], m.offsets[nl][1]
+
+        def head_table(rows, y_ptr):
+            t = np.zeros(1, dtype=L.HEAD_DTYPE)
+            t[0] = (self.H[-1].data_ptr(), self.dZ[-1].data_ptr(), self.P.data_ptr() + hw_off * 4,
+                    self.P.data_ptr() + hb_off * 4, self.G32.data_ptr() + hw_off * 4, self.G32.data_ptr() + hb_off * 4, y_ptr,
+                    self.loss_acc.data_ptr(), self.metrics.data_ptr(), rows, hidden[-1], hidden[-1],
+                    LOSS_CODES[sp.loss_function], 1 << 30, 0)
+            return torch.from_numpy(t.view(np.uint8).reshape(-1).copy()).to(dev)
+
+        self._head_train = head_table(b, self.ybuf.data_ptr())
+        self._head_eval = head_table(rows_max, tr.yval.data_ptr())
+        hp = np.zeros(1, dtype=L.OPT_DTYPE)
+        hp[0] = (sp.learning_rate, sp.beta1, sp.beta2, sp.eps, sp.weight_decay, sp.momentum, 0.0, OPT_CODES[sp.optimizer],
+                 sp.warmup_steps, sp.total_steps, m.numel, 1 << 30, 0, 0, 0, 0)
+        self._opt = torch.from_numpy(hp.view(np.uint8).reshape(-1).copy()).to(dev)
+        # collectives: a direct RCCL communicator when there is more than one rank
+        self.rccl = None
+        # MITUNE_DP_FORCE_COLLECTIVES=1 issues the per-bucket all-reduces even with one rank (over a one-rank communicator
+        # they are copies): the event / stream choreography of the C++ driver can then be exercised on a single GPU
+        force = os.environ.get("MITUNE_DP_FORCE_COLLECTIVES") == "1"
+        if tr.comm.world_size > 1 or force:
+            from .rccl import RcclComm
+            self.rccl = RcclComm(tr.comm, dev)
+        self._events = [torch.cuda.Event() for _ in range(L.MT_MAX_LAYERS + 2)]
+        for e in self._events:
+            e.record()                        # creates the underlying HIP events
+        plan = L.DpPlan()
+        plan.n_hidden, plan.batch, plan.F = nl, b, self.F
+        plan.n_rows, plan.hb = int(tr.X.shape[0]), half_bits(int(tr.X.shape[0]))
+        plan.world = max(tr.comm.world_size, 2 if force else 1)
+        for l, (h, k) in enumerate(zip(hidden, ks)):
+            plan.widths[l], plan.ksplits[l] = h, k
+            plan.H[l], plan.dZ[l] = self.H[l].data_ptr(), self.dZ[l].data_ptr()
+        for l in range(nl + 1):
+            plan.w_off[l], plan.b_off[l] = m.offsets[l][0], m.offsets[l][1]
+            plan.bucket_lo[l], plan.bucket_hi[l] = m.bucket_bounds[l]
+        plan.numel = n
+        plan.X, plan.Y = tr.X.data_ptr(), tr.y.data_ptr()
+        plan.X0, plan.ybuf = self.X0.data_ptr(), self.ybuf.data_ptr()
+        plan.P, plan.W, plan.G32, plan.Gb = self.P.data_ptr(), self.W.data_ptr(), self.G32.data_ptr(), self.Gb.data_ptr()
+        plan.M, plan.V = self.M.data_ptr(), self.V.data_ptr()
+        plan.head, plan.opt, plan.ids = self._head_train.data_ptr(), self._opt.data_ptr(), self.ids.data_ptr()
+        plan.head_scratch = self.scratch.data_ptr()
+        if self.rccl is not None:
+            from .rccl import DTYPES, OPS
+            plan.all_reduce, plan.comm = self.rccl.fn_all_reduce, self.rccl.comm_handle
+            plan.nccl_bf16, plan.nccl_avg = DTYPES[torch.bfloat16], OPS["avg"]
+            plan.comm_stream = self.rccl.stream.cuda_stream
+        for l in range(nl + 1):
+            plan.ready[l] = self._events[l].cuda_event
+        plan.reduced = self._events[-1].cuda_event
+        self.plan = plan
+        self.plan_eval = L.DpPlan.from_buffer_copy(plan)
+        self.plan_eval.head = self._head_eval.data_ptr()
+        self.bytes_reduced = 0
+
+    def train_epoch(self, steps: int) -> torch.Tensor:
+        tr = self.tr
+        keys = np.asarray(round_keys(tr.seed, tr.trial_index * 1009 + tr.comm.rank, tr.epoch), dtype=np.uint32)
+        self.loss_acc.zero_()
+        stream = torch.cuda.current_stream(self.device)
+        if self.rccl is not None:
+            self.rccl.stream.wait_stream(stream)
+        self.L.check(self.lib.mt_dp_train_steps(C.byref(self.plan), keys.ctypes.data, 0, steps, tr.step, stream.cuda_stream),
+                     "mt_dp_train_steps")
+        if self.rccl is not None:
+            self.bytes_reduced += steps * tr.model.numel * 2
+        return self.loss_acc[0] / max(steps, 1)
+
+    def evaluate(self) -> torch.Tensor:
+        self.metrics.zero_()
+        n = int(self.tr.Xval.shape[0])
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.L.check(self.lib.mt_dp_eval(C.byref(self.plan_eval), self.tr.Xval.data_ptr(), n, self.eval_chunk, stream), "mt_dp_eval")
+        return self.metrics.clone()
 
 
 def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:

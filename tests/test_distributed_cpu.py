@@ -228,8 +228,9 @@ def _dp_data(n=512, f=12, seed=3):
     return X, y
 
 
-def test_dp_gradient_average_equals_full_batch_training():
-    """2 ranks x half the rows (batch = whole shard) == 1 rank x all rows (batch = everything)."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_dp_gradient_average_equals_full_batch_training(world):
+    """N ranks x 1/N of the rows (batch = whole shard) == 1 rank x all rows (batch = everything)."""
     from mitune.parallel.dp import DPTrainer, shard_rows
     X, y = _dp_data()
     cfg = {"hidden_sizes": [32, 16], "batch_size": 512, "learning_rate": 0.05, "optimizer": "sgd", "momentum": 0.9}
@@ -238,13 +239,15 @@ def test_dp_gradient_average_equals_full_batch_training():
         ref.train_epoch()
 
     def fn(comm):
-        lo, hi = shard_rows(512, comm.rank, 2)
+        lo, hi = shard_rows(512, comm.rank, world)
         t = DPTrainer(cfg, X[lo:hi], y[lo:hi], X[:64], y[:64], comm=comm, seed=4, trial_index=2)
         losses = [t.train_epoch() for _ in range(5)]
         return t.model.P.clone(), losses, t.evaluate(), t.reducer.bytes_reduced
 
-    (p0, l0, e0, b0), (p1, l1, e1, b1) = _run_ranks(2, fn)
-    assert torch.equal(p0, p1) and l0 == l1 and e0 == e1          # replicas never diverge
+    res = _run_ranks(world, fn)
+    (p0, l0, e0, b0), (p1, l1, e1, b1) = res[0], res[-1]
+    for p, l, e, _ in res[1:]:
+        assert torch.equal(p0, p) and l0 == l and e0 == e         # replicas never diverge
     assert torch.allclose(p0, ref.model.P, atol=1e-5)
     assert b0 == 5 * ref.model.numel * 4                            # every gradient element reduced once per step
     assert l0[-1] < l0[0]
@@ -372,3 +375,20 @@ def test_decisions_that_depend_on_time_use_the_replicated_clock():
     (r0, e0), (r1, e1) = _run_ranks(2, fn)
     assert r0 == r1 and e0 == e1 and e0 > 0
     assert len(r0) == 8 and all(it == 2 for _, it, _ in r0)                  # the budget was nowhere near spent
+
+
+def test_dp_ranks_with_uneven_shards_take_the_same_number_of_steps():
+    """513 rows over two ranks are 257 + 256: the step count comes from the smaller shard on BOTH ranks (a rank that
+    stepped once more would issue a bucket all-reduce nobody answers)."""
+    from mitune.parallel.dp import DPTrainer, shard_rows
+    X, y = _dp_data(n=513 + 64)
+    cfg = {"hidden_sizes": [16], "batch_size": 512, "learning_rate": 0.05, "optimizer": "sgd"}
+
+    def fn(comm):
+        lo, hi = shard_rows(513, comm.rank, 2)
+        t = DPTrainer(cfg, X[lo:hi], y[lo:hi], X[513:], y[513:], comm=comm, seed=1, trial_index=0)
+        t.train_epoch()
+        return hi - lo, t.steps_per_epoch, t.step
+
+    (n0, s0, k0), (n1, s1, k1) = _run_ranks(2, fn)
+    assert (n0, n1) == (257, 256) and s0 == s1 == 1 and k0 == k1 == 1

@@ -328,3 +328,88 @@ def test_rccl_backend_one_rank_collectives():
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
     assert rec["backend"] == "nccl" and rec["device"] == "cuda:0"
     assert rec["gather_ok"] and rec["bcast_ok"] and rec["max"] == 1.25 and rec["avg"] == 1.0 and rec["obj"] == {"epoch": 3}
+
+
+# ----------------------------------------------------------------------------------------- data-parallel trial on the GPU
+def test_dp_engine_step_driver_tracks_the_f32_reference():
+    """The C++ step driver of a data-parallel trial (own bf16 GEMMs, fused head/loss, bf16 gradient buckets, fused
+    optimiser; one rank, so no collective) against the same trial trained in f32 by autograd on the CPU."""
+    from mitune.parallel.dp import DPTrainer
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(4096, 32, generator=g)
+    y = torch.tanh(X[:, 0]) + 0.5 * X[:, 1] + 0.05 * torch.randn(4096, generator=g)
+    cfg = {"hidden_sizes": [256, 128, 64], "batch_size": 512, "learning_rate": 2e-3, "optimizer": "adamw", "weight_decay": 1e-3}
+    ref = DPTrainer(cfg, X[:3584], y[:3584], X[3584:], y[3584:], seed=4, trial_index=2)
+    gpu = DPTrainer(cfg, X[:3584].cuda(), y[:3584].cuda(), X[3584:].cuda(), y[3584:].cuda(), seed=4, trial_index=2)
+    assert gpu.engine is not None and ref.engine is None
+    for k, v in ref.model.state_dict().items():
+        assert torch.equal(v, gpu.model.state_dict()[k])            # same initial weights
+    for epoch in range(3):
+        lr, lg = ref.train_epoch(), gpu.train_epoch()
+        mr, mg = ref.evaluate(), gpu.evaluate()
+        assert lg == pytest.approx(lr, rel=0.05, abs=0.01), (epoch, lr, lg)
+        assert mg["validation_mse"] == pytest.approx(mr["validation_mse"], rel=0.08, abs=0.01), (epoch, mr, mg)
+    assert gpu.step == ref.step == 21 and mg["validation_mse"] < 0.5 * float(y.var())
+    # the bf16 shadow the GEMMs read is the rounded master
+    assert torch.equal(gpu.model.W, gpu.model.P.to(torch.bfloat16))
+    sd = gpu.model.state_dict()
+    assert sd["layers.0.weight"].shape == (256, 32) and not torch.equal(sd["layers.0.weight"], ref.model.state_dict()["layers.0.weight"])
+
+
+def test_dp_step_driver_with_collectives_on_the_communication_stream(monkeypatch):
+    """Same trial with the per-bucket all-reduces forced on (a one-rank RCCL communicator, where they are copies): the
+    driver's event / stream hand-offs between compute and communication stream must leave every number unchanged."""
+    from mitune.parallel.dp import DPTrainer
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(3072, 64, generator=g).cuda()
+    y = (torch.tanh(X[:, 0]) - 0.3 * X[:, 5]).cuda()
+    cfg = {"hidden_sizes": [512, 256], "batch_size": 256, "learning_rate": 1e-3, "optimizer": "adam"}
+    out = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("MITUNE_DP_FORCE_COLLECTIVES", force)
+        t = DPTrainer(cfg, X[:2560], y[:2560], X[2560:], y[2560:], seed=1, trial_index=0)
+        assert (t.engine.rccl is not None) == (force == "1")
+        losses = [t.train_epoch() for _ in range(2)]
+        out.append((losses, t.evaluate(), t.model.P.clone(), t.reducer.bytes_reduced))
+        if t.engine.rccl is not None:
+            t.engine.rccl.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and torch.equal(out[0][2], out[1][2])
+    assert out[0][3] == 0 and out[1][3] == 2 * 10 * out[1][2].numel() * 2          # bf16 bytes, every step, every element
+
+
+_RCCL_DIRECT = r"""
+import os, sys, json
+import torch
+sys.path.insert(0, os.getcwd())
+from mitune.parallel.comm import LocalComm
+from mitune.parallel.rccl import RcclComm
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+rc = RcclComm(LocalComm(dev), dev)
+out = {"lib": os.path.basename(os.path.dirname(os.path.dirname(rc.lib._name))) + "/" + os.path.basename(rc.lib._name)}
+t = torch.arange(4096, device=dev, dtype=torch.float32).to(torch.bfloat16)
+ref = t.clone()
+rc.stream.wait_stream(torch.cuda.current_stream())
+rc.all_reduce(t, "avg", stream=rc.stream)
+rc.all_reduce_rs_ag(t, "sum", stream=rc.stream)
+torch.cuda.current_stream().wait_stream(rc.stream)
+torch.cuda.synchronize()
+out["same"] = bool(torch.equal(t, ref))
+out["fn"] = bool(rc.fn_all_reduce) and bool(rc.comm_handle)
+rc.close()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_direct_rccl_communicator_one_rank():
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / reduce-scatter + all-gather through parallel/rccl.py on the RCCL
+    library PyTorch itself has loaded (a one-rank communicator: the box has one GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _RCCL_DIRECT], cwd=root, capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    assert rec["same"] and rec["fn"] and rec["lib"].endswith("librccl.so")

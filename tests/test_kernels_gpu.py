@@ -487,3 +487,52 @@ def test_head_loss_f32_activations(lib):
         torch.testing.assert_close(dH[:, :W], (h.grad * (h > 0)).detach(), rtol=1e-5, atol=1e-7)
         d = (out - y).detach()
         torch.testing.assert_close(met[1].float(), (d * d).sum(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_head_loss_wide_layers(lib, f32):
+    """Heads wider than 2048 columns (data-parallel trials) take the two-pass form of the head/loss kernels."""
+    if NSTAGE != 2:
+        pytest.skip("not a GEMM test")
+    L, so = lib
+    g = torch.Generator(device="cuda").manual_seed(24)
+    cfgs = [(200, 8192), (64, 4096)]
+    dt = torch.float32 if f32 else torch.bfloat16
+    slots = np.zeros(len(cfgs), dtype=L.HEAD_DTYPE)
+    keep = []
+    for s, (B, W) in enumerate(cfgs):
+        H = torch.randn(B, W, device="cuda", generator=g).relu().to(dt)
+        dH = torch.zeros(B, W, device="cuda", dtype=dt)
+        w = torch.randn(W, device="cuda", generator=g) * 0.02; b = torch.randn(1, device="cuda", generator=g)
+        gw = torch.zeros(W, device="cuda"); gb = torch.zeros(1, device="cuda")
+        y = torch.randn(B, device="cuda", generator=g)
+        acc = torch.zeros(1, device="cuda"); met = torch.zeros(3, device="cuda", dtype=torch.float64)
+        slots[s] = (H.data_ptr(), dH.data_ptr(), w.data_ptr(), b.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                    y.data_ptr(), acc.data_ptr(), met.data_ptr(), B, W, W, 0, 1, 0)
+        keep.append((H, dH, w, b, gw, gb, y, acc, met))
+    st = _up(slots)
+    ids = torch.arange(len(cfgs), dtype=torch.int32, device="cuda")
+    scratch = torch.zeros(int(so.mt_head_scratch_floats(len(cfgs), 256, 8192)), device="cuda")
+    if f32:
+        L.check(so.mt_head_loss_f32_launch(st.data_ptr(), ids.data_ptr(), len(cfgs), 256, 8192, 0, scratch.data_ptr(), 1,
+                                           _stream()), "head_loss_f32")
+        L.check(so.mt_head_eval_f32_launch(st.data_ptr(), ids.data_ptr(), len(cfgs), 8192, 0, 0, 256, scratch.data_ptr(),
+                                           _stream()), "head_eval_f32")
+    else:
+        L.check(so.mt_head_loss_launch(st.data_ptr(), ids.data_ptr(), len(cfgs), 256, 8192, 0, scratch.data_ptr(), _stream()),
+                "head_loss")
+        L.check(so.mt_head_eval_launch(st.data_ptr(), ids.data_ptr(), len(cfgs), 8192, 0, 0, 256, scratch.data_ptr(),
+                                       _stream()), "head_eval")
+    torch.cuda.synchronize()
+    for (B, W), (H, dH, w, b, gw, gb, y, acc, met) in zip(cfgs, keep):
+        h = H.float().requires_grad_(True)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        out = h @ wr + br
+        l = ((out - y) ** 2).mean()
+        l.backward()
+        torch.testing.assert_close(acc, torch.tensor([l.item()], device="cuda"), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(gw, wr.grad, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(gb, br.grad, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(dH.float(), (h.grad * (h > 0)).detach(), rtol=1e-2, atol=1e-6)
+        d = (out - y).detach()
+        torch.testing.assert_close(met[1].float(), (d * d).sum(), rtol=1e-4, atol=1e-3)
