@@ -256,6 +256,76 @@ extern "C" int mt_mlp_eval(const MtMlpPlan* p, int n_val_rows, int chunk_rows, h
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The per-round record table, produced on the device.  After a round (one training epoch + one validation sweep of every
+// resident trial) the scheduler needs, per trial, {trial index, epoch, mean training loss, validation loss, validation
+// MSE, validation MAPE}, and every rank needs every rank's rows.  mt_metric_table_kernel writes exactly the buffer that
+// is all-gathered -- [capacity + 1][6] f64, empty slots as rows of -1, the last row {-2, seconds of the round, live
+// trials, seconds of its training part, 0, 0} -- from the loss accumulators, the f64 metric sums and a small per-slot
+// table of host-known numbers, so nothing passes through the host between the last validation kernel and the
+// collective.  The round's duration comes from the GPU's constant-rate clock (100 MHz): mt_stamp_kernel stores it at
+// the start of the round and after the training part.
+struct MtTableMeta {
+  double trial_index;
+  double epoch;          // the epoch number this round completes
+  int32_t steps;         // optimiser steps of the round (the training loss accumulator holds their sum)
+  int32_t live;          // 0: empty slot
+};
+
+__global__ void mt_stamp_kernel(unsigned long long* slot) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *slot = wall_clock64();
+}
+
+extern "C" int mt_stamp_launch(void* slot, hipStream_t stream) {
+  hipLaunchKernelGGL(mt_stamp_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<unsigned long long*>(slot));
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void mt_metric_table_kernel(const MtTableMeta* __restrict__ meta,
+                                                              const float* __restrict__ loss_acc,
+                                                              const double* __restrict__ metrics, int capacity, int n_val,
+                                                              int n_live, const unsigned long long* __restrict__ stamps,
+                                                              double* __restrict__ table) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > capacity) return;
+  double* row = table + (size_t)i * 6;
+  if (i == capacity) {
+    const unsigned long long now = wall_clock64();
+    row[0] = -2.0;
+    row[1] = (double)(now - stamps[0]) * 1e-8;               // 100 MHz ticks -> seconds
+    row[2] = (double)n_live;
+    row[3] = (double)(stamps[1] - stamps[0]) * 1e-8;
+    row[4] = 0.0;
+    row[5] = 0.0;
+    return;
+  }
+  const MtTableMeta m = meta[i];
+  if (!m.live) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) row[k] = -1.0;
+    return;
+  }
+  const double nv = (double)n_val;
+  row[0] = m.trial_index;
+  row[1] = m.epoch;
+  // the same f64 quotients the host path computes from the same accumulators: the two paths agree bit for bit
+  row[2] = (double)loss_acc[i] / (double)(m.steps > 0 ? m.steps : 1);
+  row[3] = metrics[i * 3 + 0] / nv;
+  row[4] = metrics[i * 3 + 1] / nv;
+  row[5] = 100.0 * metrics[i * 3 + 2] / nv;
+}
+
+extern "C" int mt_metric_table_launch(const void* meta, const float* loss_acc, const double* metrics, int capacity, int n_val,
+                                      int n_live, const void* stamps, double* table, hipStream_t stream) {
+  if (capacity <= 0 || n_val <= 0) return -2;
+  hipLaunchKernelGGL(mt_metric_table_kernel, dim3((capacity + 1 + 255) / 256), dim3(256), 0, stream,
+                     reinterpret_cast<const MtTableMeta*>(meta), loss_acc, metrics, capacity, n_val, n_live,
+                     reinterpret_cast<const unsigned long long*>(stamps), table);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mt_table_meta_sizeof() { return (int)sizeof(MtTableMeta); }
+
 // Digest of the source files this library was built from (ops/build.py passes it as -DMT_SRC_DIGEST).
 #ifndef MT_SRC_DIGEST
 #define MT_SRC_DIGEST ""

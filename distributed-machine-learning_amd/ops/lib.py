@@ -112,6 +112,8 @@ OPT_DTYPE = np.dtype([("lr", "<f4"), ("beta1", "<f4"), ("beta2", "<f4"), ("eps",
                       ("total", "<i4"), ("n_params", "<i4"), ("active_steps", "<i4"), ("step_base", "<i4"),
                       ("first_end", "<i4"), ("first_splits", "<i4"), ("pad", "<i4")], align=True)
 
+TABLE_META_DTYPE = np.dtype([("trial_index", "<f8"), ("epoch", "<f8"), ("steps", "<i4"), ("live", "<i4")], align=True)
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -215,6 +217,11 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_gemm_single_launch.argtypes = [C.c_int] + [c_void_p] * 4 + [C.c_int] * 8 + [c_void_p]
     lib.mt_gemm_f32_single_launch.argtypes = [C.c_int] + [c_void_p] * 5 + [C.c_int] * 7 + [c_void_p]
     lib.mt_gemm_single_launch.restype = lib.mt_gemm_f32_single_launch.restype = C.c_int
+    if lib.mt_table_meta_sizeof() != TABLE_META_DTYPE.itemsize:
+        raise KernelLibraryError("MtTableMeta layout mismatch between lib.py and the library")
+    lib.mt_stamp_launch.argtypes = [c_void_p, c_void_p]
+    lib.mt_metric_table_launch.argtypes = [c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, c_void_p, c_void_p, c_void_p]
+    lib.mt_stamp_launch.restype = lib.mt_metric_table_launch.restype = C.c_int
     if lib.mt_dp_plan_sizeof() != C.sizeof(DpPlan):
         raise KernelLibraryError(f"MtDpPlan is {lib.mt_dp_plan_sizeof()} bytes in the library, {C.sizeof(DpPlan)} in lib.py")
     lib.mt_dp_train_steps.argtypes = [C.POINTER(DpPlan), c_void_p, C.c_int, C.c_int, C.c_int, c_void_p]

@@ -211,6 +211,11 @@ class HipPackEngine(PackEngine):
         self._chains: List[_Chain] = []
         self.n_streams_override = int(os.environ.get("MITUNE_STREAMS", kw.get("streams", 0)) or 0)
         self._train_loss: Dict[int, float] = {}
+        self._loss_pending = False          # the epoch's loss accumulators have not been read by the host yet
+        self._round_steps: Dict[int, int] = {}
+        # the round's record table as the ranks all-gather it, written by one kernel (ops/csrc/runtime.hip)
+        self._table = torch.zeros(T + 1, 6, device=dev, dtype=torch.float64)
+        self._stamps = torch.zeros(2, device=dev, dtype=torch.int64)      # GPU clock at round start / after training
 
     # ------------------------------------------------------------------ slot management
     def occupied(self) -> List[int]:
@@ -352,6 +357,24 @@ class HipPackEngine(PackEngine):
         self._refresh_shadow(slot)
         self.loss_acc[slot] = 0
         self.slots[slot] = s
+        self._dirty = True
+
+    def adopt_raw(self, slot: int, raw: torch.Tensor, config: Dict) -> None:
+        """PBT exploit across GPUs: the occupied ``slot`` takes over the parameters, both optimiser moments and the step
+        count of a donor trial's ``export_raw`` slab (same architecture, possibly other hyper-parameters); it keeps its
+        own trial index and epoch count.  Device to device: nothing is unpacked on the host."""
+        s, n = self.slots[slot], self.stride
+        if raw.numel() != self.raw_numel:
+            raise ValueError(f"raw slot state of {raw.numel()} words, this engine's slots take {self.raw_numel}")
+        spec = MLPTrialSpec.from_config(config, self.F)
+        if spec.hidden_sizes != s.spec.hidden_sizes:
+            raise ValueError("an exploit cannot change the architecture")
+        raw = raw.to(self.device)
+        for i, slab in enumerate((self.P, self.M, self.V)):
+            self._region(slab, slot).copy_(raw[i * n:(i + 1) * n])
+        self._refresh_shadow(slot)
+        _, step, _, _ = raw[3 * n:].view(torch.int32).tolist()
+        s.spec, s.layout, s.config, s.step = spec, SlotLayout(spec, self.Fpad), dict(config), int(step)
         self._dirty = True
 
     def import_state(self, slot, state, config):
@@ -619,16 +642,29 @@ class HipPackEngine(PackEngine):
                                                        ch.steps - nb * GRAPH_STEPS, st.cuda_stream),
                         "mt_mlp_train_steps_at")
                 main.wait_stream(st)
-        losses = self.loss_acc.to("cpu")           # the epoch's only host synchronisation
+        L.check(self.lib.mt_stamp_launch(self._stamps[1:].data_ptr(), main.cuda_stream), "mt_stamp_launch")
+        self._round_steps = {}
         for slot, s in self.slots.items():
             n = self.n_train // min(s.spec.batch_size, self.n_train)
-            self._train_loss[slot] = float(losses[slot]) / max(n, 1)
+            self._round_steps[slot] = n
             s.step += n
             s.epoch += 1
+        self._loss_pending = True                   # nothing was read back: the host does not wait for the epoch here
 
-    def evaluate(self):
-        if not self.slots:
-            return {}
+    def begin_round(self) -> None:
+        """Stamp the GPU clock: the start of a scheduling round (before the epoch is enqueued)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.mt_stamp_launch(self._stamps.data_ptr(), stream), "mt_stamp_launch")
+
+    def _fetch_losses(self) -> None:
+        if not self._loss_pending:
+            return
+        losses = self.loss_acc.to("cpu")            # host synchronisation
+        for slot, n in self._round_steps.items():
+            self._train_loss[slot] = float(losses[slot]) / max(n, 1)
+        self._loss_pending = False
+
+    def _enqueue_eval(self) -> None:
         if self._dirty or "eval_plan" not in self._tables:
             self._build_chains()
             self._tables["eval_plan"] = self._build_plan(eval_mode=True)
@@ -637,6 +673,31 @@ class HipPackEngine(PackEngine):
         self.metrics.zero_()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.mt_mlp_eval(C.byref(plan), self.n_val, self.val_chunk, stream), "mt_mlp_eval")
+
+    def device_table(self) -> torch.Tensor:
+        """Validate every resident trial and return the round's record table ``[capacity + 1, 6]`` (f64) ON THE DEVICE,
+        without waiting for it: rows ``{trial index, epoch, train loss, validation loss, validation MSE, validation
+        MAPE}`` per slot (-1 in empty slots), last row ``{-2, seconds since begin_round, live trials, seconds of the
+        training part, 0, 0}`` from the GPU clock.  This is the buffer the ranks all-gather."""
+        T = self.capacity
+        meta = np.zeros(T, dtype=L.TABLE_META_DTYPE)
+        for slot, s in self.slots.items():
+            meta[slot] = (float(s.trial_index), float(s.epoch), self._round_steps.get(slot, 1), 1)
+        if self.slots:
+            self._enqueue_eval()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.mt_metric_table_launch(self._upload("table_meta", meta), self.loss_acc.data_ptr(),
+                                                self.metrics.data_ptr(), T, max(self.n_val, 1), len(self.slots),
+                                                self._stamps.data_ptr(), self._table.data_ptr(), stream),
+                "mt_metric_table_launch")
+        self._loss_pending = False        # whoever reads the table has the losses
+        return self._table
+
+    def evaluate(self):
+        if not self.slots:
+            return {}
+        self._fetch_losses()
+        self._enqueue_eval()
         m = self.metrics.to("cpu")
         out: Dict[int, Dict[str, float]] = {}
         for slot in self.occupied():

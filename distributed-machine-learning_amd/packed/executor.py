@@ -153,40 +153,59 @@ class PackedExecutor(Executor):
         if self.world > 1 and self.t.rebalance_gap > 0:
             self._rebalance()      # the runner has filled what it could with pending trials; even out what is left
         t0 = time.time()
-        begin = getattr(self.engine, "train_epoch_begin", None)
-        if begin is not None and self.world == 1 and self.runner is not None and hasattr(self.engine, "prepare"):
-            begin()                                   # the GPU trains ...
-            self._prefetch(t0)                        # ... while the host builds and captures the trials that come next
-            self.engine.train_epoch_end()
-        else:
+        device_table = getattr(self.engine, "device_table", None)
+        if device_table is not None:
+            # The engine writes the record table on the device (metrics, the round's duration from the GPU clock) and the
+            # ranks all-gather that very buffer: between the last validation kernel and the collective nothing goes
+            # through the host; the one synchronisation of the round is the read-back of the gathered table.
+            self.engine.begin_round()
             self.engine.train_epoch()
-        t1 = time.time()
-        local = self.engine.evaluate()
-        t2 = time.time()
-        mine = {slot: tid for tid, (r, slot) in self._place.items() if r == self.rank}
-        rows_local = [[-1.0] * _REC for _ in range(self.capacity)]
-        for slot, m in local.items():
-            tr = self._live[mine[slot]]
-            rows_local[slot] = [float(tr.index), float(tr.training_iteration + 1), m["train_loss"], m["validation_loss"],
-                                m["validation_mse"], m["validation_mape"]]
-        # one more row: this rank's time for the round and how many trials it spent it on; gathered with the metrics, so
-        # that every rank knows every rank's cost per trial and all of them weigh a move the same way
-        rows_local.append([-2.0, t2 - t0, float(len(local)), 0.0, 0.0, 0.0])
-        table = torch.tensor(rows_local, dtype=torch.float64)         # one conversion, not one per slot
+            table = device_table()
+            if self.comm.device.type != "cuda":       # a CPU-side collective (gloo, in-process ranks): one copy down
+                table = table.cpu()
+            t1 = t2 = time.time()
+            n_local = len(self.engine.occupied())
+        else:
+            begin = getattr(self.engine, "train_epoch_begin", None)
+            if begin is not None and self.world == 1 and self.runner is not None and hasattr(self.engine, "prepare"):
+                begin()                                   # the GPU trains ...
+                self._prefetch(t0)                        # ... while the host builds and captures the trials that come next
+                self.engine.train_epoch_end()
+            else:
+                self.engine.train_epoch()
+            t1 = time.time()
+            local = self.engine.evaluate()
+            t2 = time.time()
+            n_local = len(local)
+            mine = {slot: tid for tid, (r, slot) in self._place.items() if r == self.rank}
+            rows_local = [[-1.0] * _REC for _ in range(self.capacity)]
+            for slot, m in local.items():
+                tr = self._live[mine[slot]]
+                rows_local[slot] = [float(tr.index), float(tr.training_iteration + 1), m["train_loss"], m["validation_loss"],
+                                    m["validation_mse"], m["validation_mape"]]
+            # one more row: this rank's time for the round and how many trials it spent it on; gathered with the metrics,
+            # so that every rank knows every rank's cost per trial and all of them weigh a move the same way
+            rows_local.append([-2.0, t2 - t0, float(len(local)), t1 - t0, 0.0, 0.0])
+            table = torch.tensor(rows_local, dtype=torch.float64)         # one conversion, not one per slot
         try:
             gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
+            gathered = gathered.cpu()
         except Exception as e:          # noqa: BLE001 - RCCL / gloo raise backend-specific types
             raise RankLostError(f"rank {self.rank} of {self.world}: metric exchange after epoch {self.stats['epochs'] + 1} "
                                 f"failed ({type(e).__name__}: {e})") from e
         t3 = time.time()
+        if device_table is not None:                  # the device's own clock split the round into training and validation
+            mine_row = gathered[self.rank, -1]
+            total, train = float(mine_row[1]), float(mine_row[3])
+            t1, t2 = t0 + train, t0 + total
         self.stats["epochs"] += 1
-        self.stats["slot_epochs"] += len(local)
+        self.stats["slot_epochs"] += n_local
         self.stats["train_s"] += t1 - t0
         self.stats["prepared_ahead"] = getattr(self.engine, "prepared_total", 0)
         if hasattr(self.engine, "stream_window"):
             self.stats["stream_window"] = str(self.engine.stream_window)
         self.stats["eval_s"] += t2 - t1
-        self.stats["comm_s"] += t3 - t2
+        self.stats["comm_s"] += max(0.0, t3 - t2)
 
         by_index = {tr.index: tr for tr in self._live.values()}
         # numpy, not torch: a masked select + argsort of a few hundred rows costs tens of milliseconds per call through
@@ -331,7 +350,16 @@ class PackedExecutor(Executor):
             if drank == self.rank:
                 self.engine.clone(dslot, rslot, tr.config)
             return
-        # donor and receiver live on different GPUs: ship the flattened state point-to-point
+        # donor and receiver live on different GPUs
+        if hasattr(self.engine, "adopt_raw"):
+            # the slot's device slab (parameters + both moments + counters) goes point-to-point: HBM -> xGMI -> HBM
+            if self.rank == drank:
+                self.comm.send(self.engine.export_raw(dslot), rrank)
+            elif self.rank == rrank:
+                buf = torch.empty(self.engine.raw_numel, dtype=torch.float32, device=self.device)
+                self.engine.adopt_raw(rslot, self.comm.recv(buf, drank), tr.config)
+            return
+        # other engines ship the flattened state dict point-to-point
         from ..parallel.exchange import recv_state, send_state
         if self.rank == drank:
             send_state(self.comm, self.engine.export(dslot), rrank)

@@ -413,3 +413,61 @@ def test_direct_rccl_communicator_one_rank():
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
     assert rec["same"] and rec["fn"] and rec["lib"].endswith("librccl.so")
+
+
+def test_device_record_table_matches_the_host_path():
+    """The round's record table written on the device (what the ranks all-gather) carries exactly the numbers of the
+    host path (train_epoch + evaluate), bit for bit, plus a time row from the GPU clock."""
+    from mitune.packed import PackedTrainable
+    from mitune.packed.engine_hip import HipPackEngine
+    train, val = _data(seed=9)
+    for dtype in ("bf16", "f32"):
+        tr = PackedTrainable(train=train, val=val, max_epochs=2, val_chunk=512, dtype=dtype,
+                             model_kwargs={"max_width": 256, "max_layers": 3, "max_batch": 512})
+        a = HipPackEngine(tr, device="cuda", capacity=5, seed=3)
+        b = HipPackEngine(tr, device="cuda", capacity=5, seed=3)
+        for eng in (a, b):
+            eng.load(1, 11, CONFIGS[0])
+            eng.load(3, 12, CONFIGS[1])
+        for epoch in (1, 2):
+            a.train_epoch()
+            host = a.evaluate()
+            b.begin_round()
+            b.train_epoch()
+            tab = b.device_table()
+            assert tab.device.type == "cuda" and tab.shape == (6, 6) and tab.dtype == torch.float64
+            t = tab.cpu()
+            for slot, idx in ((1, 11), (3, 12)):
+                m = host[slot]
+                assert t[slot].tolist() == [float(idx), float(epoch), m["train_loss"], m["validation_loss"], m["validation_mse"],
+                                            m["validation_mape"]]
+            for slot in (0, 2, 4):
+                assert t[slot].tolist() == [-1.0] * 6
+            assert t[5, 0] == -2.0 and t[5, 2] == 2.0 and 0.0 < t[5, 3] <= t[5, 1] < 5.0
+
+
+def test_cross_rank_exploit_moves_device_slabs():
+    """PBT exploit between two engines (= two GPUs): export_raw on the donor, adopt_raw on the receiver, no host copy of
+    the weights; the receiver then continues exactly like an in-pack clone of the donor would."""
+    from mitune.packed import PackedTrainable
+    from mitune.packed.engine_hip import HipPackEngine
+    train, val = _data(seed=10)
+    tr = PackedTrainable(train=train, val=val, max_epochs=3, val_chunk=512,
+                         model_kwargs={"max_width": 256, "max_layers": 3, "max_batch": 512})
+    donor_cfg = dict(CONFIGS[1])
+    new_cfg = dict(CONFIGS[1], learning_rate=5e-4)
+    a = HipPackEngine(tr, device="cuda", capacity=4, seed=1)       # "rank 0": donor 20 and, for reference, an in-pack clone
+    b = HipPackEngine(tr, device="cuda", capacity=4, seed=1)       # "rank 1": receiver 21
+    a.load(0, 20, donor_cfg); a.load(1, 21, dict(CONFIGS[1], learning_rate=3e-3))
+    b.load(2, 21, dict(CONFIGS[1], learning_rate=3e-3))
+    a.train_epoch(); b.train_epoch()
+    raw = a.export_raw(0)
+    b.adopt_raw(2, raw, new_cfg)
+    a.clone(0, 1, new_cfg)
+    a.train_epoch(); b.train_epoch()
+    ea, eb = a.export(1), b.export(2)
+    for k, v in ea["model"].items():
+        assert torch.equal(v, eb["model"][k]), k
+    assert ea["step"] == eb["step"] and eb["trial_index"] == 21
+    with pytest.raises(ValueError):
+        b.adopt_raw(2, raw, dict(CONFIGS[0]))                      # another architecture
