@@ -46,13 +46,13 @@ class Problem:
         tl = []
         for t in range(T):
             if mode == 0:
-                groups[t] = (x[t].data_ptr(), w[t].data_ptr(), y[t].data_ptr(), bias[t].data_ptr(), 0, B, W, W, W, W, W, 0, 1)
+                groups[t] = L.gemm_group(x[t].data_ptr(), w[t].data_ptr(), y[t].data_ptr(), bias[t].data_ptr(), 0, B, W, W, W, W, W, 0, 1)
                 tl.append((t, -(-B // edge), -(-W // edge), W // 64))
             elif mode == 1:
-                groups[t] = (dy[t].data_ptr(), w[t].data_ptr(), y[t].data_ptr(), x[t].data_ptr(), 0, B, W, W, W, W, W, W, 1)
+                groups[t] = L.gemm_group(dy[t].data_ptr(), w[t].data_ptr(), y[t].data_ptr(), x[t].data_ptr(), 0, B, W, W, W, W, W, W, 1)
                 tl.append((t, -(-B // edge), -(-W // edge), W // 64))
             else:
-                groups[t] = (dy[t].data_ptr(), x[t].data_ptr(), dw[0, t].data_ptr(), 0, db[0, t].data_ptr(), W, W, B, W, W, W, 0, 1)
+                groups[t] = L.gemm_group(dy[t].data_ptr(), x[t].data_ptr(), dw[0, t].data_ptr(), 0, db[0, t].data_ptr(), W, W, B, W, W, W, 0, 1)
                 tl.append((t, -(-W // edge), -(-W // edge), B // 64))
         tiles = balanced_tiles(tl, ksplits if mode == 2 else 1)
         self.keep = (x, w, dy, y, bias, arena)

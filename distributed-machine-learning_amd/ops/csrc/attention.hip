@@ -118,22 +118,17 @@ __device__ __forceinline__ void scores_T(f32x4 (&acc)[NKB], const uint8_t* ldsK,
 // the halves of a fused QK projection and a [B, S, d_model] value / output tensor are used in place; H = 1 with
 // ld = d is the plain contiguous [BH, S, d] form.
 template <int NKB, int PCHQ, bool F32>
-__global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const void* __restrict__ Q_, const void* __restrict__ K_,
-                                                                 const void* __restrict__ V_,
-                                                                 const uint8_t* __restrict__ keep,
-                                                                 void* __restrict__ O_, float* __restrict__ stat,
-                                                                 int S, int dk, int dv, float scale, float keep_scale,
-                                                                 int kind, int H, long ldq, long ldv, long ldo,
-                                                                 const int64_t* __restrict__ seed, uint32_t thresh) {
-  // attention dropout: a stored [BH, S, S] byte mask if `keep` is given, else drawn here from the device seed
-  const bool masked = keep != nullptr || seed != nullptr;
-  uint32_t seed_lo = 0u, seed_hi = 0u;
-  if (seed != nullptr) { const uint64_t sv = (uint64_t)seed[0]; seed_lo = (uint32_t)sv; seed_hi = (uint32_t)(sv >> 32); }
+__device__ __forceinline__ void attn_fwd_body(uint8_t* lds, const void* __restrict__ Q_, const void* __restrict__ K_,
+                                              const void* __restrict__ V_, const uint8_t* __restrict__ keep,
+                                              void* __restrict__ O_, float* __restrict__ stat, int S, int dk, int dv,
+                                              float scale, float keep_scale, int kind, int H, long ldq, long ldv, long ldo,
+                                              bool seeded, uint32_t seed_lo, uint32_t seed_hi, uint32_t thresh, int bh) {
+  // attention dropout: a stored [BH, S, S] byte mask if `keep` is given, else drawn here from the seed words
+  const bool masked = keep != nullptr || seeded;
   constexpr int SP = NKB * 16;
   constexpr int IMG = SP * PCHQ * 16;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * IMG];
   uint8_t *ldsQ = lds, *ldsK = lds + IMG, *ldsV = lds + 2 * IMG;
-  const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, fr = lane & 15;
   constexpr int ES = F32 ? 4 : 2;       // bytes per operand element
   const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
@@ -231,27 +226,37 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const void* __r
   }
 }
 
-template <int NKB, int PCHQ, bool F32>     // dQ, dK, dV are f32 and laid out like Q, K, V (same row strides)
-__global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const void* __restrict__ Q_, const void* __restrict__ K_,
-                                                                 const void* __restrict__ V_, const void* __restrict__ dO_,
+template <int NKB, int PCHQ, bool F32>
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const void* __restrict__ Q_, const void* __restrict__ K_,
+                                                                 const void* __restrict__ V_,
                                                                  const uint8_t* __restrict__ keep,
-                                                                 const float* __restrict__ stat, float* __restrict__ dQ,
-                                                                 float* __restrict__ dK, float* __restrict__ dV, int S,
-                                                                 int dk, int dv, float scale, float keep_scale,
+                                                                 void* __restrict__ O_, float* __restrict__ stat,
+                                                                 int S, int dk, int dv, float scale, float keep_scale,
                                                                  int kind, int H, long ldq, long ldv, long ldo,
                                                                  const int64_t* __restrict__ seed, uint32_t thresh) {
-  // attention dropout: a stored [BH, S, S] byte mask if `keep` is given, else drawn here from the device seed
-  const bool masked = keep != nullptr || seed != nullptr;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * NKB * 16 * PCHQ * 16];
   uint32_t seed_lo = 0u, seed_hi = 0u;
   if (seed != nullptr) { const uint64_t sv = (uint64_t)seed[0]; seed_lo = (uint32_t)sv; seed_hi = (uint32_t)(sv >> 32); }
+  attn_fwd_body<NKB, PCHQ, F32>(lds, Q_, K_, V_, keep, O_, stat, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo,
+                                seed != nullptr, seed_lo, seed_hi, thresh, blockIdx.x);
+}
+
+template <int NKB, int PCHQ, bool F32>     // dQ, dK, dV are f32 and laid out like Q, K, V (same row strides)
+__device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restrict__ Q_, const void* __restrict__ K_,
+                                              const void* __restrict__ V_, const void* __restrict__ dO_,
+                                              const uint8_t* __restrict__ keep, const float* __restrict__ stat,
+                                              float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, int S,
+                                              int dk, int dv, float scale, float keep_scale, int kind, int H, long ldq,
+                                              long ldv, long ldo, bool seeded, uint32_t seed_lo, uint32_t seed_hi,
+                                              uint32_t thresh, int bh) {
+  const bool masked = keep != nullptr || seeded;
   constexpr int SP = NKB * 16;
   constexpr int PCH = (SP <= 64) ? 8 : 16;        // chunks per row of the [key][query] images
   constexpr int PT_BYTES = SP * PCH * 16;
   constexpr int IMG = SP * PCHQ * 16;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * IMG + 2 * PT_BYTES];
   uint8_t *ldsQ = lds, *ldsK = lds + IMG, *ldsV = lds + 2 * IMG, *ldsdO = lds + 3 * IMG;
   uint8_t *ldsPT = lds + 4 * IMG, *ldsST = ldsPT + PT_BYTES;
-  const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, fr = lane & 15;
   constexpr int ES = F32 ? 4 : 2;
   const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
@@ -376,6 +381,86 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const void* __r
   }
 }
 
+template <int NKB, int PCHQ>
+constexpr int at_bwd_lds_bytes() {
+  constexpr int SP = NKB * 16;
+  return 4 * SP * PCHQ * 16 + 2 * SP * ((SP <= 64) ? 8 : 16) * 16;
+}
+
+template <int NKB, int PCHQ, bool F32>
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const void* __restrict__ Q_, const void* __restrict__ K_,
+                                                                 const void* __restrict__ V_, const void* __restrict__ dO_,
+                                                                 const uint8_t* __restrict__ keep,
+                                                                 const float* __restrict__ stat, float* __restrict__ dQ,
+                                                                 float* __restrict__ dK, float* __restrict__ dV, int S,
+                                                                 int dk, int dv, float scale, float keep_scale,
+                                                                 int kind, int H, long ldq, long ldv, long ldo,
+                                                                 const int64_t* __restrict__ seed, uint32_t thresh) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[at_bwd_lds_bytes<NKB, PCHQ>()];
+  uint32_t seed_lo = 0u, seed_hi = 0u;
+  if (seed != nullptr) { const uint64_t sv = (uint64_t)seed[0]; seed_lo = (uint32_t)sv; seed_hi = (uint32_t)(sv >> 32); }
+  attn_bwd_body<NKB, PCHQ, F32>(lds, Q_, K_, V_, dO_, keep, stat, dQ, dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq,
+                                ldv, ldo, seed != nullptr, seed_lo, seed_hi, thresh, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Grouped form for packs of sequence-model trials: one launch covers the attention of one encoder layer of EVERY
+// resident trial.  Workgroup (x, y) is (batch, head) problem x of trial slot ids[y]; each slot brings its own head
+// count, head width, dropout rate and seed.  Operands are the slot's fused projection output [B*S][3d] = q | k | v
+// (f32, read in place) and its [B*S][d] attention output.
+struct MtAttnSlot {
+  const float* qkv;
+  float* o;
+  float* stat;          // [B*H][S] row statistic saved for the backward pass
+  const float* d_o;     // backward: gradient of o
+  float* dqkv;          // backward: gradient of qkv, same layout
+  const uint32_t* seed; // {lo, hi} dropout seed words of the slot's current epoch
+  int32_t B, H, dk, active_steps;
+  float scale, keep_scale;
+  uint32_t thresh;      // p * 2^32, 0 = no attention dropout
+  int32_t site;
+};
+
+template <int NKB, int PCHQ>
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_grouped_kernel(const MtAttnSlot* __restrict__ slots,
+                                                                         const int32_t* __restrict__ ids, int S,
+                                                                         int step_imm, int b_override, int train,
+                                                                         const int* __restrict__ step_base) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * NKB * 16 * PCHQ * 16];
+  const int step = mt_step(step_imm, step_base);
+  const MtAttnSlot a = slots[ids[blockIdx.y]];
+  if (step >= a.active_steps) return;
+  const int B = b_override > 0 ? b_override : a.B;
+  if ((int)blockIdx.x >= B * a.H) return;
+  const int d = a.H * a.dk;
+  const bool seeded = train && a.thresh != 0u && a.seed != nullptr;
+  uint32_t s0 = 0u, s1 = 0u;
+  if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
+  attn_fwd_body<NKB, PCHQ, true>(lds, a.qkv, a.qkv + d, a.qkv + 2 * d, nullptr, a.o, a.stat, S, a.dk, a.dk, a.scale,
+                                 seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1, a.thresh,
+                                 blockIdx.x);
+}
+
+template <int NKB, int PCHQ>
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_kernel(const MtAttnSlot* __restrict__ slots,
+                                                                         const int32_t* __restrict__ ids, int S,
+                                                                         int step_imm, const int* __restrict__ step_base) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[at_bwd_lds_bytes<NKB, PCHQ>()];
+  const int step = mt_step(step_imm, step_base);
+  const MtAttnSlot a = slots[ids[blockIdx.y]];
+  if (step >= a.active_steps) return;
+  if ((int)blockIdx.x >= a.B * a.H) return;
+  const int d = a.H * a.dk;
+  const bool seeded = a.thresh != 0u && a.seed != nullptr;
+  uint32_t s0 = 0u, s1 = 0u;
+  if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
+  attn_bwd_body<NKB, PCHQ, true>(lds, a.qkv, a.qkv + d, a.qkv + 2 * d, a.d_o, nullptr, a.stat, a.dqkv, a.dqkv + d,
+                                 a.dqkv + 2 * d, S, a.dk, a.dk, a.scale, seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d,
+                                 (long)d, seeded, s0, s1, a.thresh, blockIdx.x);
+}
+
+extern "C" int mt_attn_slot_sizeof() { return (int)sizeof(MtAttnSlot); }
+
 static int nkb_for(int S) { return ((S + 31) / 32) * 2; }   // pad the sequence to a multiple of 32
 
 // Strided form.  Q, K: [B, S, H * dk] with row stride ldq elements (the two halves of a fused QK projection pass the
@@ -459,4 +544,45 @@ extern "C" int mt_attn_bwd_launch(const void* Q, const void* K, const void* V, c
                                   float scale, float keep_scale, int kind, hipStream_t stream) {
   return mt_attn_bwd_strided_launch(Q, K, V, dO, keep, stat, dQ, dK, dV, BH, S, dk, dv, scale, keep_scale, kind, 1, dk, dv,
                                     dv, 0, nullptr, 0.f, stream);
+}
+
+// max_bh: the largest B * H among the active slots; wide != 0: some slot has heads wider than 32 (64-element images).
+extern "C" int mt_attn_fwd_grouped_launch(const MtAttnSlot* slots, const int32_t* ids, int n_active, int max_bh, int S,
+                                          int wide, int step, int b_override, int train, hipStream_t stream) {
+  if (n_active <= 0 || max_bh <= 0) return 0;
+  if (S < 1 || S > 128) return -2;
+  dim3 grid(max_bh, n_active), block(AT_THREADS);
+#define AT_GF(N, P) hipLaunchKernelGGL((mt_attn_fwd_grouped_kernel<N, P>), grid, block, 0, stream, slots, ids, S, step, \
+                                       b_override, train, mt_step_base_tls)
+#define AT_GFW(N) do { if (wide) AT_GF(N, 8); else AT_GF(N, 4); } while (0)
+  switch (nkb_for(S)) {
+    case 2: AT_GFW(2); break;
+    case 4: AT_GFW(4); break;
+    case 6: AT_GFW(6); break;
+    case 8: AT_GFW(8); break;
+    default: return -3;
+  }
+#undef AT_GFW
+#undef AT_GF
+  return (int)hipGetLastError();
+}
+
+extern "C" int mt_attn_bwd_grouped_launch(const MtAttnSlot* slots, const int32_t* ids, int n_active, int max_bh, int S,
+                                          int wide, int step, hipStream_t stream) {
+  if (n_active <= 0 || max_bh <= 0) return 0;
+  if (S < 1 || S > 128) return -2;
+  dim3 grid(max_bh, n_active), block(AT_THREADS);
+#define AT_GB(N, P) hipLaunchKernelGGL((mt_attn_bwd_grouped_kernel<N, P>), grid, block, 0, stream, slots, ids, S, step, \
+                                       mt_step_base_tls)
+#define AT_GBW(N) do { if (wide) AT_GB(N, 8); else AT_GB(N, 4); } while (0)
+  switch (nkb_for(S)) {
+    case 2: AT_GBW(2); break;
+    case 4: AT_GBW(4); break;
+    case 6: AT_GBW(6); break;
+    case 8: AT_GBW(8); break;
+    default: return -3;
+  }
+#undef AT_GBW
+#undef AT_GB
+  return (int)hipGetLastError();
 }

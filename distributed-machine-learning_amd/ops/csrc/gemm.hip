@@ -694,7 +694,7 @@ extern "C" int mt_wgrad_single_launch(const void* dY, const void* X, float* C, f
   if ((out & 7) || (in & 7) || ksplits < 1 || ksplits > 127) return -2;
   const int tiles_i = (out + BM - 1) / BM, tiles_j = (in + BN - 1) / BN;
   if (tiles_i > 255) return -2;
-  MtGemmGroup g;
+  MtGemmGroup g = {};
   g.A = dY; g.B = X; g.C = C; g.aux = nullptr; g.aux_out = db;
   g.I = out; g.J = in; g.KK = M;
   g.lda = out; g.ldb = in; g.ldc = in; g.ldaux = 0;
@@ -744,7 +744,7 @@ extern "C" int mt_gemm_single_launch(int mode, const void* A, const void* B, voi
   if (mode == 1 && (flags & MT_GEMM_FLAG_MASK) && (aux == nullptr || (ldaux & 7))) return -2;
   const int tiles_i = (M + BM - 1) / BM, tiles_j = (N + BN - 1) / BN;
   if (tiles_i > 32767 || tiles_j > 32767) return -2;
-  MtGemmGroup g;
+  MtGemmGroup g = {};
   g.A = A; g.B = B; g.C = C; g.aux = aux; g.aux_out = nullptr;
   g.I = M; g.J = N; g.KK = K;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;

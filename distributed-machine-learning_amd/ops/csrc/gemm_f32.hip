@@ -256,8 +256,13 @@ __device__ __forceinline__ void f32_gemm_tile(const MtGemmGroup* __restrict__ gr
     return;
   }
 
-  const bool relu = (MODE == 0) && (flags & MT_GEMM_FLAG_RELU);
-  const bool masked = (MODE == 1) && (flags & MT_GEMM_FLAG_MASK) && g.aux != nullptr;
+  const bool relu = (MODE == 0) && ((flags & MT_GEMM_FLAG_RELU) || (g.gflags & MT_GROUP_ACT));
+  const bool add = (MODE == 1) && (g.gflags & MT_GROUP_ADD) && g.aux != nullptr;
+  const bool masked = (MODE == 1) && !add && ((flags & MT_GEMM_FLAG_MASK) || (g.gflags & MT_GROUP_ACT)) && g.aux != nullptr;
+  const float mscale = (g.scale != 0.f) ? g.scale : 1.f;
+  const bool drop = (MODE == 0) && g.thresh != 0u && g.seed != nullptr;
+  uint32_t s0 = 0u, s1 = 0u;
+  if (drop) mt_site_seed(g.seed, g.site, step, s0, s1);
   float* C = reinterpret_cast<float*>(g.C);
 #pragma unroll
   for (int n = 0; n < R; ++n) {
@@ -277,11 +282,17 @@ __device__ __forceinline__ void f32_gemm_tile(const MtGemmGroup* __restrict__ gr
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
       }
-      if (masked) {      // ReLU backward: zero where the forward activation was not positive
+      if (drop) {        // dropout behind the activation: element index = position in the [I][ldc] output
+        const uint32_t kw = mt_keep_word4s(s0, s1, g.thresh, (uint32_t)row * (uint32_t)g.ldc + (uint32_t)col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ((kw >> (8 * j)) & 0xFFu) ? v[j] * mscale : 0.f;
+      }
+      if (masked) {      // ReLU (+ dropout) backward: zero where the forward output was not positive
         const f32x4 h = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.aux) + (size_t)row * g.ldaux + col);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = h[j] > 0.f ? v[j] : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = h[j] > 0.f ? v[j] * mscale : 0.f;
       }
+      if (add) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.aux) + (size_t)row * g.ldaux + col);
       // Columns >= J inside the last 4-chunk are products with zero-filled operand rows (and zero bias): they are
       // written as zeros, which keeps the pad columns of activation rows zero.
       *reinterpret_cast<f32x4*>(C + (size_t)row * g.ldc + col) = v;
@@ -396,7 +407,7 @@ extern "C" int mt_gemm_f32_single_launch(int mode, const void* A, const void* B,
   const int T = n128 >= 512 ? 128 : 64;
   const int tiles_i = (I + T - 1) / T, tiles_j = (J + T - 1) / T;
   if (tiles_i > (mode == 2 ? 255 : 32767) || tiles_j > 32767) return -2;
-  MtGemmGroup g;
+  MtGemmGroup g = {};
   g.A = A; g.B = B; g.C = C; g.aux = aux; g.aux_out = aux_out;
   g.I = I; g.J = J; g.KK = KK;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = 0;

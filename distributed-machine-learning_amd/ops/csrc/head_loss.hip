@@ -16,19 +16,6 @@
 #define HL_THREADS 256
 #define HL_WAVES 4
 
-__device__ __forceinline__ void loss_and_grad(int type, float out, float y, float& l, float& g) {
-  const float d = out - y;
-  const float a = fabsf(d);
-  const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-  switch (type) {
-    case 0: l = d * d; g = 2.f * d; break;
-    case 1: l = a; g = sgn; break;
-    case 2: if (a < 1.f) { l = 0.5f * d * d; g = d; } else { l = a - 0.5f; g = sgn; } break;
-    default: { const float den = fabsf(y) + 1e-8f; l = 100.f * a / den; g = 100.f * sgn / den; } break;
-  }
-}
-
-
 // Eight consecutive activations of one row as the lane holds them: packed bf16 (one 16-byte load) or f32 (two).
 template <bool F32> struct HRow8;
 template <> struct HRow8<false> {

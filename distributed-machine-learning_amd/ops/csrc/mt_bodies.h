@@ -7,6 +7,20 @@
 
 #define HL_ROWS 32       // rows per workgroup of the head/loss kernel = rows per partial record
 
+// Loss value and its derivative w.r.t. the prediction: 0 squared error, 1 absolute error, 2 Huber (beta 1),
+// 3 absolute percentage error.
+__device__ __forceinline__ void loss_and_grad(int type, float out, float y, float& l, float& g) {
+  const float d = out - y;
+  const float a = fabsf(d);
+  const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+  switch (type) {
+    case 0: l = d * d; g = 2.f * d; break;
+    case 1: l = a; g = sgn; break;
+    case 2: if (a < 1.f) { l = 0.5f * d * d; g = d; } else { l = a - 0.5f; g = sgn; } break;
+    default: { const float den = fabsf(y) + 1e-8f; l = 100.f * a / den; g = 100.f * sgn / den; } break;
+  }
+}
+
 struct MtHeadReduceArgs {      // by-value kernel argument of the launch that carries the head reduction
   const MtHeadSlot* slots;
   const int32_t* ids;

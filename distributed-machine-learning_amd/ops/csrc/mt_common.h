@@ -52,12 +52,23 @@ struct MtGemmGroup {
   const void* A;
   const void* B;
   void* C;
-  const void* aux;     // mode 0: bias f32[J]; mode 1: ReLU source bf16 [I][ldaux] (output masked where <= 0)
+  const void* aux;     // mode 0: bias f32[J]; mode 1: ReLU source [I][ldaux] (output masked where <= 0), or with
+                       // MT_GROUP_ADD the addend [I][ldaux]
   void* aux_out;       // mode 2: bias gradient f32[I] (column sums of A), written by the tj == 0 tiles
+  const uint32_t* seed;  // f32 kernels, mode 0, thresh != 0: {lo, hi} words of the slot's dropout seed for this epoch
   int32_t I, J, KK;
   int32_t lda, ldb, ldc, ldaux;
   int32_t active_steps;  // the group takes part while step < active_steps
+  // Per-group extras of the f32 kernels (zero = off; the bf16 kernels ignore them): sequence-model packs put dense
+  // layers with different epilogues and dropout rates into one launch.
+  uint32_t thresh;       // mode 0: drop an output element when its hash is below this (p * 2^32), after the ReLU
+  float scale;           // mode 0: factor of the kept elements, 1 / (1 - p); mode 1: factor applied with the mask (0 = 1)
+  int32_t gflags;        // MT_GROUP_* bits, OR-ed to the launch's flags
+  int32_t site;          // which dropout site of the model this layer is (decorrelates the sites of one slot)
 };
+
+#define MT_GROUP_ACT 1    // mode 0: ReLU after bias; mode 1: multiply by (aux > 0)
+#define MT_GROUP_ADD 2    // mode 1: output += aux (the gradient arriving over a residual connection); excludes the mask
 
 struct MtTile {
   int32_t group;
@@ -119,6 +130,18 @@ __device__ __forceinline__ uint32_t mt_rng_hash(uint32_t s0, uint32_t s1, uint32
   return mt_mix32(i * 0x9E3779B9u + s0) ^ mt_mix32((i >> 5) + s1 * 0x85EBCA6Bu + 0x27D4EB2Fu);
 }
 // Keep flags (one byte each, 0 or 1) of elements i .. i+3, from a stored mask if there is one, else from the seed.
+// Seed words of one dropout site at one step: derived from the slot's epoch seed so that forward and backward of the
+// same step agree and no two sites or steps share a stream.
+__device__ __forceinline__ void mt_site_seed(const uint32_t* __restrict__ seed, int site, int step, uint32_t& s0, uint32_t& s1) {
+  s0 = seed[0] + (uint32_t)site * 0x9E3779B9u;
+  s1 = seed[1] ^ mt_mix32((uint32_t)step * 0x85EBCA6Bu + (uint32_t)site + 0x51ED270Bu);
+}
+__device__ __forceinline__ uint32_t mt_keep_word4s(uint32_t s0, uint32_t s1, uint32_t thresh, uint32_t i) {
+  uint32_t w = 0u;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w |= (mt_rng_hash(s0, s1, i + e) >= thresh ? 1u : 0u) << (8 * e);
+  return w;
+}
 __device__ __forceinline__ uint32_t mt_keep_word4(const uint8_t* __restrict__ keep, const int64_t* __restrict__ seed,
                                                   uint32_t thresh, size_t i) {
   if (keep != nullptr) return *reinterpret_cast<const uint32_t*>(keep + i);

@@ -22,9 +22,11 @@ c_void_p, c_int32, c_uint32, c_float, c_size_t = C.c_void_p, C.c_int32, C.c_uint
 
 class GemmGroup(C.Structure):
     _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("aux", c_void_p), ("aux_out", c_void_p),
+                ("seed", c_void_p),
                 ("I", c_int32), ("J", c_int32), ("KK", c_int32),
                 ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldaux", c_int32),
-                ("active_steps", c_int32)]
+                ("active_steps", c_int32),
+                ("thresh", c_uint32), ("scale", c_float), ("gflags", c_int32), ("site", c_int32)]
 
 
 class Tile(C.Structure):
@@ -99,8 +101,17 @@ class HeadMlp(C.Structure):
 
 # numpy views of the same layouts, for building whole descriptor tables vectorised
 GEMM_GROUP_DTYPE = np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("aux", "<u8"), ("aux_out", "<u8"),
+                             ("seed", "<u8"),
                              ("I", "<i4"), ("J", "<i4"), ("KK", "<i4"), ("lda", "<i4"), ("ldb", "<i4"),
-                             ("ldc", "<i4"), ("ldaux", "<i4"), ("active_steps", "<i4")], align=True)
+                             ("ldc", "<i4"), ("ldaux", "<i4"), ("active_steps", "<i4"),
+                             ("thresh", "<u4"), ("scale", "<f4"), ("gflags", "<i4"), ("site", "<i4")], align=True)
+GROUP_ACT, GROUP_ADD = 1, 2
+
+
+def gemm_group(A, B, C, aux, aux_out, I, J, KK, lda, ldb, ldc, ldaux, active_steps, seed=0, thresh=0, scale=0.0,
+               gflags=0, site=0):
+    """One record of ``GEMM_GROUP_DTYPE`` (field order of ``MtGemmGroup``); the trailing per-group extras default off."""
+    return (A, B, C, aux, aux_out, seed, I, J, KK, lda, ldb, ldc, ldaux, active_steps, thresh, scale, gflags, site)
 TILE_DTYPE = np.dtype([("group", "<i4"), ("ti", "<i2"), ("tj", "<i2")], align=True)
 GATHER_DTYPE = np.dtype([("X0", "<u8"), ("y", "<u8"), ("key", "<u4", (4,)), ("B", "<i4"), ("active_steps", "<i4")],
                         align=True)

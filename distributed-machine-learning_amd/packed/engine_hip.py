@@ -99,6 +99,9 @@ class _Chain:
     __slots__ = ("ids", "tag", "plan", "steps", "counter", "graph")
 
 
+gemm_group = L.gemm_group
+
+
 def balanced_tiles(groups: List[Tuple[int, int, int, int]], ksplits: int = 1) -> np.ndarray:
     """XCD-aware tile list (``ksplits`` > 1: one entry per contraction split, index in the high byte of ``ti``).
 
@@ -450,20 +453,20 @@ class HipPackEngine(PackEngine):
                     a_in = self.Xva.data_ptr() if eval_mode else self.X0.data_ptr() + slot * x0_stride
                 else:
                     a_in = self._act_ptr(self.H[l - 1], slot)
-                fwd[slot] = (a_in, w_base + (base + lay.w_off[l]) * wb, self._act_ptr(self.H[l], slot),
-                             p_base + (base + lay.b_off[l]) * 4, 0,
-                             bsz, h, k_real, k_ld, k_ld, o_ld, 0, steps)
+                fwd[slot] = gemm_group(a_in, w_base + (base + lay.w_off[l]) * wb, self._act_ptr(self.H[l], slot),
+                                       p_base + (base + lay.b_off[l]) * 4, 0,
+                                       bsz, h, k_real, k_ld, k_ld, o_ld, 0, steps)
                 fl.append((slot, bsz, h, (k_real + 63) // 64))
                 if eval_mode:
                     continue
                 if l > 0:
-                    dg[slot] = (self._act_ptr(self.dZ[l], slot), w_base + (base + lay.w_off[l]) * wb,
-                                self._act_ptr(self.dZ[l - 1], slot), self._act_ptr(self.H[l - 1], slot), 0,
-                                bsz, k_real, h, o_ld, k_ld, k_ld, k_ld, steps)
+                    dg[slot] = gemm_group(self._act_ptr(self.dZ[l], slot), w_base + (base + lay.w_off[l]) * wb,
+                                          self._act_ptr(self.dZ[l - 1], slot), self._act_ptr(self.H[l - 1], slot), 0,
+                                          bsz, k_real, h, o_ld, k_ld, k_ld, k_ld, steps)
                     dl.append((slot, bsz, k_real, (h + 63) // 64))
-                wg[slot] = (self._act_ptr(self.dZ[l], slot), a_in, g_base + (base + lay.w_off[l]) * 4, 0,
-                            g_base + (base + lay.b_off[l]) * 4,
-                            h, k_real, bsz, o_ld, k_ld, k_ld, 0, steps)
+                wg[slot] = gemm_group(self._act_ptr(self.dZ[l], slot), a_in, g_base + (base + lay.w_off[l]) * 4, 0,
+                                      g_base + (base + lay.b_off[l]) * 4,
+                                      h, k_real, bsz, o_ld, k_ld, k_ld, 0, steps)
                 wl.append((slot, h, k_real, (bsz + 63) // 64))
             def tiled(lst, edge):
                 return [(g_, (r_ + edge - 1) // edge, (c_ + edge - 1) // edge, w_) for g_, r_, c_, w_ in lst]

@@ -65,7 +65,7 @@ def test_gemm_forward_nt(lib, relu):
         w = torch.zeros(n, ldk, device="cuda", dtype=torch.bfloat16); w[:, :k] = _rand_bf16(n, k, scale=0.2, gen=g)
         b = torch.randn(n, device="cuda", generator=g)
         y = torch.full((m, ldn), 7.0, device="cuda", dtype=torch.bfloat16)
-        groups[gi] = (x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, m, n, k, ldk, ldk, ldn, 0, 1)
+        groups[gi] = L.gemm_group(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, m, n, k, ldk, ldk, ldn, 0, 1)
         keep.append((x, w, b, y)); dims.append((gi, m, n))
     groups[len(SHAPES)]["active_steps"] = 0
     tiles = _tiles(L, dims)
@@ -92,7 +92,7 @@ def test_gemm_forward_identity_asymmetric(lib):
     b = torch.zeros(n, device="cuda")
     y = torch.zeros(n, n, device="cuda", dtype=torch.bfloat16)
     groups = np.zeros(1, dtype=L.GEMM_GROUP_DTYPE)
-    groups[0] = (x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, n, n, n, n, n, n, 0, 1)
+    groups[0] = L.gemm_group(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, n, n, n, n, n, n, 0, 1)
     tiles = _tiles(L, [(0, n, n)])
     gt, tt = _up(groups), _up(tiles)
     L.check(so.mt_gemm_launch(0, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, 0, 0, 0, 1, 0, NSTAGE, _stream()), "gemm")
@@ -112,7 +112,7 @@ def test_gemm_dgrad_nn(lib, mask):
         w = torch.zeros(n, ldk, device="cuda", dtype=torch.bfloat16); w[:, :k] = _rand_bf16(n, k, scale=0.2, gen=g)
         h = torch.zeros(m, ldk, device="cuda", dtype=torch.bfloat16); h[:, :k] = _rand_bf16(m, k, gen=g).relu()
         dx = torch.full((m, ldk), 7.0, device="cuda", dtype=torch.bfloat16)
-        groups[gi] = (dy.data_ptr(), w.data_ptr(), dx.data_ptr(), h.data_ptr(), 0, m, k, n, ldn, ldk, ldk, ldk, 1)
+        groups[gi] = L.gemm_group(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), h.data_ptr(), 0, m, k, n, ldn, ldk, ldk, ldk, 1)
         keep.append((dy, w, h, dx)); dims.append((gi, m, k))
     tiles = _tiles(L, dims)
     gt, tt = _up(groups), _up(tiles)
@@ -140,7 +140,7 @@ def test_gemm_wgrad_tn(lib, ksplits):
         dw_all = arena[:, :n * ldk].view(ksplits, n, ldk)
         dw_all.zero_()
         db_all = arena[:, 590 * 600:590 * 600 + n]
-        groups[gi] = (dy.data_ptr(), x.data_ptr(), arena.data_ptr(), 0, db_all.data_ptr(), n, k, m, ldn, ldk, ldk, 0, 1)
+        groups[gi] = L.gemm_group(dy.data_ptr(), x.data_ptr(), arena.data_ptr(), 0, db_all.data_ptr(), n, k, m, ldn, ldk, ldk, 0, 1)
         keep.append((dy, x, dw_all, db_all)); dims.append((gi, n, k))
     tiles = _tiles(L, dims)
     if ksplits > 1:
@@ -316,7 +316,7 @@ def test_gemm_f32_forward_nt(lib, relu, edge):
         w = torch.zeros(n, ldk, device="cuda"); w[:, :k] = torch.randn(n, k, device="cuda", generator=g) * 0.2
         b = torch.randn(n, device="cuda", generator=g)
         y = torch.full((m, ldn), 7.0, device="cuda")
-        groups[gi] = (x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, m, n, k, ldk, ldk, ldn, 0, 1)
+        groups[gi] = L.gemm_group(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, m, n, k, ldk, ldk, ldn, 0, 1)
         keep.append((x, w, b, y)); dims.append((gi, m, n))
     groups[len(F32_SHAPES)]["active_steps"] = 0
     tiles = _tiles_edge(L, dims, edge)
@@ -345,7 +345,7 @@ def test_gemm_f32_forward_identity_asymmetric(lib, edge):
     b = torch.zeros(n, device="cuda")
     y = torch.zeros(n, n, device="cuda")
     groups = np.zeros(1, dtype=L.GEMM_GROUP_DTYPE)
-    groups[0] = (x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, n, n, n, n, n, n, 0, 1)
+    groups[0] = L.gemm_group(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, n, n, n, n, n, n, 0, 1)
     tiles = _tiles_edge(L, [(0, n, n)], edge)
     gt, tt = _up(groups), _up(tiles)
     L.check(so.mt_gemm_f32_launch(0, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, 0, 0, 0, 1, 0, edge, _stream()), "gemm_f32")
@@ -368,7 +368,7 @@ def test_gemm_f32_dgrad_nn(lib, mask, edge):
         w = torch.zeros(n, ldk, device="cuda"); w[:, :k] = torch.randn(n, k, device="cuda", generator=g) * 0.2
         h = torch.zeros(m, ldk, device="cuda"); h[:, :k] = torch.randn(m, k, device="cuda", generator=g).relu()
         dx = torch.full((m, ldk), 7.0, device="cuda")
-        groups[gi] = (dy.data_ptr(), w.data_ptr(), dx.data_ptr(), h.data_ptr(), 0, m, k, n, ldn, ldk, ldk, ldk, 1)
+        groups[gi] = L.gemm_group(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), h.data_ptr(), 0, m, k, n, ldn, ldk, ldk, ldk, 1)
         keep.append((dy, w, h, dx)); dims.append((gi, m, k))
     tiles = _tiles_edge(L, dims, edge)
     gt, tt = _up(groups), _up(tiles)
@@ -399,7 +399,7 @@ def test_gemm_f32_wgrad_tn(lib, ksplits, edge):
         dw_all = arena[:, :n * ldk].view(ksplits, n, ldk)
         dw_all.zero_()
         db_all = arena[:, 590 * 600:590 * 600 + n]
-        groups[gi] = (dy.data_ptr(), x.data_ptr(), arena.data_ptr(), 0, db_all.data_ptr(), n, k, m, ldn, ldk, ldk, 0, 1)
+        groups[gi] = L.gemm_group(dy.data_ptr(), x.data_ptr(), arena.data_ptr(), 0, db_all.data_ptr(), n, k, m, ldn, ldk, ldk, 0, 1)
         keep.append((dy, x, dw_all, db_all)); dims.append((gi, n, k))
     tiles = _tiles_edge(L, dims, edge)
     if ksplits > 1:
