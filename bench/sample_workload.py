@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--packed", type=int, default=0, help="trial slots of the packed executor (0: one function trial at a time)")
     ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--engine", default="auto", help="packed engine: auto (grouped launches, 'seq') | graph (one captured step per slot) | torch")
     args = ap.parse_args()
     tl, vl = create_dummy_data(learnable=not args.noise_target)
     space = dict(SAMPLE_SPACE, device=args.device, hip_graph=not args.no_graph)
@@ -51,7 +52,7 @@ def main():
         Xt, yt = tl.dataset.tensors
         Xv, yv = vl.dataset.tensors
         tr = PackedTrainable(model="simple_transformer", train=(Xt, yt), val=(Xv, yv), max_epochs=5, dtype="f32",
-                             capacity=args.packed, name="sample_packed",
+                             capacity=args.packed, name="sample_packed", engine=args.engine,
                              model_kwargs={"batch_size": 32, "optimizer": "adamw", "streams": args.streams})
         sched = FIFOScheduler() if args.no_asha else ASHAScheduler(metric="validation_loss", mode="min", max_t=5)
         return tune.run(tr, config=SAMPLE_SPACE, num_samples=n, scheduler=sched, local_dir=None, verbose=0, seed=seed,

@@ -9,14 +9,16 @@
 // learning rates shares each launch:
 //
 //   * every dense layer of layer index l of all slots is ONE grouped exact-f32 MFMA GEMM (gemm_f32.hip): descriptors
-//     per slot, an XCD-aware tile list, bias / ReLU / dropout fused in the epilogue; backward is one launch per dense
-//     layer holding the weight-gradient tiles (split over the token dimension) and the input-gradient tiles (ReLU +
-//     dropout mask, or the residual gradient added in the epilogue);
+//     per slot, an XCD-aware tile list, bias / ReLU / dropout fused in the epilogue; in the backward pass the chain of
+//     input gradients is one launch per dense layer (ReLU + dropout mask, or the residual gradient added, in the
+//     epilogue), and the weight gradients of ALL dense layers of all slots -- which nothing in the chain waits for --
+//     are one launch at the end of the pass: a tile of theirs is a long contraction over the tokens, and only all of
+//     them together are enough tiles to fill the chip;
 //   * attention, residual + dropout + LayerNorm, the head + loss and the mini-batch gather are grouped kernels whose
 //     workgroup (x, y) works on piece x of trial slot ids[y] from a per-slot descriptor;
 //   * the optimiser is the per-slot fused one of optim.hip over the pack's flat parameter slab.
 //
-// A step of the whole pack is 12 launches per encoder layer plus 6, whatever the number of trials; the C++ driver
+// A step of the whole pack is 14 launches per encoder layer plus 7, whatever the number of trials; the C++ driver
 // below enqueues all steps of an epoch back to back and the host synchronises once per epoch.  Trials of fewer layers
 // than the deepest one simply have no tiles / inactive descriptors in the deeper launches.  Dropout masks are never
 // stored: forward and backward derive them from (slot seed of the epoch, site, step, element index).
@@ -72,14 +74,6 @@ struct MtSeqOp {          // one grouped GEMM launch
   int32_t ntiles, edge;
 };
 
-struct MtSeqBwdOp {       // backward of one dense layer: weight-gradient tiles + input-gradient tiles in one launch
-  const MtGemmGroup* wgroups;
-  const MtTile* wtiles;
-  const MtGemmGroup* dgroups;
-  const MtTile* dtiles;
-  int32_t n_w, n_d, edge, pad;
-};
-
 struct MtAttnSlot;      // attention.hip
 
 struct MtSeqPlan {
@@ -95,8 +89,8 @@ struct MtSeqPlan {
   const MtAttnSlot* attn[MT_SEQ_MAX_LAYERS];
   const MtLnSlot* ln1[MT_SEQ_MAX_LAYERS];
   const MtLnSlot* ln2[MT_SEQ_MAX_LAYERS];
-  MtSeqBwdOp b_ff2[MT_SEQ_MAX_LAYERS], b_ff1[MT_SEQ_MAX_LAYERS], b_out[MT_SEQ_MAX_LAYERS], b_qkv[MT_SEQ_MAX_LAYERS];
-  MtSeqOp b_in;
+  MtSeqOp d_ff2[MT_SEQ_MAX_LAYERS], d_ff1[MT_SEQ_MAX_LAYERS], d_out[MT_SEQ_MAX_LAYERS], d_qkv[MT_SEQ_MAX_LAYERS];
+  MtSeqOp wgrad;          // weight + bias gradients of every dense layer of every slot (mode 2, split over the tokens)
   const MtSeqHeadSlot* head;
   float* P;
   float* G;
@@ -437,9 +431,8 @@ static int seq_forward(const MtSeqPlan* p, int step, int arow0, int rows, int nb
   return (int)hipGetLastError();
 }
 
-static int seq_bwd(const MtSeqBwdOp& op, int step, const MtSeqPlan* p, hipStream_t stream) {
-  return mt_gemm_f32_bwd_launch(op.wgroups, op.wtiles, op.n_w, op.dgroups, op.dtiles, op.n_d, step, p->ksplits,
-                                p->gsplit_stride, op.edge, stream);
+static int seq_dgrad(const MtSeqOp& op, int step, hipStream_t stream) {
+  return mt_gemm_f32_launch(1, op.groups, op.tiles, op.ntiles, step, 0, 0, 0, 1, 0, op.edge, stream);
 }
 
 // Enqueue steps [step0, step0 + nsteps) of the epoch described by the plan's per-epoch tables.  opt_step is the
@@ -465,16 +458,16 @@ extern "C" int mt_seq_train_steps(const MtSeqPlan* p, int step0, int nsteps, hip
     for (int l = p->n_layers - 1; l >= 0; --l) {
       hipLaunchKernelGGL(mt_seq_ln_bwd_kernel, dim3(ln_blocks, p->n_active), block, 0, stream, p->ln2[l], p->ids, step,
                          mt_step_base_tls);
-      SQ_TRY(seq_bwd(p->b_ff2[l], step, p, stream));
-      SQ_TRY(seq_bwd(p->b_ff1[l], step, p, stream));
+      SQ_TRY(seq_dgrad(p->d_ff2[l], step, stream));
+      SQ_TRY(seq_dgrad(p->d_ff1[l], step, stream));
       hipLaunchKernelGGL(mt_seq_ln_bwd_kernel, dim3(ln_blocks, p->n_active), block, 0, stream, p->ln1[l], p->ids, step,
                          mt_step_base_tls);
-      SQ_TRY(seq_bwd(p->b_out[l], step, p, stream));
+      SQ_TRY(seq_dgrad(p->d_out[l], step, stream));
       SQ_TRY(mt_attn_bwd_grouped_launch(p->attn[l], p->ids, p->n_active, p->max_bh, p->S, p->wide, step, stream));
-      SQ_TRY(seq_bwd(p->b_qkv[l], step, p, stream));
+      SQ_TRY(seq_dgrad(p->d_qkv[l], step, stream));
     }
-    SQ_TRY(mt_gemm_f32_launch(2, p->b_in.groups, p->b_in.tiles, p->b_in.ntiles, step, MT_GEMM_FLAG_DBIAS, 0, 0, p->ksplits,
-                              p->gsplit_stride, p->b_in.edge, stream));
+    SQ_TRY(mt_gemm_f32_launch(2, p->wgrad.groups, p->wgrad.tiles, p->wgrad.ntiles, step, MT_GEMM_FLAG_DBIAS, 0, 0,
+                              p->ksplits, p->gsplit_stride, p->wgrad.edge, stream));
     hipLaunchKernelGGL(mt_seq_ln_reduce_kernel, dim3(2 * p->n_layers, p->n_active), block, 0, stream, tabs, p->ids, step,
                        mt_step_base_tls);
     SQ_TRY(mt_optim_launch(p->P, p->G, p->M, p->V, nullptr, p->slot_stride, p->opt, p->ids, p->n_active, p->max_params,

@@ -48,8 +48,18 @@ def make_engine(trainable: PackedTrainable, device: torch.device, capacity: Opti
         # slot's training step captured in a hipGraph (fused attention / LayerNorm / optimiser kernels inside)
         if device.type == "cuda":
             kind = "hip" if trainable.model == "mlp" else "graph"
+            if trainable.model == "simple_transformer" and trainable.dtype == "f32" \
+                    and os.environ.get("MITUNE_SEQ_ENGINE", "1") != "0":
+                # small encoder trials share launches (grouped GEMMs, grouped attention / LayerNorm); shapes the grouped
+                # kernels do not cover stay on the one-graph-per-slot engine
+                from . import engine_seq
+                if engine_seq.supports(trainable) is None:
+                    kind = "seq"
         else:
             kind = "torch"
+    if kind == "seq":
+        from .engine_seq import SeqPackEngine
+        return SeqPackEngine(trainable, device, capacity, seed)
     if kind == "graph":
         from .engine_graph import GraphPackEngine
         return GraphPackEngine(trainable, str(device), capacity, seed)
@@ -161,6 +171,8 @@ class PackedExecutor(Executor):
             self.engine.begin_round()
             self.engine.train_epoch()
             table = device_table()
+            if self.world == 1 and self.runner is not None and hasattr(self.engine, "prepare"):
+                self._prefetch(t0)      # the epoch and its validation are enqueued: build the next trials meanwhile
             if self.comm.device.type != "cuda":       # a CPU-side collective (gloo, in-process ranks): one copy down
                 table = table.cpu()
             t1 = t2 = time.time()

@@ -21,7 +21,7 @@ class PackedTrainable:
     train: Tuple[torch.Tensor, torch.Tensor] = None      # (X [N, F] or sequences [N, S, F], y [N])
     val: Tuple[torch.Tensor, torch.Tensor] = None
     max_epochs: int = 16                                 # a trial that is never stopped ends here
-    engine: str = "auto"                                 # "auto" | "torch" | "hip" | "graph"
+    engine: str = "auto"                                 # "auto" | "torch" | "hip" | "graph" | "seq"
     dtype: str = "bf16"                                  # compute dtype of the HIP engine ("bf16" | "f32")
     capacity: Optional[int] = None                       # trial slots per GPU (None: HBM budget decides)
     hbm_budget_gb: float = 240.0                         # of the 288 GB, what a pack may plan for
