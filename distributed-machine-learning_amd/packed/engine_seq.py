@@ -295,6 +295,8 @@ class SeqPackEngine(PackEngine):
         self._stage: Optional[torch.Tensor] = None
         self._tables: Dict[str, Any] = {}
         self._prepared: Dict[int, Tuple[Dict, torch.Tensor]] = {}
+        self._init_rng = torch.Generator()
+        self._pin_pool: List[torch.Tensor] = []          # pinned staging images, recycled once their copy has finished
         self.prepared_total = 0
         self._dirty = True
         self._plans: Dict[str, SeqPlan] = {}
@@ -327,16 +329,47 @@ class SeqPackEngine(PackEngine):
             raise ValueError(f"batch_size {spec.opt.batch_size} > max_batch {self.max_batch}")
         return spec
 
+    def _initial_image(self, lay: SeqLayout, trial_index: int, host: torch.Tensor) -> None:
+        """Write the trial's starting weights into ``host`` (a slab-region image): bit for bit those of the module every
+        other engine builds for it -- ``SimpleTransformerModel`` under ``manual_seed`` of the trial's stream draws, in
+        construction order, a uniform(-1/sqrt(fan_in), 1/sqrt(fan_in)) weight and then bias for each dense layer, and sets
+        LayerNorm to (1, 0) -- without building the module (a millisecond of host time per trial, which is what bounds a
+        search of thousands of one-epoch trials)."""
+        host[:lay.total].zero_()
+        g = self._init_rng              # a private generator: same stream as the global one under the same seed, and
+        g.manual_seed((self.seed * 1_000_003 + int(trial_index)) * 16 + 7)        # seeding it costs 1.5 us instead of 160
+        bound = 0.0
+        for key, off, (rows, cols), ld in lay.entries:       # construction order of the module
+            if ".norm" in key:
+                if key.endswith(".weight"):
+                    host[off:off + cols].fill_(1.0)
+                continue
+            if key.endswith(".weight"):
+                bound = 1.0 / math.sqrt(cols)                # fan_in; the bias that follows shares it
+                if ld == cols:
+                    host[off:off + rows * cols].view(rows, cols).uniform_(-bound, bound, generator=g)
+                else:
+                    host[off:off + rows * ld].view(rows, ld)[:, :cols] = torch.empty(rows, cols).uniform_(-bound, bound,
+                                                                                                         generator=g)
+            else:
+                host[off:off + cols].uniform_(-bound, bound, generator=g)
+
     def _initial_state(self, spec: SeqSpec, config: Dict, trial_index: int) -> Dict[str, torch.Tensor]:
-        """The trial's starting weights: those of the module every other engine builds for it (same seeded stream)."""
-        from ..models.transformer import SimpleTransformerModel
-        with torch.random.fork_rng(devices=[]):
-            torch.manual_seed((self.seed * 1_000_003 + int(trial_index)) * 16 + 7)
-            model = SimpleTransformerModel.from_config({**self.t.model_kwargs, **config}, self.F)
-        return model.state_dict()
+        """The same weights as a state dict (tests compare it with the module's)."""
+        lay = SeqLayout(self.F, self.fpad, spec.d, spec.layers)
+        host = torch.zeros(lay.total, dtype=torch.float32)
+        self._initial_image(lay, trial_index, host)
+        out: Dict[str, torch.Tensor] = {}
+        for key, off, (rows, cols), ld in lay.entries:
+            t = host[off:off + rows * ld].reshape(rows, ld)[:, :cols].clone()
+            out[key] = t.reshape(-1) if (key.endswith(".bias") or ".norm" in key) else t
+        return out
+
+    def _pinned(self) -> torch.Tensor:
+        return self._pin_pool.pop() if self._pin_pool else torch.zeros(self.stride, dtype=torch.float32).pin_memory()
 
     def _pack(self, lay: SeqLayout, state: Dict[str, torch.Tensor], host: torch.Tensor) -> None:
-        host.zero_()
+        host[:lay.total].zero_()
         for key, off, (rows, cols), ld in lay.entries:
             src = state[key].detach().to("cpu", torch.float32).reshape(rows, cols)
             if ld == cols:
@@ -348,7 +381,7 @@ class SeqPackEngine(PackEngine):
         if self._stage is None:
             self._stage = torch.zeros(self.stride, dtype=torch.float32).pin_memory()
         self._pack(lay, state, self._stage)
-        self._region(slab, slot).copy_(self._stage)       # blocking: the staging region is free again on return
+        self._region(slab, slot)[:lay.total].copy_(self._stage[:lay.total])       # blocking: the staging region is free again on return
 
     def _read_params(self, slot: int, lay: SeqLayout, slab: torch.Tensor) -> Dict[str, torch.Tensor]:
         host = self._region(slab, slot).detach().to("cpu", torch.float32)
@@ -367,8 +400,8 @@ class SeqPackEngine(PackEngine):
             return False
         spec = self._spec(config)
         lay = SeqLayout(self.F, self.fpad, spec.d, spec.layers)
-        host = torch.zeros(self.stride, dtype=torch.float32).pin_memory()
-        self._pack(lay, self._initial_state(spec, config, trial_index), host)
+        host = self._pinned()
+        self._initial_image(lay, trial_index, host)
         self._prepared[int(trial_index)] = (dict(config), host)
         self.prepared_total += 1
         return True
@@ -382,11 +415,12 @@ class SeqPackEngine(PackEngine):
         s.layout = SeqLayout(self.F, self.fpad, spec.d, spec.layers)
         s.arena = ArenaLayout(self.rows_max, self.S, self.fpad, spec.d, spec.heads, spec.layers)
         s.epoch, s.step = 0, 0
+        n = s.layout.total                  # nothing ever touches a region beyond the tenant's own tensors
         for slab in (self.M, self.V):
-            self._region(slab, slot).zero_()
+            self._region(slab, slot)[:n].zero_()
         for sp in range(self.ksplits):      # a previous tenant laid its tensors out differently
             off = (sp * self.capacity + slot) * self.stride
-            self.G[off:off + self.stride].zero_()
+            self.G[off:off + n].zero_()
         ready = self._prepared.pop(int(trial_index), None)
         if state is not None and "model" in state:
             self._write_params(slot, s.layout, state["model"], self.P)
@@ -395,10 +429,16 @@ class SeqPackEngine(PackEngine):
                 self._write_params(slot, s.layout, opt["exp_avg"], self.M)
                 self._write_params(slot, s.layout, opt["exp_avg_sq"], self.V)
             s.epoch, s.step = int(state.get("epoch", 0)), int(state.get("step", 0))
-        elif ready is not None and ready[0] == dict(config):
-            self._region(self.P, slot).copy_(ready[1])
         else:
-            self._write_params(slot, s.layout, self._initial_state(spec, config, trial_index), self.P)
+            if ready is not None and ready[0] == dict(config):
+                host = ready[1]
+            else:
+                host = self._pinned()
+                self._initial_image(s.layout, trial_index, host)
+            self._region(self.P, slot)[:n].copy_(host[:n])        # blocking: the image is free again on return
+            self._pin_pool.append(host)
+        if ready is not None and state is not None:
+            self._pin_pool.append(ready[1])
         self.loss_acc[slot] = 0
         self.slots[slot] = s
         self._dirty = True
