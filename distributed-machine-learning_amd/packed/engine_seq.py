@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from .engine import PackEngine
-from .engine_hip import F32_SMALL_TILES, SMALL_TILE, TILE, balanced_tiles
+from .engine_hip import SMALL_TILE, balanced_tiles
 from .permutation import half_bits, mix32, round_keys
 from .trainable import PackedTrainable
 from ..models.mlp import MLPTrialSpec
@@ -468,6 +468,63 @@ class SeqPackEngine(PackEngine):
         b.step = a.step
         self._dirty = True
 
+    # ------------------------------------------------------------------ moving a trial to another GPU
+    @property
+    def raw_numel(self) -> int:
+        return 3 * self.stride + 4
+
+    def export_raw(self, slot: int) -> torch.Tensor:
+        """One slot's parameters and both optimiser moment regions as a single device tensor, epoch / step / trial index
+        in the last four words.  A region's layout depends on the trial's shape only, so it is valid in any slot of any
+        engine built from the same trainable: another GPU's ``import_raw`` copies it in without the host."""
+        s, n = self.slots[slot], self.stride
+        out = torch.empty(self.raw_numel, device=self.device, dtype=torch.float32)
+        for i, slab in enumerate((self.P, self.M, self.V)):
+            out[i * n:(i + 1) * n].copy_(self._region(slab, slot))
+        out[3 * n:].view(torch.int32).copy_(torch.tensor([s.epoch, s.step, s.trial_index, 0], dtype=torch.int32))
+        return out
+
+    def _take_raw(self, slot: int, raw: torch.Tensor) -> List[int]:
+        n = self.stride
+        if raw.numel() != self.raw_numel:
+            raise ValueError(f"raw slot state of {raw.numel()} words, this engine's slots take {self.raw_numel}")
+        raw = raw.to(self.device)
+        for i, slab in enumerate((self.P, self.M, self.V)):
+            self._region(slab, slot).copy_(raw[i * n:(i + 1) * n])
+        for sp in range(self.ksplits):
+            off = (sp * self.capacity + slot) * self.stride
+            self.G[off:off + self.stride].zero_()
+        return raw[3 * n:].view(torch.int32).tolist()
+
+    def import_raw(self, slot: int, trial_index: int, config: Dict, raw: torch.Tensor) -> None:
+        if slot in self.slots:
+            raise RuntimeError(f"slot {slot} is occupied")
+        spec = self._spec(config)
+        n = self.stride
+        owner = int(raw[3 * n:].view(torch.int32)[2])
+        if owner != int(trial_index):
+            raise ValueError(f"slot state belongs to trial {owner}, not {trial_index}")
+        epoch, step, _, _ = self._take_raw(slot, raw)
+        s = _SSlot()
+        s.trial_index, s.spec, s.config = int(trial_index), spec, dict(config)
+        s.layout = SeqLayout(self.F, self.fpad, spec.d, spec.layers)
+        s.arena = ArenaLayout(self.rows_max, self.S, self.fpad, spec.d, spec.heads, spec.layers)
+        s.epoch, s.step = int(epoch), int(step)
+        self.loss_acc[slot] = 0
+        self.slots[slot] = s
+        self._dirty = True
+
+    def adopt_raw(self, slot: int, raw: torch.Tensor, config: Dict) -> None:
+        """PBT exploit across GPUs: the occupied ``slot`` takes over a donor's weights, moments and step count (same
+        architecture, possibly other hyper-parameters); it keeps its own trial index and epoch count."""
+        s = self.slots[slot]
+        spec = self._spec(config)
+        if (spec.d, spec.heads, spec.layers) != (s.spec.d, s.spec.heads, s.spec.layers):
+            raise ValueError("an exploit cannot change the architecture")
+        _, step, _, _ = self._take_raw(slot, raw)
+        s.spec, s.config, s.step = spec, dict(config), int(step)
+        self._dirty = True
+
     def import_state(self, slot, state, config):
         keep, epoch = self.slots[slot].trial_index, self.slots[slot].epoch
         self.evict(slot)
@@ -486,10 +543,11 @@ class SeqPackEngine(PackEngine):
         return t.data_ptr()
 
     def _op(self, tag: str, groups: np.ndarray, shapes: List[Tuple[int, int, int, int]], mode2_splits: int = 1) -> SeqOp:
-        """Upload one grouped GEMM: ``shapes`` = (slot, output rows, output cols, weight) per group."""
-        def count(edge):
-            return sum(((r + edge - 1) // edge) * ((c + edge - 1) // edge) for _, r, c, _ in shapes)
-        edge = SMALL_TILE if count(TILE) * mode2_splits < F32_SMALL_TILES else TILE
+        """Upload one grouped GEMM: ``shapes`` = (group, output rows, output cols, weight) per group.  Always 64 x 64
+        tiles: the layers of this family are 32 to 512 wide with contractions of 32 to 512 (the weight gradients: the
+        token count), and 128-tiles measured slower at every pack size (16 / 64 / 128 slots: 57 / 38 / 34 us per slot
+        step against 68 / 46 / 38)."""
+        edge = SMALL_TILE
         tiles = balanced_tiles([(g, (r + edge - 1) // edge, (c + edge - 1) // edge, w) for g, r, c, w in shapes],
                                mode2_splits)
         op = SeqOp()

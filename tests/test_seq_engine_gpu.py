@@ -197,3 +197,51 @@ def test_unsupported_shapes_fall_back_to_the_per_slot_engine():
     tr = _trainable(engine="auto")
     assert engine_seq.supports(tr, {"d_model": 48, "num_heads": 4, "num_layers": 1}) is not None       # heads 12 wide
     assert engine_seq.supports(tr, {"d_model": 64, "num_heads": 4, "num_layers": 2}) is None
+
+
+def test_two_ranks_move_sequence_trials_as_device_slabs_without_changing_them():
+    """Two executors wired through threads, both packs on this GPU: every even trial stops after its first epoch, so one
+    rank runs empty and trials move over as raw device slabs; no trial's numbers change against the run without moves."""
+    import threading
+    import mitune
+    from mitune import tune
+    from mitune.packed import PackedExecutor
+    from mitune.parallel.comm import ThreadComm
+    from mitune.schedulers import ASHAScheduler
+
+    class StopEven(ASHAScheduler):
+        def on_batch_result(self, runner, trials, results):
+            return [self.STOP if (t.index % 2 == 0 or r["training_iteration"] >= 3) else self.CONTINUE
+                    for t, r in zip(trials, results)]
+
+    space = {"d_model": tune.choice([32, 64]), "num_heads": tune.choice([2, 4]), "num_layers": tune.choice([1, 2]),
+             "dropout": tune.uniform(0.1, 0.3), "learning_rate": tune.loguniform(1e-4, 1e-2), "weight_decay": 1e-4}
+
+    def search(gap):
+        comms = ThreadComm.make(2)
+        out, errs = [None, None], []
+
+        def body(r):
+            try:
+                tr = _trainable(engine="auto", capacity=4, rebalance_gap=gap)
+                ex = PackedExecutor(tr, comm=comms[r], device=torch.device("cuda", 0), capacity=4, seed=0)
+                an = mitune.run(tr, config=space, num_samples=8, executor=ex, seed=0, verbose=0,
+                                scheduler=StopEven(metric="validation_loss", mode="min", max_t=3))
+                out[r] = ({t.trial_id: (t.training_iteration, t.last_result["validation_loss"], t.last_result["train_loss"])
+                           for t in an.trials}, an.stats["migrations"], an.stats["engine"])
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+                comms[r].hub.barrier.abort()
+
+        ths = [threading.Thread(target=body, args=(r,)) for r in range(2)]
+        [t.start() for t in ths]
+        [t.join(timeout=100) for t in ths]
+        if errs:
+            raise errs[0]
+        assert out[0] == out[1]
+        return out[0]
+
+    res, moves, engine = search(2)
+    res0, moves0, _ = search(0)
+    assert engine == "seq" and moves >= 1 and moves0 == 0
+    assert res == res0
