@@ -422,7 +422,7 @@ def test_packed_search_over_the_sample_space_on_gpu():
     from mitune.schedulers import ASHAScheduler
     tl, vl = create_dummy_data(num_samples=400, seq_len=20, input_size=6)
     tr = PackedTrainable(model="simple_transformer", train=tuple(tl.dataset.tensors), val=tuple(vl.dataset.tensors),
-                         max_epochs=3, dtype="f32", capacity=4, model_kwargs={"batch_size": 32, "optimizer": "adamw"})
+                         max_epochs=3, dtype="f32", engine="graph", capacity=4, model_kwargs={"batch_size": 32, "optimizer": "adamw"})
     an = tune.run(tr, config={"d_model": tune.choice([32, 64]), "num_heads": tune.choice([2, 4]),
                               "num_layers": tune.choice([1, 2]), "dropout": tune.uniform(0.1, 0.3),
                               "learning_rate": tune.loguniform(1e-4, 1e-2), "weight_decay": 1e-4},
@@ -441,7 +441,7 @@ def test_trials_prepared_during_a_running_epoch_end_like_trials_built_on_demand(
 
     def search():
         tr = PackedTrainable(model="simple_transformer", train=tuple(tl.dataset.tensors), val=tuple(vl.dataset.tensors),
-                             max_epochs=2, dtype="f32", capacity=3, model_kwargs={"batch_size": 32, "optimizer": "adamw"})
+                             max_epochs=2, dtype="f32", engine="graph", capacity=3, model_kwargs={"batch_size": 32, "optimizer": "adamw"})
         an = tune.run(tr, config={"d_model": tune.choice([32, 64]), "num_heads": 2, "num_layers": tune.choice([1, 2]),
                                   "dropout": 0.1, "learning_rate": tune.loguniform(1e-4, 1e-2)},
                       num_samples=9, local_dir=None, verbose=0, seed=2, metric="validation_loss", mode="min",
@@ -557,7 +557,7 @@ def _two_rank_worker(rank, world, port, out_dir):
     comm = TorchDistComm(backend="gloo", device=torch.device("cpu"), rank=rank, world_size=world)
     tl, vl = create_dummy_data(num_samples=300, seq_len=16, input_size=6)
     tr = PackedTrainable(model="simple_transformer", train=tuple(tl.dataset.tensors), val=tuple(vl.dataset.tensors),
-                         max_epochs=3, dtype="f32", capacity=3, model_kwargs={"batch_size": 32, "optimizer": "adamw"})
+                         max_epochs=3, dtype="f32", engine="graph", capacity=3, model_kwargs={"batch_size": 32, "optimizer": "adamw"})
     ex = PackedExecutor(tr, comm=comm, device=dev, capacity=3, seed=0)
     an = mitune.run(tr, config={"d_model": tune.choice([32, 64]), "num_heads": 2, "num_layers": tune.choice([1, 2]),
                                 "dropout": 0.1, "learning_rate": tune.loguniform(1e-4, 1e-2)},
