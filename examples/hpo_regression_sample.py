@@ -6,9 +6,10 @@ Counterpart of /root/reference/ray-tune-hpo-regression-sample.py:152-172 with th
 
     python examples/hpo_regression_sample.py [--num-samples 10] [--local-dir ./mitune_results] [--epochs 5] [--packed K]
 
-``--packed K`` hands the same search to the packed executor: K trials resident on the GPU at a time, every one with a
-captured training step, replayed over a few HIP streams by one host thread (several times the throughput of running
-the function trainable one trial at a time; the result tree on disk has the same layout).
+``--packed K`` hands the same search to the packed executor: K trials resident on the GPU at a time, all of them advancing
+in shared kernel launches (grouped GEMMs, grouped attention / LayerNorm; ``packed/engine_seq.py``) -- hundreds of times
+the throughput of one trial at a time; the result tree on disk has the same layout, ``--checkpoint`` adds a
+``checkpoint_<iter>/model.pt`` per trial that loads into the plain ``SimpleTransformerModel``.
 """
 import argparse
 import os
@@ -31,6 +32,7 @@ def main():
     ap.add_argument("--local-dir", default="./mitune_results")
     ap.add_argument("--noise-target", action="store_true", help="target independent of the inputs, like the reference")
     ap.add_argument("--packed", type=int, default=0, help="trial slots of the packed executor (0: function trainable)")
+    ap.add_argument("--checkpoint", action="store_true", help="packed: write every trial's final weights")
     args = ap.parse_args()
     logger = setup_logging(args.local_dir, prefix="mitune_workflow_sample_run")
     logger.info("Starting the mitune workflow...")
@@ -40,6 +42,7 @@ def main():
         trainable = PackedTrainable(model="simple_transformer", train=tuple(train_loader.dataset.tensors),
                                     val=tuple(val_loader.dataset.tensors), max_epochs=args.epochs, dtype="f32",
                                     capacity=args.packed, name="train_dummy_model_packed",
+                                    checkpoint_at_end=args.checkpoint,
                                     model_kwargs={"batch_size": 32, "optimizer": "adamw"})
     else:
         trainable = tune.with_parameters(train_dummy_model, data_loader=train_loader, val_loader=val_loader,
