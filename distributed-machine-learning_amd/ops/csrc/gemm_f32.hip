@@ -331,23 +331,24 @@ __global__ __launch_bounds__(F32_THREADS) void mt_gemm_f32_bwd_kernel(const MtGe
     mt_head_reduce_body(hr.slots, hr.ids, step, hr.scratch, hr.max_chunks, hr.rec, b - n_wtiles - n_dtiles);
 }
 
-// tile_edge: 128 (two-stage, two-barrier pipeline) or 64 (three stages, one barrier per K-step); the tile list must
-// have been built with the same edge.
+// tile_edge: 128 or 64 (both on the two-stage, two-barrier pipeline: 32 KB of LDS per 64-tile workgroup, so five of
+// them fit a CU and a launch of four tiles per CU has no second round; measured 7-22 % faster than the three-stage,
+// one-barrier form, which 65 still selects for comparison); the tile list must have been built with the same edge.
 extern "C" int mt_gemm_f32_launch(int mode, const MtGemmGroup* groups, const MtTile* tiles, int ntiles, int step,
                                   int flags, int arow0, int i_override, int ksplits, size_t split_stride, int tile_edge,
                                   hipStream_t stream) {
   if (ntiles <= 0) return 0;
   if (ksplits < 1 || ksplits > 127 || (mode != 2 && ksplits != 1)) return -5;
-  if (tile_edge != 128 && tile_edge != 64) return -7;
+  if (tile_edge != 128 && tile_edge != 64 && tile_edge != 65) return -7;      // 65: 64-tiles on the three-stage pipeline
   dim3 grid(ntiles), block(F32_THREADS);
 #define MT_F32_GO(M, N, T_, KS, SS)                                                                                       \
   hipLaunchKernelGGL((mt_gemm_f32_kernel<M, N, T_>), grid, block, 0, stream, groups, tiles, step, flags, arow0, i_override, \
                      KS, SS, mt_step_base_tls)
-  const bool big = tile_edge == 128;
+  const bool big = tile_edge == 128, two = tile_edge == 64;
   switch (mode) {
-    case 0: if (big) MT_F32_GO(0, 2, 128, 1, (size_t)0); else MT_F32_GO(0, 3, 64, 1, (size_t)0); break;
-    case 1: if (big) MT_F32_GO(1, 2, 128, 1, (size_t)0); else MT_F32_GO(1, 3, 64, 1, (size_t)0); break;
-    case 2: if (big) MT_F32_GO(2, 2, 128, ksplits, split_stride); else MT_F32_GO(2, 3, 64, ksplits, split_stride); break;
+    case 0: if (big) MT_F32_GO(0, 2, 128, 1, (size_t)0); else if (two) MT_F32_GO(0, 2, 64, 1, (size_t)0); else MT_F32_GO(0, 3, 64, 1, (size_t)0); break;
+    case 1: if (big) MT_F32_GO(1, 2, 128, 1, (size_t)0); else if (two) MT_F32_GO(1, 2, 64, 1, (size_t)0); else MT_F32_GO(1, 3, 64, 1, (size_t)0); break;
+    case 2: if (big) MT_F32_GO(2, 2, 128, ksplits, split_stride); else if (two) MT_F32_GO(2, 2, 64, ksplits, split_stride); else MT_F32_GO(2, 3, 64, ksplits, split_stride); break;
     default: return -1;
   }
 #undef MT_F32_GO
@@ -360,9 +361,12 @@ extern "C" int mt_gemm_f32_bwd_head_launch(const MtGemmGroup* wgroups, const MtT
                                            hipStream_t stream) {
   if (n_wtiles + n_dtiles + hr.n_slots <= 0) return 0;
   if (ksplits < 1 || ksplits > 127) return -5;
-  if (tile_edge != 128 && tile_edge != 64) return -7;
+  if (tile_edge != 128 && tile_edge != 64 && tile_edge != 65) return -7;
   dim3 grid(n_wtiles + n_dtiles + hr.n_slots), block(F32_THREADS);
-  if (tile_edge == 128)
+  if (tile_edge == 64)
+    hipLaunchKernelGGL((mt_gemm_f32_bwd_kernel<2, 64>), grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles,
+                       n_dtiles, step, ksplits, split_stride, mt_step_base_tls, hr);
+  else if (tile_edge == 128)
     hipLaunchKernelGGL((mt_gemm_f32_bwd_kernel<2, 128>), grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles,
                        n_dtiles, step, ksplits, split_stride, mt_step_base_tls, hr);
   else
@@ -417,11 +421,80 @@ extern "C" int mt_gemm_f32_single_launch(int mode, const void* A, const void* B,
 #define MT_F32_SINGLE(M_) \
   do { \
     if (T == 128) hipLaunchKernelGGL((mt_gemm_f32_single_kernel<M_, 2, 128>), grid, block, 0, stream, g, tiles_i, tiles_j, flags); \
-    else hipLaunchKernelGGL((mt_gemm_f32_single_kernel<M_, 3, 64>), grid, block, 0, stream, g, tiles_i, tiles_j, flags); \
+    else hipLaunchKernelGGL((mt_gemm_f32_single_kernel<M_, 2, 64>), grid, block, 0, stream, g, tiles_i, tiles_j, flags); \
   } while (0)
   if (mode == 0) MT_F32_SINGLE(0);
   else if (mode == 1) MT_F32_SINGLE(1);
   else MT_F32_SINGLE(2);
 #undef MT_F32_SINGLE
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Weight (+ bias) gradient of ONE f32 dense layer with the contraction over the rows split into `ksplits` slices:
+// dW [I x J] = dY^T X is a handful of output tiles with a contraction as long as the batch has token rows, so without a
+// split a few workgroups would each walk hundreds of K-steps while the rest of the chip idles.  Slice s writes its
+// partial products to arena + s * slab (dW at offset 0, db at offset I * J); mt_slab_sum_kernel adds the slices in
+// index order (fixed order: bitwise repeatable, no atomics).
+template <int NSTAGE, int T>
+__global__ __launch_bounds__(F32_THREADS) void mt_wgrad_f32_single_kernel(MtGemmGroup g, int tiles_i, int tiles_j,
+                                                                          int ksplits, size_t slab, int flags) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * 2 * T * 128];
+  const int b = blockIdx.x;
+  const int n = tiles_i * tiles_j * ksplits;
+  const int per = (n + 7) / 8;
+  const int t = (b % 8) * per + b / 8;        // consecutive work items of one XCD share the operands' column blocks
+  if (t >= n) return;
+  const int split = t % ksplits, tt = t / ksplits;
+  MtTile tile;
+  tile.group = 0;
+  tile.ti = (int16_t)((tt / tiles_j) | (split << 8));
+  tile.tj = (int16_t)(tt % tiles_j);
+  f32_gemm_tile<2, NSTAGE, T>(&g, tile, 0, flags, 0, 0, ksplits, slab, lds);
+}
+
+__global__ __launch_bounds__(256) void mt_slab_sum_kernel(const float* __restrict__ arena, float* __restrict__ out, long n,
+                                                          int ksplits, size_t slab) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n) {
+    f32x4 acc = *reinterpret_cast<const f32x4*>(arena + i);
+    for (int s = 1; s < ksplits; ++s) acc += *reinterpret_cast<const f32x4*>(arena + (size_t)s * slab + i);
+    *reinterpret_cast<f32x4*>(out + i) = acc;
+  } else {
+    for (long k = i; k < n; ++k) {
+      float acc = arena[k];
+      for (int s = 1; s < ksplits; ++s) acc += arena[(size_t)s * slab + k];
+      out[k] = acc;
+    }
+  }
+}
+
+// out[0 .. n) = sum over s of arena[s * slab + (0 .. n)), slices added in index order (slab and out 16-byte aligned).
+extern "C" int mt_slab_sum_launch(const float* arena, float* out, long n, int ksplits, size_t slab, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (ksplits < 1 || !arena || !out || (slab & 3) || (((uintptr_t)arena | (uintptr_t)out) & 15)) return -2;
+  hipLaunchKernelGGL(mt_slab_sum_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, arena, out, n, ksplits,
+                     slab);
+  return (int)hipGetLastError();
+}
+
+// dY: [M][I] (row stride I), X: [M][J]; arena: ksplits slices of `slab` floats (slab >= I * J + I, a multiple of 4).
+// with_bias != 0: column sums of dY go to offset I * J of every slice.
+extern "C" int mt_wgrad_f32_single_launch(const void* dY, const void* X, float* arena, int M, int I, int J, int ksplits,
+                                          size_t slab, int with_bias, hipStream_t stream) {
+  if (M <= 0 || I <= 0 || J <= 0) return 0;
+  if ((I & 3) || (J & 3) || ksplits < 1 || ksplits > 127 || (slab & 3) || slab < (size_t)I * J + (with_bias ? I : 0)) return -2;
+  constexpr int T = 64;
+  const int tiles_i = (I + T - 1) / T, tiles_j = (J + T - 1) / T;
+  if (tiles_i > 255 || tiles_j > 32767) return -2;
+  MtGemmGroup g = {};
+  g.A = dY; g.B = X; g.C = arena; g.aux = nullptr; g.aux_out = with_bias ? arena + (size_t)I * J : nullptr;
+  g.I = I; g.J = J; g.KK = M;
+  g.lda = I; g.ldb = J; g.ldc = J; g.ldaux = 0;
+  g.active_steps = 1;
+  const int nblocks = ((tiles_i * tiles_j * ksplits + 7) / 8) * 8;
+  hipLaunchKernelGGL((mt_wgrad_f32_single_kernel<2, T>), dim3(nblocks), dim3(F32_THREADS), 0, stream, g, tiles_i, tiles_j,
+                     ksplits, slab, with_bias ? MT_GEMM_FLAG_DBIAS : 0);
   return (int)hipGetLastError();
 }

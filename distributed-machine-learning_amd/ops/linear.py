@@ -10,13 +10,12 @@ through LDS in a fixed order; no workspace and no traffic between workgroups).  
 1600x64x256 29.9 / 6.9, 1600x128x384 27.5 / 13.0, 1600x128x512 28.3 / 15.3, 3200x64x256 43.7 / 18.3; past the bound the
 library's larger LDS-staged tiles catch up (4800x256x768 77.1 / 74.4, 1600x256x1024 37.4 / 40.5) and keep the layer.
 
-On a GPU, under bf16 autocast, with a long
-token dimension (FT-Transformer and sequence-encoder layers see M = batch x tokens ~ 10^4..10^5 rows against a few
-hundred features), the backward's ``dW = dY^T X`` is a long skinny contraction for which the BLAS library picked a
-64x64 tile and no K split (87 TFLOP/s measured).  Here it goes to ``mt_wgrad_single_launch`` (``csrc/gemm.hip``):
-128x128 tiles, the token dimension split over enough workgroups to fill the chip, f32 partial slabs added in a fixed
-order, and the bias gradient produced by the same pass from the tiles it already holds.  Forward and the input
-gradient stay library GEMMs.
+Everything else on a GPU runs on the tile kernels of ``csrc/gemm.hip`` (bf16 autocast: ``DenseBF16``) and
+``csrc/gemm_f32.hip`` (f32: ``DenseF32``): forward with the bias in the epilogue, input gradient, and the weight + bias
+gradient ``dW = dY^T X`` -- a long skinny contraction over the token rows (M = batch x tokens ~ 10^4..10^5 against a few
+hundred features) -- split over enough workgroups to fill the chip, the f32 partial slabs added in a fixed order by one
+small launch.  No BLAS-library GEMM is left in a training step (``MITUNE_OWN_GEMM=0`` restores the library for
+comparison).
 """
 from __future__ import annotations
 
@@ -117,7 +116,36 @@ def _wgrad_bf16(dyc: torch.Tensor, xc: torch.Tensor, out_f: int, in_f: int, has_
     L.check(so.mt_wgrad_single_launch(dyc.data_ptr(), xc.data_ptr(), arena.data_ptr(), db_ptr, M, out_f, in_f,
                                       ksplits, slab, L.raw_stream(xc.device)),
             "mt_wgrad_single_launch")
-    total = arena.sum(0) if ksplits > 1 else arena[0]
+    if ksplits > 1:       # slices added in index order by one launch (weights and bias together)
+        total = torch.empty(slab, device=xc.device, dtype=torch.float32)
+        L.check(so.mt_slab_sum_launch(arena.data_ptr(), total.data_ptr(), out_f * in_f + (out_f if has_bias else 0), ksplits,
+                                      slab, L.raw_stream(xc.device)), "mt_slab_sum_launch")
+    else:
+        total = arena[0]
+    dw = total[:out_f * in_f].view(out_f, in_f)
+    db = total[out_f * in_f:out_f * in_f + out_f] if has_bias else None
+    return dw, db
+
+
+def _wgrad_f32(dyc: torch.Tensor, xc: torch.Tensor, out_f: int, in_f: int, has_bias: bool):
+    """dW [out, in] and db [out] of an f32 layer: the contraction over the token rows is split so that the launch has
+    about ``SPLIT_TARGET`` workgroups (a slice keeps at least 4 K-steps of 32 rows), slices summed in index order."""
+    from . import lib as L
+    so = L.load()
+    M = xc.shape[0]
+    tiles = ((out_f + 63) // 64) * ((in_f + 63) // 64)
+    ksplits = max(1, min(127, (M + 127) // 128, (SPLIT_TARGET + tiles - 1) // tiles))
+    slab = (out_f * in_f + out_f + 63) // 64 * 64
+    arena = torch.empty(ksplits, slab, device=xc.device, dtype=torch.float32)
+    stream = L.raw_stream(xc.device)
+    L.check(so.mt_wgrad_f32_single_launch(dyc.data_ptr(), xc.data_ptr(), arena.data_ptr(), M, out_f, in_f, ksplits, slab,
+                                          1 if has_bias else 0, stream), "mt_wgrad_f32_single_launch")
+    if ksplits > 1:
+        total = torch.empty(slab, device=xc.device, dtype=torch.float32)
+        L.check(so.mt_slab_sum_launch(arena.data_ptr(), total.data_ptr(), out_f * in_f + (out_f if has_bias else 0), ksplits,
+                                      slab, stream), "mt_slab_sum_launch")
+    else:
+        total = arena[0]
     dw = total[:out_f * in_f].view(out_f, in_f)
     db = total[out_f * in_f:out_f * in_f + out_f] if has_bias else None
     return dw, db
@@ -214,11 +242,7 @@ class DenseF32(torch.autograd.Function):
             L.check(so.mt_gemm_f32_single_launch(1, dyc.data_ptr(), wc.data_ptr(), dx.data_ptr(), None, None, M, in_f, out_f,
                                                  out_f, in_f, in_f, 0, L.raw_stream(dev)), "mt_gemm_f32_single_launch")
             dx = dx.view(ctx.x_shape)
-        dw = torch.empty(out_f, in_f, device=dev, dtype=torch.float32)
-        db = torch.empty(out_f, device=dev, dtype=torch.float32) if ctx.has_bias else None
-        L.check(so.mt_gemm_f32_single_launch(2, dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), None,
-                                             db.data_ptr() if db is not None else None, out_f, in_f, M, out_f, in_f, in_f,
-                                             1 if db is not None else 0, L.raw_stream(dev)), "mt_gemm_f32_single_launch")
+        dw, db = _wgrad_f32(dyc, xc, out_f, in_f, ctx.has_bias)
         return dx, dw, db
 
 
