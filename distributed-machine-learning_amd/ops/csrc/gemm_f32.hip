@@ -453,19 +453,32 @@ __global__ __launch_bounds__(F32_THREADS) void mt_wgrad_f32_single_kernel(MtGemm
   f32_gemm_tile<2, NSTAGE, T>(&g, tile, 0, flags, 0, 0, ksplits, slab, lds);
 }
 
+// Thread -> one float4 column group; the slices are walked with four running sums (slice s goes to sum s % 4) so that
+// eight loads are in flight instead of one dependent chain, and the four sums are combined as (0 + 1) + (2 + 3): a fixed
+// order, independent of the launch geometry.
 __global__ __launch_bounds__(256) void mt_slab_sum_kernel(const float* __restrict__ arena, float* __restrict__ out, long n,
                                                           int ksplits, size_t slab) {
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   if (i + 3 < n) {
-    f32x4 acc = *reinterpret_cast<const f32x4*>(arena + i);
-    for (int s = 1; s < ksplits; ++s) acc += *reinterpret_cast<const f32x4*>(arena + (size_t)s * slab + i);
-    *reinterpret_cast<f32x4*>(out + i) = acc;
+    f32x4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= ksplits; s += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(arena + (size_t)(s + k) * slab + i);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k & 3] += v[k];
+    }
+    for (; s < ksplits; ++s) acc[s & 3] += *reinterpret_cast<const f32x4*>(arena + (size_t)s * slab + i);
+    *reinterpret_cast<f32x4*>(out + i) = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   } else {
     for (long k = i; k < n; ++k) {
-      float acc = arena[k];
-      for (int s = 1; s < ksplits; ++s) acc += arena[(size_t)s * slab + k];
-      out[k] = acc;
+      float a4[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < ksplits; ++s) a4[s & 3] += arena[(size_t)s * slab + k];
+      out[k] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
   }
 }
