@@ -18,8 +18,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .transformer import SelfAttention
-from ..ops.elementwise import dropout
-from ..ops.layernorm import residual_layer_norm
+from ..ops.elementwise import reglu_dropout
+from ..ops.layernorm import residual_layer_norm_mixed
 from ..ops.linear import linear
 
 
@@ -44,8 +44,8 @@ class ReGLU(nn.Module):
         self.p = dropout
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        a, g = linear(x, self.up.weight, self.up.bias).chunk(2, dim=-1)
-        return linear(dropout(a * F.relu(g), self.p, self.training), self.down.weight, self.down.bias)
+        u = linear(x, self.up.weight, self.up.bias)                     # [a | g]
+        return linear(reglu_dropout(u, self.p, self.training), self.down.weight, self.down.bias)
 
 
 class FTBlock(nn.Module):
@@ -57,12 +57,18 @@ class FTBlock(nn.Module):
         self.norm1, self.norm2 = nn.LayerNorm(d_token), nn.LayerNorm(d_token)
         self.p = residual_dropout
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, x16=None, last: bool = False):
+        """``x``: the f32 residual stream; ``x16``: its bf16 copy when the caller has one (under bf16 autocast the GEMMs
+        read that, and the LayerNorm kernels take the GEMMs' bf16 outputs as they are: no cast kernels in between).
+        Returns the new stream and its bf16 copy (``None`` for the last block or outside autocast)."""
         p = self.p if self.training else 0.0
-        a, _ = self.attn(x)
-        x = residual_layer_norm(a.float(), x.float(), self.norm1.weight, self.norm1.bias, self.norm1.eps, dropout_p=p)
-        f = self.ffn(x)
-        return residual_layer_norm(f.float(), x, self.norm2.weight, self.norm2.bias, self.norm2.eps, dropout_p=p)
+        amp = torch.is_autocast_enabled() and x.is_cuda
+        a, _ = self.attn(x16 if x16 is not None else x)
+        x, x16 = residual_layer_norm_mixed(a, x.float(), self.norm1.weight, self.norm1.bias, self.norm1.eps, dropout_p=p,
+                                           want_bf16=amp)
+        f = self.ffn(x16 if x16 is not None else x)
+        return residual_layer_norm_mixed(f, x, self.norm2.weight, self.norm2.bias, self.norm2.eps, dropout_p=p,
+                                         want_bf16=amp and not last)
 
 
 class FTTransformer(nn.Module):
@@ -80,9 +86,9 @@ class FTTransformer(nn.Module):
         self.head = nn.Linear(d_token, 1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:            # [B, F] -> [B]
-        t = self.tokenizer(x)
-        for blk in self.blocks:
-            t = blk(t)
+        t, t16 = self.tokenizer(x), None
+        for i, blk in enumerate(self.blocks):
+            t, t16 = blk(t, t16, last=i == len(self.blocks) - 1)
         cls = t[:, -1, :]
         return linear(F.relu(self.head_norm(cls.float())), self.head.weight, self.head.bias).squeeze(-1)
 

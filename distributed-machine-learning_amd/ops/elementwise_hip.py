@@ -130,3 +130,32 @@ class FusedReluDropout(torch.autograd.Function):
         L.check(so.mt_relu_dropout_bwd_launch(dyc.data_ptr(), y.data_ptr(), dx.data_ptr(), dyc.numel(), ctx.p,
                                               0 if y.dtype == torch.float32 else 1, _stream(dy)), "mt_relu_dropout_bwd_launch")
         return dx, None, None
+
+
+class FusedReGLUDropout(torch.autograd.Function):
+    """``dropout(a * relu(g))`` for ``u = [a | g]`` in bf16: one launch per direction (``csrc/dropout.hip``); the backward
+    writes both halves of ``du`` in place of five element-wise launches and a concatenation."""
+
+    @staticmethod
+    def forward(ctx, u, seed, p: float):
+        so = L.load()
+        h = u.shape[-1] // 2
+        uc = u.contiguous()
+        rows = uc.numel() // (2 * h)
+        out = torch.empty(u.shape[:-1] + (h,), device=u.device, dtype=torch.bfloat16)
+        L.check(so.mt_reglu_fwd_launch(uc.data_ptr(), out.data_ptr(), rows, h, seed.data_ptr() if seed is not None else None,
+                                       float(p), _stream(u)), "mt_reglu_fwd_launch")
+        ctx.save_for_backward(uc)
+        ctx.seed, ctx.p, ctx.h, ctx.rows = seed, float(p), h, rows
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        so = L.load()
+        (uc,) = ctx.saved_tensors
+        dc = dout.to(torch.bfloat16).contiguous()
+        du = torch.empty_like(uc)
+        L.check(so.mt_reglu_bwd_launch(uc.data_ptr(), dc.data_ptr(), du.data_ptr(), ctx.rows, ctx.h,
+                                       ctx.seed.data_ptr() if ctx.seed is not None else None, ctx.p, _stream(dout)),
+                "mt_reglu_bwd_launch")
+        return du, None, None

@@ -38,3 +38,24 @@ def residual_layer_norm(x: torch.Tensor, residual: torch.Tensor, weight: torch.T
         from .elementwise import keep_mask
         keep = keep_mask(x.shape, dropout_p, x.device)
     return residual_layer_norm_reference(x, residual, weight, bias, eps, keep, dropout_p)
+
+
+def residual_layer_norm_mixed(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
+                              eps: float = 1e-5, dropout_p: float = 0.0, want_bf16: bool = True):
+    """``(y, y16)``: ``y = LayerNorm(residual + dropout(x))`` in f32 (the residual stream) and its bf16 copy for the next
+    GEMM (``None`` when ``want_bf16`` is false).  ``x`` may be the bf16 output of an autocast GEMM: on a GPU with rows of at
+    most 256 columns one kernel per direction does all of it (``csrc/layernorm.hip``, mixed forms); elsewhere the f32 path
+    plus explicit casts."""
+    d = x.shape[-1]
+    if (x.is_cuda and d <= 256 and d % 4 == 0 and x.dtype in (torch.float32, torch.bfloat16)
+            and residual.dtype == torch.float32):
+        from .layernorm_hip import MixedResidualLayerNorm, available
+        if available():
+            seed = None
+            if dropout_p > 0.0:
+                from .rng import next_seed
+                seed = next_seed(x.device)
+            out = MixedResidualLayerNorm.apply(x, residual, weight, bias, eps, dropout_p, seed, bool(want_bf16))
+            return out if want_bf16 else (out, None)
+    y = residual_layer_norm(x.float(), residual.float(), weight, bias, eps, dropout_p)
+    return y, (y.to(torch.bfloat16) if want_bf16 else None)

@@ -345,3 +345,66 @@ def test_small_unaligned_f32_layer_stays_on_own_kernels():
     ref = x.double() @ w.detach().double().t() + b.detach().double()
     torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(w.grad.double(), x.double().reshape(-1, 10).sum(0).expand(64, 10), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("x_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,d", [(65 * 33, 192), (1000, 64), (37, 256)])
+def test_mixed_precision_layer_norm_matches_f32_reference(rows, d, x_dtype):
+    """bf16 (or f32) branch input, f32 residual, two outputs (f32 + bf16 copy), two incoming gradients added in-kernel."""
+    from mitune.ops.layernorm import residual_layer_norm_mixed
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(rows, d, device="cuda", generator=g).to(x_dtype).requires_grad_(True)
+    res = torch.randn(rows, d, device="cuda", generator=g).requires_grad_(True)
+    w = (1 + 0.1 * torch.randn(d, device="cuda", generator=g)).requires_grad_(True)
+    b = (0.1 * torch.randn(d, device="cuda", generator=g)).requires_grad_(True)
+    gy = torch.randn(rows, d, device="cuda", generator=g)
+    g16 = torch.randn(rows, d, device="cuda", generator=g).to(torch.bfloat16)
+    y, y16 = residual_layer_norm_mixed(x, res, w, b, 1e-5, 0.0, want_bf16=True)
+    assert y.dtype == torch.float32 and y16.dtype == torch.bfloat16
+    ((y * gy).sum() + (y16.float() * g16.float()).sum()).backward()
+    xr, rr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, res, w, b))
+    yr = torch.nn.functional.layer_norm(rr + xr, (d,), wr, br, 1e-5)
+    (yr * (gy.double() + g16.double())).sum().backward()
+    torch.testing.assert_close(y.double(), yr, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(y16.double(), yr, rtol=1e-2, atol=1e-2)
+    assert x.grad.dtype == x_dtype
+    tol = 2e-2 if x_dtype == torch.bfloat16 else 1e-4
+    torch.testing.assert_close(x.grad.double(), xr.grad, rtol=tol, atol=tol)
+    torch.testing.assert_close(res.grad.double(), rr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(w.grad.double(), wr.grad, rtol=1e-3, atol=1e-3 * float(wr.grad.abs().max()))
+    torch.testing.assert_close(b.grad.double(), br.grad, rtol=1e-3, atol=1e-3 * float(br.grad.abs().max()))
+    # one output only, dropout on: the mask of the backward pass is the forward's
+    x2 = torch.randn(rows, d, device="cuda", generator=g).to(x_dtype).requires_grad_(True)
+    zero_res = torch.zeros(rows, d, device="cuda")
+    y2, none = residual_layer_norm_mixed(x2, zero_res, torch.ones(d, device="cuda"), torch.zeros(d, device="cuda"), 1e-5, 0.5,
+                                         want_bf16=False)
+    assert none is None and torch.isfinite(y2).all()
+    y2.sum().backward()
+    assert torch.isfinite(x2.grad.float()).all()
+
+
+def test_reglu_dropout_matches_reference_and_reuses_its_mask():
+    from mitune.ops.elementwise import reglu_dropout
+    g = torch.Generator(device="cuda").manual_seed(6)
+    rows, h = 65 * 40, 256
+    u = torch.randn(rows, 2 * h, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True)
+    dout = torch.randn(rows, h, device="cuda", generator=g).to(torch.bfloat16)
+    out = reglu_dropout(u, 0.0, True)
+    out.backward(dout)
+    ur = u.detach().float().requires_grad_(True)
+    a, gg = ur.chunk(2, -1)
+    ref = a * torch.relu(gg)
+    ref.backward(dout.float())
+    torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(u.grad.float(), ur.grad, rtol=1e-2, atol=1e-2)
+    # dropout: about half the positive-gate outputs survive, scaled by 2; the gradient is zero exactly where the output is
+    u2 = (torch.rand(rows, 2 * h, device="cuda", generator=g) + 0.5).to(torch.bfloat16).requires_grad_(True)
+    o2 = reglu_dropout(u2, 0.5, True)
+    kept = (o2 != 0).float().mean().item()
+    assert 0.47 < kept < 0.53
+    a2, g2 = u2.detach().float().chunk(2, -1)
+    torch.testing.assert_close(o2.float()[o2 != 0], (2 * a2 * g2)[o2 != 0], rtol=2e-2, atol=2e-2)
+    o2.backward(torch.ones_like(o2))
+    da = u2.grad[:, :h]
+    assert torch.equal(da != 0, o2 != 0)
+    assert torch.equal(reglu_dropout(u2, 0.5, False), reglu_dropout(u2, 0.0, True))       # evaluation: no mask
