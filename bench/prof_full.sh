@@ -1,6 +1,7 @@
 #!/bin/bash
 # Kernel trace of the reference's full workflow through the packed executor: bench/prof_full.sh <tag> [extra args]
 set -e
+trap 'rm -rf $OUT' EXIT      # the raw trace is tens of megabytes: only the summary travels back
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_full_$TAG
@@ -18,8 +19,11 @@ tot = sum(float(r[2]) for r in rows[1:])
 aten = sum(float(r[2]) for r in rows[1:] if "at::native" in r[0] or "rocclr" in r[0])
 cijk = sum(float(r[2]) for r in rows[1:] if r[0].startswith("Cijk"))
 print(f"kernel time {tot/1e9:.2f} s, framework kernels {100*aten/tot:.1f} %, BLAS-library kernels {100*cijk/tot:.1f} %")
-for r in rows[1:26]:
+for r in rows[1:22]:
     print(f"{float(r[4]):6.2f}% calls {int(r[1]):7d} avg {float(r[3])/1e3:8.1f}us  {r[0][:100]}")
+for r in rows[1:]:
+    if r[0].startswith("Cijk"):
+        print(f"BLAS {float(r[4]):6.2f}% calls {int(r[1]):7d} avg {float(r[3])/1e3:8.1f}us  {r[0][:150]}")
 PY
 grep workload $GRAFT_REPO_ROOT/gpurun_out/prof_full_$TAG.log | cut -c1-400
 rm -rf $OUT      # the raw trace is tens of megabytes: only the summary travels back

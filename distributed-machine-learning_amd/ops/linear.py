@@ -86,6 +86,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
                 return SmallLinear.apply(x, weight, bias)
             if out_f % 4 == 0 and in_f % 4 == 0:
                 return DenseF32.apply(x, weight, bias)
+            if out_f % 4 == 0 and torch.is_grad_enabled() and x.numel() // in_f >= MIN_ROWS:
+                # a big layer whose rows are not 16-byte aligned (81 input features): zero columns up to the next
+                # multiple of 4 on both operands keep it on the tile kernels; autograd slices the weight gradient back
+                pad = (-in_f) % 4
+                return DenseF32.apply(F.pad(x, (0, pad)), F.pad(weight, (0, pad)), bias)
             if _small_inference(x, weight, bias):
                 return SmallLinear.forward(_NoCtx(), x, weight, bias)
     if _eligible(x, weight):

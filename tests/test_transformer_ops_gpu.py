@@ -408,3 +408,19 @@ def test_reglu_dropout_matches_reference_and_reuses_its_mask():
     da = u2.grad[:, :h]
     assert torch.equal(da != 0, o2 != 0)
     assert torch.equal(reglu_dropout(u2, 0.5, False), reglu_dropout(u2, 0.0, True))       # evaluation: no mask
+
+
+def test_big_unaligned_f32_layer_is_padded_onto_the_tile_kernels():
+    """81 input features at 24 576 rows: too big for the small-layer kernels, rows not 16-byte aligned."""
+    from mitune.ops.linear import DenseF32, linear
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(256, 96, 81, device="cuda", generator=g)
+    w = (torch.randn(512, 81, device="cuda", generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(512, device="cuda", generator=g).requires_grad_(True)
+    y = linear(x, w, b)
+    y.backward(torch.ones_like(y))
+    ref = x.double() @ w.detach().double().t() + b.detach().double()
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-4)
+    assert w.grad.shape == (512, 81)
+    torch.testing.assert_close(w.grad.double(), x.double().reshape(-1, 81).sum(0).expand(512, 81), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(b.grad.double(), torch.full((512,), 256.0 * 96, device="cuda", dtype=torch.float64))
