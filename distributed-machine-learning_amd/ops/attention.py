@@ -65,9 +65,17 @@ def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kind: str
     return attention_reference(q, k, v, kind, keep, dropout_p)
 
 
+WIDE_HEAD_DIM = 128      # heads of 65..128 elements fit the kernels' LDS budget for sequences of at most WIDE_MAX_SEQ tokens
+WIDE_MAX_SEQ = 96
+
+
 def _kernel_envelope(t: torch.Tensor, S: int, dk: int, dv: int) -> bool:
-    return (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and S <= MAX_SEQ and 0 < dk <= MAX_HEAD_DIM
-            and 0 < dv <= MAX_HEAD_DIM and dk % 8 == 0 and dv % 8 == 0)
+    """Strided (projection-output) operands: any head width from 1 to 64 -- widths that are not multiples of 8 are staged
+    element by element -- and up to 128 for short sequences."""
+    if not (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and S <= MAX_SEQ and dk > 0 and dv > 0):
+        return False
+    widest = max(dk, dv)
+    return widest <= MAX_HEAD_DIM or (widest <= WIDE_HEAD_DIM and S <= WIDE_MAX_SEQ)
 
 
 def self_attention_qkv(qkv: torch.Tensor, num_heads: int, dk: int, kind: str = "softmax",
@@ -78,7 +86,7 @@ def self_attention_qkv(qkv: torch.Tensor, num_heads: int, dk: int, kind: str = "
     B, S, W = qkv.shape
     h = num_heads
     dv = (W - 2 * h * dk) // h
-    if _kernel_envelope(qkv, S, dk, dv) and W % 8 == 0:
+    if _kernel_envelope(qkv, S, dk, dv):
         from .attention_hip import FusedQKVAttention, available
         if available():
             seed = None

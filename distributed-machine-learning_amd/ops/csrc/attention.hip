@@ -1,7 +1,8 @@
 // Fused short-sequence self-attention, forward and backward (gfx950, bf16 MFMA, f32 softmax/accumulate).
 //
 // One workgroup (4 waves) owns one (batch, head): Q, K, V (and dO in backward) are staged once into LDS
-// as [row][64] bf16 images; the whole S x S score tile lives in registers.  S <= 128, head dims <= 64.
+// as [row][32 | 64 | 128] bf16 images; the whole S x S score tile lives in registers.  S <= 128, head widths 1..64 (any
+// value; widths that are not multiples of 8 are staged element by element) and 65..128 for S <= 96.
 //
 // Register-level dataflow (no LDS round trip for the probabilities in forward):
 //   * scores are computed TRANSPOSED, S^T[key][query] = K . Q^T, with v_mfma_f32_16x16x32_bf16.  In the
@@ -35,14 +36,31 @@ __device__ __forceinline__ int img_off(int row, int chunk, int cpr) {
 }
 
 // global [rows][cols] (row stride ld elements; bf16, or f32 converted on the way in) -> zero-padded LDS image
-// [rows_pad][PCHQ * 8] bf16
+// [rows_pad][PCHQ * 8] bf16.  Head widths that are multiples of 8 on rows that keep every 8-element chunk 16-byte
+// aligned are loaded as vectors; any other width (heads of 2, 4, 6, 10, 12, 20 ... elements, which a search space with
+// free head counts produces) element by element -- a head is at most S x 128 values, the MFMA work is the same.
 template <int PCHQ, bool F32>
 __device__ __forceinline__ void stage_image(uint8_t* lds, const void* __restrict__ src_, int rows, int cols, long ld,
                                             int rows_pad, int tid) {
+  const bool vec = ((cols & 7) == 0) && ((ld & 7) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(src_) & 15) == 0);
   for (int q = tid; q < rows_pad * PCHQ; q += AT_THREADS) {
     const int r = q / PCHQ, c = q % PCHQ;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (r < rows && c * 8 < cols) {
+    if (r < rows && c * 8 < cols && !vec) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = c * 8 + e;
+        float x = 0.f;
+        if (col < cols) {
+          if constexpr (F32) x = reinterpret_cast<const float*>(src_)[(size_t)r * ld + col];
+          else x = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(src_)[(size_t)r * ld + col]);
+        }
+        f[e] = x;
+      }
+      v = u32x4{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+    } else if (r < rows && c * 8 < cols) {
       if constexpr (F32) {
         const float* src = reinterpret_cast<const float*>(src_) + (size_t)r * ld + c * 8;
         const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
@@ -467,9 +485,10 @@ static int nkb_for(int S) { return ((S + 31) / 32) * 2; }   // pad the sequence 
 // same ldq and pointers dk * H apart); V: row stride ldv; O (and dO): row stride ldo.  f32 != 0: operands and output
 // are f32, otherwise bf16.  All strides and head dims must keep 16-byte alignment of every 8-element chunk.
 static int at_check(int BH, int S, int dk, int dv, int H, long ldq, long ldv, long ldo, int f32) {
-  if (S < 1 || S > 128 || dk > 64 || dv > 64 || (dk & 7) || (dv & 7) || H < 1 || BH % H != 0) return -2;
-  const int al = f32 ? 4 : 8;       // elements per 16 bytes
-  if (ldq % al || ldv % al || ldo % al || ldq < (long)H * dk || ldv < (long)H * dv || ldo < (long)H * dv) return -2;
+  if (S < 1 || S > 128 || dk < 1 || dv < 1 || dk > 128 || dv > 128 || H < 1 || BH % H != 0) return -2;
+  if ((dk > 64 || dv > 64) && S > 96) return -2;      // 128-wide images of a 128-token sequence exceed the LDS (backward)
+  (void)f32;
+  if (ldq < (long)H * dk || ldv < (long)H * dv || ldo < (long)H * dv) return -2;
   return 0;
 }
 
@@ -488,12 +507,13 @@ extern "C" int mt_attn_fwd_strided_launch(const void* Q, const void* K, const vo
   hipLaunchKernelGGL((mt_attn_fwd_kernel<N, P, F>), grid, block, 0, stream, Q, K, V, (const uint8_t*)keep, O, stat, S, dk, \
                      dv, scale, keep_scale, kind, H, ldq, ldv, ldo, seed, thresh)
 #define AT_FWD1(N, P) do { if (f32) AT_FWD2(N, P, true); else AT_FWD2(N, P, false); } while (0)
-#define AT_FWD(N) do { if (narrow) AT_FWD1(N, 4); else AT_FWD1(N, 8); } while (0)
+  const bool wide = dk > 64 || dv > 64;       // heads of 65..128 elements: 256-byte image rows (S <= 96, checked above)
+#define AT_FWD(N) do { if (narrow) AT_FWD1(N, 4); else if (!wide) AT_FWD1(N, 8); else AT_FWD1(N, 16); } while (0)
   switch (nkb_for(S)) {
     case 2: AT_FWD(2); break;
     case 4: AT_FWD(4); break;
     case 6: AT_FWD(6); break;
-    case 8: AT_FWD(8); break;
+    case 8: if (narrow) AT_FWD1(8, 4); else AT_FWD1(8, 8); break;
     default: return -3;
   }
 #undef AT_FWD
@@ -517,12 +537,13 @@ extern "C" int mt_attn_bwd_strided_launch(const void* Q, const void* K, const vo
   hipLaunchKernelGGL((mt_attn_bwd_kernel<N, P, F>), grid, block, 0, stream, Q, K, V, dO, (const uint8_t*)keep, stat, dQ, \
                      dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo, seed, thresh)
 #define AT_BWD1(N, P) do { if (f32) AT_BWD2(N, P, true); else AT_BWD2(N, P, false); } while (0)
-#define AT_BWD(N) do { if (narrow) AT_BWD1(N, 4); else AT_BWD1(N, 8); } while (0)
+  const bool wide = dk > 64 || dv > 64;
+#define AT_BWD(N) do { if (narrow) AT_BWD1(N, 4); else if (!wide) AT_BWD1(N, 8); else AT_BWD1(N, 16); } while (0)
   switch (nkb_for(S)) {
     case 2: AT_BWD(2); break;
     case 4: AT_BWD(4); break;
     case 6: AT_BWD(6); break;
-    case 8: AT_BWD(8); break;
+    case 8: if (narrow) AT_BWD1(8, 4); else AT_BWD1(8, 8); break;
     default: return -3;
   }
 #undef AT_BWD

@@ -98,7 +98,12 @@ def test_transformer_models_run_on_the_fused_kernels():
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind", ["softmax", "relu"])
 @pytest.mark.parametrize("B,S,h,dk,dv,drop", [(4, 50, 4, 16, 16, 0.0), (3, 65, 8, 24, 24, 0.2), (2, 96, 2, 64, 32, 0.1),
-                                              (5, 17, 2, 8, 40, 0.0)])
+                                              (5, 17, 2, 8, 40, 0.0),
+                                              # head widths off the 8-element grid (element-wise staging) ...
+                                              (3, 96, 16, 3, 12, 0.1), (2, 50, 32, 2, 2, 0.0), (2, 96, 32, 5, 10, 0.0),
+                                              (2, 33, 3, 6, 20, 0.2), (2, 96, 4, 2, 4, 0.0),
+                                              # ... and wider than 64 (256-byte image rows, S <= 96)
+                                              (2, 96, 2, 96, 96, 0.1), (2, 64, 2, 128, 128, 0.0), (3, 50, 2, 40, 80, 0.0)])
 def test_strided_self_attention_on_projection_outputs(B, S, h, dk, dv, drop, kind, dtype):
     """The kernels read Q and K in place from one [B, S, 2*h*dk] tensor and V / O as [B, S, h*dv]."""
     from mitune.ops.attention import attention_reference
@@ -124,7 +129,9 @@ def test_strided_self_attention_on_projection_outputs(B, S, h, dk, dv, drop, kin
 
 
 @pytest.mark.parametrize("B,S,h,dk,dv,dtype", [(3, 50, 4, 16, 16, torch.float32), (2, 65, 8, 24, 24, torch.bfloat16),
-                                                (2, 20, 2, 8, 16, torch.float32), (1, 128, 4, 32, 64, torch.bfloat16)])
+                                                (2, 20, 2, 8, 16, torch.float32), (1, 128, 4, 32, 64, torch.bfloat16),
+                                                (2, 96, 16, 3, 12, torch.float32), (2, 96, 32, 5, 10, torch.bfloat16),
+                                                (2, 96, 2, 48, 96, torch.float32)])
 @pytest.mark.parametrize("p", [0.0, 0.25])
 def test_fused_qkv_attention_equals_the_two_operand_form(B, S, h, dk, dv, dtype, p):
     """One [B, S, 2*h*dk + h*dv] projection output read in place, one gradient tensor back: bitwise the values the
