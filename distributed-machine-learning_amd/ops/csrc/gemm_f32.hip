@@ -132,6 +132,7 @@ __device__ __forceinline__ float f32_colsum_stage(const uint8_t* ldsA, int tid) 
 template <int N>
 __device__ __forceinline__ void f32_wait_vm() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -339,12 +340,21 @@ extern "C" int mt_gemm_f32_launch(int mode, const MtGemmGroup* groups, const MtT
                                   hipStream_t stream) {
   if (ntiles <= 0) return 0;
   if (ksplits < 1 || ksplits > 127 || (mode != 2 && ksplits != 1)) return -5;
-  if (tile_edge != 128 && tile_edge != 64 && tile_edge != 65) return -7;      // 65: 64-tiles on the three-stage pipeline
+  if (tile_edge != 128 && tile_edge != 64 && tile_edge != 65 && tile_edge != 32) return -7;      // 65: 64-tiles, three stages
   dim3 grid(ntiles), block(F32_THREADS);
 #define MT_F32_GO(M, N, T_, KS, SS)                                                                                       \
   hipLaunchKernelGGL((mt_gemm_f32_kernel<M, N, T_>), grid, block, 0, stream, groups, tiles, step, flags, arow0, i_override, \
                      KS, SS, mt_step_base_tls)
   const bool big = tile_edge == 128, two = tile_edge == 64;
+  if (tile_edge == 32) {        // latency form: launches of a few hundred 64-tiles fill the chip four times better
+    switch (mode) {
+      case 0: MT_F32_GO(0, 2, 32, 1, (size_t)0); break;
+      case 1: MT_F32_GO(1, 2, 32, 1, (size_t)0); break;
+      case 2: MT_F32_GO(2, 2, 32, ksplits, split_stride); break;
+      default: return -1;
+    }
+    return (int)hipGetLastError();
+  }
   switch (mode) {
     case 0: if (big) MT_F32_GO(0, 2, 128, 1, (size_t)0); else if (two) MT_F32_GO(0, 2, 64, 1, (size_t)0); else MT_F32_GO(0, 3, 64, 1, (size_t)0); break;
     case 1: if (big) MT_F32_GO(1, 2, 128, 1, (size_t)0); else if (two) MT_F32_GO(1, 2, 64, 1, (size_t)0); else MT_F32_GO(1, 3, 64, 1, (size_t)0); break;
@@ -361,9 +371,12 @@ extern "C" int mt_gemm_f32_bwd_head_launch(const MtGemmGroup* wgroups, const MtT
                                            hipStream_t stream) {
   if (n_wtiles + n_dtiles + hr.n_slots <= 0) return 0;
   if (ksplits < 1 || ksplits > 127) return -5;
-  if (tile_edge != 128 && tile_edge != 64 && tile_edge != 65) return -7;
+  if (tile_edge != 128 && tile_edge != 64 && tile_edge != 65 && tile_edge != 32) return -7;
   dim3 grid(n_wtiles + n_dtiles + hr.n_slots), block(F32_THREADS);
-  if (tile_edge == 64)
+  if (tile_edge == 32)
+    hipLaunchKernelGGL((mt_gemm_f32_bwd_kernel<2, 32>), grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles,
+                       n_dtiles, step, ksplits, split_stride, mt_step_base_tls, hr);
+  else if (tile_edge == 64)
     hipLaunchKernelGGL((mt_gemm_f32_bwd_kernel<2, 64>), grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles,
                        n_dtiles, step, ksplits, split_stride, mt_step_base_tls, hr);
   else if (tile_edge == 128)

@@ -50,6 +50,12 @@ GRAPH_STEPS = 25       # steps per captured hipGraph block (3125 = 125 blocks; s
 # of narrow layers and the tail of a launch that does not fill the chip.
 F32_SMALL_TILES = int(os.environ.get("MITUNE_F32_SMALL_TILES", "2048"))
 SMALL_TILE = 64
+# Launches with fewer 64-tiles than this (a late-round layer of a dozen survivors: about one tile per CU) use 32x32
+# tiles: four times the workgroups for the same arithmetic.  Measured on 16 slots x [256 x 128] . [128 x 128]: forward
+# 6.5 -> 4.5 us, weight gradient 10.9 -> 6.6 us; at 512 64-tiles the two forms are level.  Headline search by threshold:
+# 0 (never) 72.7 k trials/hour, 256 73.9 k, 512 75.5 k, 768 75.1 k, 1024 74.4 k, 2048 74.9 k.
+F32_TINY_TILES = int(os.environ.get("MITUNE_F32_TINY_TILES", "512"))
+TINY_TILE = 32
 DTYPES = ("bf16", "f32")
 
 
@@ -474,11 +480,16 @@ class HipPackEngine(PackEngine):
             def count(lst, edge):
                 return sum(a * b for _, a, b, _ in tiled(lst, edge))
 
-            if self.f32:      # tile-edge codes of the plan: 0 = 128, 2 = 64
+            if self.f32:      # tile-edge codes of the plan: 0 = 128, 2 = 64, 3 = 32
                 edge_f = SMALL_TILE if count(fl, TILE) < F32_SMALL_TILES else TILE
+                if count(fl, SMALL_TILE) < F32_TINY_TILES:
+                    edge_f = TINY_TILE
                 ks_l = ksplits0 if l == 0 else ksplits
                 edge_b = SMALL_TILE if count(dl, TILE) + count(wl, TILE) * ks_l < F32_SMALL_TILES else TILE
-                out[f"big_fwd{l}"], out[f"big_bwd{l}"] = (2 if edge_f == SMALL_TILE else 0), (2 if edge_b == SMALL_TILE else 0)
+                if count(dl, SMALL_TILE) + count(wl, SMALL_TILE) * ks_l < F32_TINY_TILES:
+                    edge_b = TINY_TILE
+                code = {TILE: 0, SMALL_TILE: 2, TINY_TILE: 3}
+                out[f"big_fwd{l}"], out[f"big_bwd{l}"] = code[edge_f], code[edge_b]
             else:
                 # 256-tiles halve the bytes staged per flop; they pay once a launch still has enough of them to fill the chip
                 big_f = BIG_MIN_TILES > 0 and count(fl, BIG_TILE) >= BIG_MIN_TILES

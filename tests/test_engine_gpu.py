@@ -91,19 +91,21 @@ def test_packing_invariance_is_bitwise(dtype):
 
 
 def test_f32_results_do_not_depend_on_the_tile_edge(monkeypatch):
-    """The exact-f32 engine picks 64- or 128-tiles from the size of the pack; a trial's weights must not notice."""
+    """The exact-f32 engine picks 128-, 64- or 32-tiles from the size of the pack; a trial's weights must not notice."""
     from mitune.packed import PackedTrainable, engine_hip
     train, val = _data(seed=8)
     tr = PackedTrainable(train=train, val=val, max_epochs=2, val_chunk=512, dtype="f32",
                          model_kwargs={"max_width": 256, "max_layers": 3, "max_batch": 512})
     out = {}
-    for limit in (0, 10 ** 9):           # 0: always 128-tiles; huge: always 64-tiles
-        monkeypatch.setattr(engine_hip, "F32_SMALL_TILES", limit)
-        _, out[limit] = _run(engine_hip.HipPackEngine, tr, [(7, CONFIGS[1]), (9, CONFIGS[3])], [0, 1], 2, device="cuda",
-                             capacity=4, seed=5)
+    for edge, (small, tiny) in {128: (0, 0), 64: (10 ** 9, 0), 32: (10 ** 9, 10 ** 9)}.items():
+        monkeypatch.setattr(engine_hip, "F32_SMALL_TILES", small)
+        monkeypatch.setattr(engine_hip, "F32_TINY_TILES", tiny)
+        _, out[edge] = _run(engine_hip.HipPackEngine, tr, [(7, CONFIGS[1]), (9, CONFIGS[3])], [0, 1], 2, device="cuda",
+                            capacity=4, seed=5)
     for slot in (0, 1):
-        for k, v in out[0][slot]["model"].items():
-            assert torch.equal(v, out[10 ** 9][slot]["model"][k]), (slot, k)
+        for k, v in out[128][slot]["model"].items():
+            assert torch.equal(v, out[64][slot]["model"][k]), (slot, k)
+            assert torch.equal(v, out[32][slot]["model"][k]), (slot, k)
 
 
 def test_a_slot_moved_between_engines_continues_bit_for_bit():

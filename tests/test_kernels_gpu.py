@@ -301,7 +301,7 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
-@pytest.mark.parametrize("edge", [128, 64])
+@pytest.mark.parametrize("edge", [128, 64, 32])
 @pytest.mark.parametrize("relu", [False, True])
 def test_gemm_f32_forward_nt(lib, relu, edge):
     if NSTAGE != 2:
@@ -334,7 +334,7 @@ def test_gemm_f32_forward_nt(lib, relu, edge):
         assert torch.all(y[:, rounded:] == 7.0)
 
 
-@pytest.mark.parametrize("edge", [128, 64])
+@pytest.mark.parametrize("edge", [128, 64, 32])
 def test_gemm_f32_forward_identity_asymmetric(lib, edge):
     if NSTAGE != 2:
         pytest.skip("the f32 kernels have one pipeline form per tile edge")
@@ -353,7 +353,7 @@ def test_gemm_f32_forward_identity_asymmetric(lib, edge):
     assert torch.equal(y, w.t())          # exact: every product is x * 1 or x * 0
 
 
-@pytest.mark.parametrize("edge", [128, 64])
+@pytest.mark.parametrize("edge", [128, 64, 32])
 @pytest.mark.parametrize("mask", [False, True])
 def test_gemm_f32_dgrad_nn(lib, mask, edge):
     if NSTAGE != 2:
@@ -382,7 +382,7 @@ def test_gemm_f32_dgrad_nn(lib, mask, edge):
         torch.testing.assert_close(dx[:, :k].double(), ref, rtol=2e-6, atol=2e-5)
 
 
-@pytest.mark.parametrize("edge", [128, 64])
+@pytest.mark.parametrize("edge", [128, 64, 32])
 @pytest.mark.parametrize("ksplits", [1, 3])
 def test_gemm_f32_wgrad_tn(lib, ksplits, edge):
     if NSTAGE != 2:
