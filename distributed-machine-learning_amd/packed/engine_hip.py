@@ -56,6 +56,16 @@ SMALL_TILE = 64
 # 0 (never) 72.7 k trials/hour, 256 73.9 k, 512 75.5 k, 768 75.1 k, 1024 74.4 k, 2048 74.9 k.
 F32_TINY_TILES = int(os.environ.get("MITUNE_F32_TINY_TILES", "512"))
 TINY_TILE = 32
+# Exact-f32 packs of 32 and more trials run as independent chains of launches on separate HIP streams: every launch of
+# the f32 engine ends in a tail of long-running tiles (the f32 matrix instruction is sixteen times slower than the bf16
+# one), and a second chain's workgroups fill it.  Packs of a dozen survivors lose from splitting (their launches are
+# already too small).  "min_slots:chains,..." -- the first rule whose pack size is reached applies.
+def _chain_rule(text: str):
+    rule = [tuple(int(v) for v in part.split(":")) for part in text.split(",") if part]
+    return sorted(rule, reverse=True)
+
+
+F32_CHAIN_RULE = _chain_rule(os.environ.get("MITUNE_F32_CHAIN_RULE", "128:4,32:2"))
 DTYPES = ("bf16", "f32")
 
 
@@ -581,6 +591,11 @@ class HipPackEngine(PackEngine):
     def _n_chains(self) -> int:
         if self.n_streams_override:
             return max(1, min(MAX_STREAMS, self.n_streams_override, len(self.slots)))
+        if self.f32:
+            n = len(self.slots)
+            for min_slots, chains in F32_CHAIN_RULE:       # largest pack size first
+                if n >= min_slots:
+                    return max(1, min(MAX_STREAMS, chains, n))
         return 1
 
     def _drop_graphs(self) -> None:
