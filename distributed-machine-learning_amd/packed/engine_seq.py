@@ -42,6 +42,17 @@ MAX_LAYERS = 8
 KSPLITS = int(os.environ.get("MITUNE_SEQ_KSPLITS", "2"))     # weight-gradient slabs: the token contraction is split in this many
 
 
+def _chain_rule(text: str):
+    return sorted((tuple(int(v) for v in part.split(":")) for part in text.split(",") if part), reverse=True)
+
+
+# "min_slots:chains,...": packs of at least min_slots trials are split into that many independent chains of launches on
+# separate HIP streams (the first rule reached applies; none: one chain).  Measured per pack step, one chain / two
+# chains / four chains: 16 slots 907 / 985 / 970 us, 64 slots 2236 / 2100 / 2202 us, 128 slots 3965 / 3702 / 4131 us --
+# two chains fill each other's launch tails once a pack is big enough to keep both busy.
+SEQ_CHAIN_RULE = _chain_rule(os.environ.get("MITUNE_SEQ_CHAIN_RULE", "32:2"))
+
+
 def ceil4(x: int) -> int:
     return (x + 3) // 4 * 4
 
@@ -300,6 +311,8 @@ class SeqPackEngine(PackEngine):
         self.prepared_total = 0
         self._dirty = True
         self._plans: Dict[str, SeqPlan] = {}
+        self._chains: List[SeqPlan] = []
+        self._streams: List[torch.cuda.Stream] = []
         self._train_loss: Dict[int, float] = {}
         self._loss_pending = False
         self._round_steps: Dict[int, int] = {}
@@ -555,10 +568,10 @@ class SeqPackEngine(PackEngine):
         op.ntiles, op.edge = len(tiles), edge
         return op
 
-    def _build_plan(self, eval_mode: bool) -> SeqPlan:
+    def _build_plan(self, eval_mode: bool, ids: Optional[List[int]] = None, tag: Optional[str] = None) -> SeqPlan:
         T = self.capacity
-        tag = "e" if eval_mode else "t"
-        ids = sorted(self.slots)
+        tag = tag or ("e" if eval_mode else "t")
+        ids = sorted(self.slots) if ids is None else sorted(ids)
         members = [(slot, self.slots[slot]) for slot in ids]
         Lmax = max(s.spec.layers for _, s in members)
         grp = L.gemm_group
@@ -727,7 +740,7 @@ class SeqPackEngine(PackEngine):
         hi = int(mix32(np.uint32(lo ^ 0x9E3779B9)))
         return lo, hi
 
-    def _epoch_tables(self, plan: SeqPlan) -> int:
+    def _epoch_tables(self, plans: List[SeqPlan]) -> int:
         T = self.capacity
         gat = np.zeros(T, dtype=L.GATHER_DTYPE)
         opt = np.zeros(T, dtype=L.OPT_DTYPE)
@@ -745,14 +758,28 @@ class SeqPackEngine(PackEngine):
             opt[slot] = (sp.learning_rate, sp.beta1, sp.beta2, sp.eps, sp.weight_decay, sp.momentum, sp.gradient_clipping,
                          OPT_CODES[sp.optimizer], sp.warmup_steps, sp.total_steps, s.layout.total, steps, s.step, 0, 0, 0)
             seeds[slot] = self._slot_seed(s)
-        plan.gather = self._upload("t_gather", gat)
-        plan.opt = self._upload("t_opt", opt)
+        g_ptr, o_ptr = self._upload("t_gather", gat), self._upload("t_opt", opt)
+        for plan in plans:          # the per-epoch tables are indexed by slot: every chain reads the same ones
+            plan.gather, plan.opt = g_ptr, o_ptr
         self.seeds.copy_(torch.from_numpy(seeds.view(np.int32)))
         return max_steps
 
+    def _n_chains(self) -> int:
+        n = len(self.slots)
+        for min_slots, chains in SEQ_CHAIN_RULE:
+            if n >= min_slots:
+                return max(1, min(chains, n))
+        return 1
+
     def _refresh(self) -> None:
-        if self._dirty or "t" not in self._plans:
-            self._plans["t"] = self._build_plan(False)
+        if self._dirty or "e" not in self._plans:
+            # independent chains of launches on separate streams: slots dealt round-robin in size order, so every chain
+            # gets a similar mix of depths and widths
+            n = self._n_chains()
+            order = sorted(self.slots, key=lambda k: (-self.slots[k].spec.layers, -self.slots[k].spec.d, k))
+            self._chains = [self._build_plan(False, order[c::n], f"t{c}_") for c in range(n)]
+            while len(self._streams) < n - 1:
+                self._streams.append(torch.cuda.Stream(self.device))
             self._plans["e"] = self._build_plan(True)
             self._dirty = False
 
@@ -761,11 +788,21 @@ class SeqPackEngine(PackEngine):
         if not self.slots:
             return
         self._refresh()
-        plan = self._plans["t"]
-        steps = self._epoch_tables(plan)
+        steps = self._epoch_tables(self._chains)
         self.loss_acc.zero_()
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        L.check(self.lib.mt_seq_train_steps(C.byref(plan), 0, steps, stream), "mt_seq_train_steps")
+        main = torch.cuda.current_stream(self.device)
+        stream = main.cuda_stream
+        if len(self._chains) == 1:
+            L.check(self.lib.mt_seq_train_steps(C.byref(self._chains[0]), 0, steps, stream), "mt_seq_train_steps")
+        else:
+            lanes = [main] + self._streams[:len(self._chains) - 1]
+            for st in lanes[1:]:
+                st.wait_stream(main)           # tables, seeds and zeroed accumulators were issued on the main stream
+            for step in range(steps):          # interleaved step by step: no chain gets a head start
+                for plan, st in zip(self._chains, lanes):
+                    L.check(self.lib.mt_seq_train_steps(C.byref(plan), step, 1, st.cuda_stream), "mt_seq_train_steps")
+            for st in lanes[1:]:
+                main.wait_stream(st)
         L.check(self.lib.mt_stamp_launch(self._stamps[1:].data_ptr(), stream), "mt_stamp_launch")
         self._round_steps = {}
         for slot, s in self.slots.items():

@@ -245,3 +245,25 @@ def test_two_ranks_move_sequence_trials_as_device_slabs_without_changing_them():
     res0, moves0, _ = search(0)
     assert engine == "seq" and moves >= 1 and moves0 == 0
     assert res == res0
+
+
+def test_chains_on_separate_streams_change_nothing(monkeypatch):
+    """A pack split into independent chains of launches on two and three HIP streams: bitwise the one-chain results."""
+    from mitune.packed import engine_seq
+    tr = _trainable()
+    cfgs = [dict(c, dropout=0.2) for c in CONFIGS] + [dict(CONFIGS[1], dropout=0.1, learning_rate=2e-3)]
+    results = {}
+    for chains in (1, 2, 3):
+        monkeypatch.setattr(engine_seq, "SEQ_CHAIN_RULE", [(2, chains)])
+        eng = _seq(tr)
+        for i, c in enumerate(cfgs):
+            eng.load(i, 70 + i, c)
+        for _ in range(2):
+            eng.train_epoch()
+        assert len(eng._chains) == chains
+        results[chains] = (eng.evaluate(), [eng.export(i)["model"] for i in range(len(cfgs))])
+    for chains in (2, 3):
+        assert results[chains][0] == results[1][0]
+        for a, b in zip(results[chains][1], results[1][1]):
+            for k in a:
+                assert torch.equal(a[k], b[k]), (chains, k)
