@@ -284,6 +284,10 @@ class SeqPackEngine(PackEngine):
         self.Xtr, self.Xva = padded(Xtr), padded(Xva)
         self.ytr = trainable.train[1].to(dev, torch.float32).contiguous()
         self.yva = trainable.val[1].to(dev, torch.float32).contiguous()
+        # Validation runs in chunks of the training batch size, through the training buffers.  Chunks of 128 samples (two
+        # passes over a 200-sample validation set instead of seven) were tried: validation got 15 % cheaper, but the
+        # forward buffers grew fourfold, spread every slot's working set over four times the address range, and TRAINING
+        # slowed by 8 % (64 slots) to 25 % (128 slots).  Compact per-slot regions matter more than fewer launches here.
         self.eval_chunk = int(min(max(1, min(trainable.val_chunk, self.max_batch)), max(self.n_val, 1)))
         self.rows_max = max(self.max_batch, self.eval_chunk)
         self.capacity = int(capacity or trainable.capacity or 64)
