@@ -39,6 +39,9 @@ from ..train.losses import LOSS_CODES
 from ..train.optim import OPT_CODES
 
 MAX_LAYERS = 8
+# host threads drawing the next trials' weights while the GPU trains (1 / 2 / 4 threads on the 2048-trial search: 6.27 /
+# 6.19 / 6.64 s -- more threads fight over the interpreter lock between the many small fills)
+PREP_THREADS = int(os.environ.get("MITUNE_SEQ_PREP_THREADS", "2"))
 KSPLITS = int(os.environ.get("MITUNE_SEQ_KSPLITS", "2"))     # weight-gradient slabs: the token contraction is split in this many
 
 
@@ -309,8 +312,9 @@ class SeqPackEngine(PackEngine):
         self.slots: Dict[int, _SSlot] = {}
         self._stage: Optional[torch.Tensor] = None
         self._tables: Dict[str, Any] = {}
-        self._prepared: Dict[int, Tuple[Dict, torch.Tensor]] = {}
+        self._prepared: Dict[int, Tuple[Dict, Any]] = {}          # trial index -> (config, future of its pinned weight image)
         self._init_rng = torch.Generator()
+        self._pool = None
         self._pin_pool: List[torch.Tensor] = []          # pinned staging images, recycled once their copy has finished
         self.prepared_total = 0
         self._dirty = True
@@ -346,14 +350,15 @@ class SeqPackEngine(PackEngine):
             raise ValueError(f"batch_size {spec.opt.batch_size} > max_batch {self.max_batch}")
         return spec
 
-    def _initial_image(self, lay: SeqLayout, trial_index: int, host: torch.Tensor) -> None:
+    def _initial_image(self, lay: SeqLayout, trial_index: int, host: torch.Tensor,
+                       g: Optional[torch.Generator] = None) -> torch.Tensor:
         """Write the trial's starting weights into ``host`` (a slab-region image): bit for bit those of the module every
         other engine builds for it -- ``SimpleTransformerModel`` under ``manual_seed`` of the trial's stream draws, in
         construction order, a uniform(-1/sqrt(fan_in), 1/sqrt(fan_in)) weight and then bias for each dense layer, and sets
         LayerNorm to (1, 0) -- without building the module (a millisecond of host time per trial, which is what bounds a
         search of thousands of one-epoch trials)."""
         host[:lay.total].zero_()
-        g = self._init_rng              # a private generator: same stream as the global one under the same seed, and
+        g = g or self._init_rng         # a private generator: same stream as the global one under the same seed, and
         g.manual_seed((self.seed * 1_000_003 + int(trial_index)) * 16 + 7)        # seeding it costs 1.5 us instead of 160
         bound = 0.0
         for key, off, (rows, cols), ld in lay.entries:       # construction order of the module
@@ -370,6 +375,7 @@ class SeqPackEngine(PackEngine):
                                                                                                          generator=g)
             else:
                 host[off:off + cols].uniform_(-bound, bound, generator=g)
+        return host
 
     def _initial_state(self, spec: SeqSpec, config: Dict, trial_index: int) -> Dict[str, torch.Tensor]:
         """The same weights as a state dict (tests compare it with the module's)."""
@@ -417,9 +423,13 @@ class SeqPackEngine(PackEngine):
             return False
         spec = self._spec(config)
         lay = SeqLayout(self.F, self.fpad, spec.d, spec.layers)
-        host = self._pinned()
-        self._initial_image(lay, trial_index, host)
-        self._prepared[int(trial_index)] = (dict(config), host)
+        # the CPU generator is the cost (3-6 ns per weight, up to 2 ms per trial): images of the trials to come are drawn
+        # by a few worker threads (the tensor library releases the interpreter lock while it fills)
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=PREP_THREADS, thread_name_prefix="mitune-seq-init")
+        fut = self._pool.submit(self._initial_image, lay, trial_index, self._pinned(), torch.Generator())
+        self._prepared[int(trial_index)] = (dict(config), fut)
         self.prepared_total += 1
         return True
 
@@ -448,14 +458,14 @@ class SeqPackEngine(PackEngine):
             s.epoch, s.step = int(state.get("epoch", 0)), int(state.get("step", 0))
         else:
             if ready is not None and ready[0] == dict(config):
-                host = ready[1]
+                host = ready[1].result()
             else:
                 host = self._pinned()
                 self._initial_image(s.layout, trial_index, host)
             self._region(self.P, slot)[:n].copy_(host[:n])        # blocking: the image is free again on return
             self._pin_pool.append(host)
-        if ready is not None and state is not None:
-            self._pin_pool.append(ready[1])
+        if ready is not None and (state is not None or ready[0] != dict(config)):
+            self._pin_pool.append(ready[1].result())
         self.loss_acc[slot] = 0
         self.slots[slot] = s
         self._dirty = True
@@ -850,6 +860,11 @@ class SeqPackEngine(PackEngine):
                 "mt_metric_table_launch")
         self._loss_pending = False
         return self._table
+
+    def close(self) -> None:
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
 
     def evaluate(self):
         if not self.slots:
