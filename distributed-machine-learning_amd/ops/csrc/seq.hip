@@ -18,7 +18,7 @@
 //     workgroup (x, y) works on piece x of trial slot ids[y] from a per-slot descriptor;
 //   * the optimiser is the per-slot fused one of optim.hip over the pack's flat parameter slab.
 //
-// A step of the whole pack is 14 launches per encoder layer plus 7, whatever the number of trials; the C++ driver
+// A step of the whole pack is 14 launches per encoder layer plus 6, whatever the number of trials; the C++ driver
 // below enqueues all steps of an epoch back to back and the host synchronises once per epoch.  Trials of fewer layers
 // than the deepest one simply have no tiles / inactive descriptors in the deeper launches.  Dropout masks are never
 // stored: forward and backward derive them from (slot seed of the epoch, site, step, element index).

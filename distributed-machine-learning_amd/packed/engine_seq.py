@@ -5,7 +5,7 @@ The reference's sample experiment (/root/reference/ray-tune-hpo-regression-sampl
 of a few workgroups each per step, on a chip with 256 compute units.  ``GraphPackEngine`` shares the GPU between such
 trials through HIP streams (one captured step per trial); this engine shares the LAUNCHES: all resident trials,
 whatever their width / heads / depth / dropout / learning rate, advance by one step in 14 launches per encoder layer
-plus 7, each launch covering every trial (``ops/csrc/seq.hip`` has the launch list).
+plus 6, each launch covering every trial (``ops/csrc/seq.hip`` has the launch list).
 
 Memory model: one f32 parameter slab ``P`` (+ ``M``, ``V`` and ``ksplits`` gradient slabs ``G``) with a fixed stride
 per slot, laid out per trial by ``SeqLayout``; one activation arena with a fixed stride per slot holding the slot's
