@@ -58,12 +58,12 @@ __device__ __forceinline__ int ctile_off(int row, int chunk) {      // [128][128
 // ---- global -> LDS by LDS-DMA (4 x 1 KiB pieces per wave per operand image) ------------------------
 __device__ __attribute__((aligned(16))) uint32_t mt_zero_chunk[4];     // source of every out-of-range chunk
 
-template <bool KMAJOR>
+template <bool KMAJOR, int PIECES = 4>      // PIECES per wave: 4 with four waves, 2 with eight
 __device__ __forceinline__ void stage_tile(uint8_t* img, const uint16_t* __restrict__ base, int ld, int mn0, int mn_lim,
                                            int k0, int k_lim, int wave, int lane) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int j = wave * 4 + t;        // which 1-KiB piece of the 16-KiB image this instruction fills
+  for (int t = 0; t < PIECES; ++t) {
+    const int j = wave * PIECES + t;   // which 1-KiB piece of the 16-KiB image this instruction fills
     int row, col;
     bool ok;
     if (KMAJOR) {      // image row r = 128 B = 8 chunks; slot s of row r holds chunk s ^ (r & 7)
@@ -566,6 +566,346 @@ __global__ __launch_bounds__(NTHREADS) void mt_gemm256_bwd_kernel(const MtGemmGr
     gemm_tile_big<1>(dgroups, dtiles[blockIdx.x - n_wtiles], step, MT_GEMM_FLAG_MASK, 0, 0, 1, 0, lds);
 }
 
+// ====================================================================================================
+// 256 x 256 output tiles on EIGHT waves, fragment reads software-pipelined under the MFMAs: the form for one large GEMM
+// (layers thousands wide, a data-parallel trial).  A 128-tile stages 32 KB per 2*128*128*64 flop and, with its two
+// barriers per K-step, tops out near a third of the matrix peak; this tile stages half the bytes per flop, and each
+// SIMD holds two waves, so one wave's ds_reads and barrier waits sit under the other's MFMAs.
+//
+// Waves 2 (rows) x 4 (columns): wave (wr, wc) owns rows wr*128..+128, columns wc*64..+64 = 8 x 4 accumulators (128
+// registers).  A stage is the same four 16-KiB images as above [A rows 0-127 | A rows 128-255 | B cols 0-127 | B cols
+// 128-255], two stages = 128 KiB, one workgroup per CU.  One K-tile (64 deep) is four groups of 16 MFMAs -- (ks, row
+// half) -- and the reads of group q+1 are issued before the MFMAs of group q:
+//     read A(ks0, lo), B(ks0) | MFMA(ks1, hi) of tile k-1 | read A(ks0, hi) | MFMA(ks0, lo) | read A(ks1, lo), B(ks1) |
+//     MFMA(ks0, hi) | read A(ks1, hi) | MFMA(ks1, lo) | barrier | LDS-DMA of tile k+2 into the stage just read
+// so every batch of ds_reads has 16 MFMAs (512 matrix-pipe cycles) to come back, and a K-tile costs ONE barrier.
+// An element's contraction is still summed in K order, so results equal the 128-tile kernels' bit for bit.
+#define P8_THREADS 512
+
+template <bool A_KMAJ>
+__device__ __forceinline__ void p8_read_a(bf16x8 (&a)[4], const uint8_t* imgA, int mh, int ks, int lane) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    if constexpr (A_KMAJ) a[m] = frag_kmajor(imgA, (mh * 4 + m) * 16, ks, lane);
+    else a[m] = frag_mnmajor(imgA, (mh * 4 + m) * 16, ks, lane);
+  }
+}
+template <bool B_KMAJ>
+__device__ __forceinline__ void p8_read_b(bf16x8 (&b)[4], const uint8_t* imgB, int col0, int ks, int lane) {
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    if constexpr (B_KMAJ) b[n] = frag_kmajor(imgB, col0 + n * 16, ks, lane);
+    else b[n] = frag_mnmajor(imgB, col0 + n * 16, ks, lane);
+  }
+}
+template <bool PRIO = false, bool DRY = false>
+__device__ __forceinline__ void p8_mma(f32x4 (&acc)[8][4], int mh, const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
+  if constexpr (DRY) {       // timing-only ablation: fragments stay live, matrix pipe idle
+#pragma unroll
+    for (int m = 0; m < 4; ++m) asm volatile("" ::"v"(a[m]), "v"(b[m]));
+    return;
+  }
+  if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      acc[mh * 4 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[n], a[m], acc[mh * 4 + m][n], 0, 0, 0);
+  if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+}
+
+// One 256 x 256 tile (ti, tj) of the group; split: which part of the contraction (weight gradient only).
+template <int MODE, int SCHED>
+__device__ __forceinline__ void gemm_tile_p8(const MtGemmGroup& g, int ti, int tj, int split, int flags, int ksplits,
+                                             size_t split_stride, uint8_t* lds) {
+  constexpr bool A_KMAJ = (MODE != 2);
+  constexpr bool B_KMAJ = (MODE == 0);
+  constexpr int BASE = SCHED & 3;
+  constexpr bool DRY = (SCHED & 8) != 0, NOFILL = (SCHED & 16) != 0;      // timing-only ablations
+  constexpr bool PRIO = (SCHED & 4) != 0;      // raise the wave's priority while it issues a group of MFMAs
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int i0 = ti * BIGT, j0 = tj * BIGT;
+  if (i0 >= g.I || j0 >= g.J) return;
+  const uint16_t* A = reinterpret_cast<const uint16_t*>(g.A);
+  const uint16_t* B = reinterpret_cast<const uint16_t*>(g.B);
+  const int qi0 = i0 + wr * 128, qj0 = j0 + wc * 64;                     // this wave's block of the output
+  const bool live = (qi0 < g.I) && (qj0 < g.J);      // wave-uniform; a wave outside the matrix multiplies the zeros staged for it
+  const int offA = wr * 16384, offB = 32768 + (wc >> 1) * 16384, bcol0 = (wc & 1) * 64;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const bool want_db = (MODE == 2) && (flags & MT_GEMM_FLAG_DBIAS) && tj == 0 && g.aux_out != nullptr;
+  float db_acc = 0.f;
+
+  const int nk_all = (g.KK + BK - 1) / BK;
+  int kt_lo = 0, kt_hi = nk_all;
+  if (MODE == 2 && ksplits > 1) {
+    const int per = (nk_all + ksplits - 1) / ksplits;
+    kt_lo = split * per;
+    kt_hi = (kt_lo + per < nk_all) ? kt_lo + per : nk_all;
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int n_it = kt_hi - kt_lo;
+  auto issue = [&](int slot, int kt) {      // 8 LDS-DMA pieces per wave: tile kt -> the four images of stage `slot`
+    uint8_t* st = lds + slot * BIG_STAGE_BYTES;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));            // addresses are recomputed per tile instead of pinned across the loop
+    stage_tile<A_KMAJ, 2>(st, A, g.lda, i0, g.I, kt * BK, g.KK, wave_u, ln);
+    stage_tile<A_KMAJ, 2>(st + 16384, A, g.lda, i0 + 128, g.I, kt * BK, g.KK, wave_u, ln);
+    stage_tile<B_KMAJ, 2>(st + 32768, B, g.ldb, j0, g.J, kt * BK, g.KK, wave_u, ln);
+    stage_tile<B_KMAJ, 2>(st + 49152, B, g.ldb, j0 + 128, g.J, kt * BK, g.KK, wave_u, ln);
+  };
+
+  if constexpr (BASE != 1) {
+  constexpr bool WEAVE = (BASE == 2);      // refill issued unconditionally (past the end: zeros) and woven into the MFMAs
+  // Two barriers per K-tile: B1 publishes tile it, B2 (after this wave's last read of it) frees the stage, whose refill
+  // then has the second half of this tile and the whole next one to land.
+  if (n_it > 0) issue(0, kt_lo);
+  if (n_it > 1) issue(1, kt_lo + 1);
+  for (int it = 0; it < n_it; ++it) {
+    const int cur = it & 1;
+    const uint8_t* st = lds + cur * BIG_STAGE_BYTES;
+    const uint8_t* imgA = st + offA;
+    const uint8_t* imgB = st + offB;
+    if (WEAVE || it + 1 < n_it) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8 a0[4], a1[4], a2[4], a3[4], b0[4], b1[4];
+    p8_read_a<A_KMAJ>(a0, imgA, 0, 0, lane);
+    p8_read_b<B_KMAJ>(b0, imgB, bcol0, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    p8_read_a<A_KMAJ>(a1, imgA, 1, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    p8_mma<PRIO, DRY>(acc, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    p8_read_a<A_KMAJ>(a2, imgA, 0, 1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    p8_mma<PRIO, DRY>(acc, 1, a1, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    p8_read_b<B_KMAJ>(b1, imgB, bcol0, 1, lane);
+    p8_read_a<A_KMAJ>(a3, imgA, 1, 1, lane);
+    if (want_db) db_acc += colsum_stage(st + (tid >> 8) * 16384, tid & 255);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // every wave holds its fragments: the stage may be refilled
+    if (!NOFILL && (WEAVE || it + 2 < n_it)) issue(cur, kt_lo + it + 2);
+    if (!WEAVE) __builtin_amdgcn_sched_barrier(0);
+    p8_mma<PRIO, DRY>(acc, 0, a2, b1);
+    if (WEAVE) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {            // 2 MFMAs, then a slice of the refill's address arithmetic and one DMA
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 14, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    p8_mma<PRIO, DRY>(acc, 1, a3, b1);
+  }
+  if (WEAVE) {       // the refills past the last tile must not land in the epilogue's staging images
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  } else {
+  // One barrier per K-tile: it publishes tile it+1 (this wave's pieces of it are back: vmcnt(0), nothing younger is in
+  // flight yet) and proves that every wave has read the last fragment of tile it, whose stage is refilled right after.
+  // The fourth MFMA group of a tile is held back until the first reads of the next tile have been issued.
+  bf16x8 a3[4], b1[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { a3[m] = bf16x8{}; b1[m] = bf16x8{}; }      // tile "-1": adds +0 to the zeroed accumulators
+  if (n_it > 0) issue(0, kt_lo);
+  if (n_it > 1) issue(1, kt_lo + 1);
+  if (n_it > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int it = 0; it < n_it; ++it) {
+    const int cur = it & 1;
+    const uint8_t* st = lds + cur * BIG_STAGE_BYTES;
+    const uint8_t* imgA = st + offA;
+    const uint8_t* imgB = st + offB;
+    {
+      bf16x8 a0[4], a1[4], a2[4], b0[4];
+      p8_read_a<A_KMAJ>(a0, imgA, 0, 0, lane);
+      p8_read_b<B_KMAJ>(b0, imgB, bcol0, 0, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      p8_mma<PRIO, DRY>(acc, 1, a3, b1);                      // (ks1, rows hi) of the previous tile
+      __builtin_amdgcn_sched_barrier(0);
+      p8_read_a<A_KMAJ>(a1, imgA, 1, 0, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      p8_mma<PRIO, DRY>(acc, 0, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      p8_read_a<A_KMAJ>(a2, imgA, 0, 1, lane);
+      p8_read_b<B_KMAJ>(b1, imgB, bcol0, 1, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      p8_mma<PRIO, DRY>(acc, 1, a1, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      p8_read_a<A_KMAJ>(a3, imgA, 1, 1, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      p8_mma<PRIO, DRY>(acc, 0, a2, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (want_db) db_acc += colsum_stage(st + (tid >> 8) * 16384, tid & 255);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!NOFILL && it + 2 < n_it) issue(cur, kt_lo + it + 2);
+  }
+  p8_mma<PRIO, DRY>(acc, 1, a3, b1);
+
+  }
+  // ------------------------------------------------------------------------------ epilogues
+  const int fq = lane >> 4, fr = lane & 15;
+  if (MODE == 2) {
+    float* C = reinterpret_cast<float*>(g.C) + (size_t)split * split_stride;
+    if (live) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int row = qi0 + m * 16 + fr;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const int col = qj0 + n * 16 + fq * 4;
+          if (row < g.I) {
+            float* dst = C + (size_t)row * g.ldc + col;
+            if (col + 3 < g.J) *reinterpret_cast<f32x4*>(dst) = acc[m][n];
+            else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (col + j < g.J) dst[j] = acc[m][n][j];
+            }
+          }
+        }
+      }
+    }
+    if (want_db) {
+      float* red = reinterpret_cast<float*>(lds);    // all waves are past the last K-step barrier
+      red[tid] = db_acc;
+      __syncthreads();
+      float* out = reinterpret_cast<float*>(g.aux_out) + (size_t)split * split_stride;
+      const int t = tid & 255, row = i0 + (tid >> 8) * 128 + t;
+      if (t < 128 && row < g.I) out[row] = red[tid] + red[tid + 128];
+    }
+    return;
+  }
+  if (!live) return;
+  {
+    uint8_t* img = lds + wave * 16384;       // this wave's own [128][64] bf16 staging image (wave-private: no barrier)
+    const bool relu = (MODE == 0) && (flags & MT_GEMM_FLAG_RELU);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int lcol = n * 16 + fq * 4;
+      float bb[4] = {0.f, 0.f, 0.f, 0.f};
+      if (MODE == 0 && g.aux != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (qj0 + lcol + j < g.J) bb[j] = reinterpret_cast<const float*>(g.aux)[qj0 + lcol + j];
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int lrow = m * 16 + fr;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[m][n][j] + bb[j];
+          if (relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(img + kmaj_off(lrow, lcol >> 3) + (lcol & 7) * 2) = pk;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    uint16_t* C = reinterpret_cast<uint16_t*>(g.C);
+    const uint16_t* msk = (MODE == 1 && (flags & MT_GEMM_FLAG_MASK)) ? reinterpret_cast<const uint16_t*>(g.aux)
+                                                                    : nullptr;
+#pragma unroll 1
+    for (int t0 = 0; t0 < 16; t0 += 8) {
+      u32x4 hv[8];
+      if (msk != nullptr) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int q = lane + 64 * (t0 + t);
+          const int row = qi0 + (q >> 3), col = qj0 + (q & 7) * 8;
+          const bool ok = (row < g.I && col < g.J);
+          hv[t] = *reinterpret_cast<const u32x4*>(msk + (ok ? ((size_t)row * g.ldaux + col) : (size_t)0));
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int q = lane + 64 * (t0 + t);
+        const int lrow = q >> 3, ch = q & 7;
+        const int row = qi0 + lrow, col = qj0 + ch * 8;
+        u32x4 v = *reinterpret_cast<const u32x4*>(img + kmaj_off(lrow, ch));
+        if (msk != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t hw = hv[t][e];
+            const uint32_t lo_ok = ((hw & 0x8000u) == 0u && (hw & 0x7FFFu) != 0u) ? 0x0000FFFFu : 0u;
+            const uint32_t hi_ok = ((hw & 0x80000000u) == 0u && (hw & 0x7FFF0000u) != 0u) ? 0xFFFF0000u : 0u;
+            v[e] &= (lo_ok | hi_ok);
+          }
+        }
+        if (row < g.I && col < g.J) *reinterpret_cast<u32x4*>(C + (size_t)row * g.ldc + col) = v;
+      }
+    }
+  }
+}
+
+// Block -> tile as in mt_gemm_single_kernel (whole row panels per XCD); the contraction split is the fastest index.
+// Block -> tile: block b runs on XCD b % 8, which takes a contiguous run of the tile sequence; the sequence walks the
+// grid in bands of `band` row tiles, row tile fastest inside a band, so the ~32 tiles an XCD has in flight form a
+// band x (32 / band) rectangle that shares band + 32 / band operand panels in its L2 instead of 33.
+template <int MODE, int SCHED>
+__global__ __launch_bounds__(P8_THREADS) void mt_gemm_p8_kernel(MtGemmGroup g, int tiles_i, int tiles_j, int ksplits,
+                                                                size_t split_stride, int flags, int band) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BIG_STAGE_BYTES];
+  const int b = blockIdx.x;
+  const int n = tiles_i * tiles_j * ksplits;
+  const int per = (n + 7) / 8;
+  const int u = (b % 8) * per + b / 8;
+  if (u >= n) return;
+  const int sp = u % ksplits, t = u / ksplits;
+  const int in_band = band * tiles_j;
+  const int first = (t / in_band) * band;
+  const int rows = (tiles_i - first < band) ? tiles_i - first : band;      // the last band may be narrower
+  const int r = t - (t / in_band) * in_band;
+  gemm_tile_p8<MODE, SCHED>(g, first + r % rows, r / rows, sp, flags, ksplits, split_stride, lds);
+}
+
+// Large single GEMMs take the eight-wave 256-tile form once they have this many 256-tiles (0: never).
+static int p8_limit = -1;
+static int p8_min_tiles() {
+  if (p8_limit < 0) {
+    const char* e = getenv("MITUNE_P8_MIN_TILES");
+    p8_limit = e ? atoi(e) : 256;
+  }
+  return p8_limit;
+}
+// schedule (-1: by mode -- one barrier per K-tile when both operands are K-major, two otherwise: the forward GEMM gains
+// 4-8 % from the single barrier, the input- and weight-gradient GEMMs lose 10-15 % to the shorter time their refills get;
+// 0 / 1 / 2 force the two-barrier / one-barrier / woven form, +4 raises the wave priority around MFMA groups (measured:
+// no effect), +8 / +16 are timing-only ablations without MFMAs / without refills) and the band height in tiles.
+static int p8_opts[2] = {-1, 4};
+extern "C" int mt_gemm_p8_option(int which, int value) {      // experiments: returns the value in force before
+  if (which < 0 || which > 1) return -2;
+  const int was = p8_opts[which];
+  if (value >= -1) p8_opts[which] = which == 1 && value < 1 ? 1 : value;
+  return was;
+}
+extern "C" int mt_gemm_p8_min_tiles(int set) {      // set >= 0 replaces the threshold; returns the one in force before
+  const int was = p8_min_tiles();
+  if (set >= 0) p8_limit = set;
+  return was;
+}
+static bool p8_wanted(int rows, int cols, int ksplits) {
+  const int lim = p8_min_tiles();
+  if (lim <= 0) return false;
+  const long n = (long)((rows + BIGT - 1) / BIGT) * ((cols + BIGT - 1) / BIGT) * ksplits;
+  return rows >= 2 * BIGT && cols >= 2 * BIGT && n >= lim;
+}
+
 template <int MODE, int NSTAGE>
 __global__ __launch_bounds__(NTHREADS) void mt_gemm_kernel(const MtGemmGroup* __restrict__ groups,
                                                            const MtTile* __restrict__ tiles, int step, int flags,
@@ -701,6 +1041,23 @@ extern "C" int mt_wgrad_single_launch(const void* dY, const void* X, float* C, f
   g.active_steps = 1;
   const int nblocks = tiles_i * tiles_j * ksplits;
   const int flags = db != nullptr ? MT_GEMM_FLAG_DBIAS : 0;
+  if (p8_wanted(out, in, ksplits)) {
+    const int t_i = (out + BIGT - 1) / BIGT, t_j = (in + BIGT - 1) / BIGT;
+    const int nb = ((t_i * t_j * ksplits + 7) / 8) * 8;
+#define MT_P8_GO(M, S) \
+  hipLaunchKernelGGL((mt_gemm_p8_kernel<M, S>), dim3(nb), dim3(P8_THREADS), 0, stream, g, t_i, t_j, ksplits, split_stride, flags, \
+                     p8_opts[1])
+    switch (p8_opts[0] < 0 ? 0 : p8_opts[0]) {
+      case 1: MT_P8_GO(2, 1); break;
+      case 2: MT_P8_GO(2, 2); break;
+      case 4: MT_P8_GO(2, 4); break;
+      case 5: MT_P8_GO(2, 5); break;
+      case 6: MT_P8_GO(2, 6); break;
+      default: MT_P8_GO(2, 0); break;
+    }
+#undef MT_P8_GO
+    return (int)hipGetLastError();
+  }
   if (nblocks <= 320)
     hipLaunchKernelGGL(mt_wgrad_single_kernel<4>, dim3(nblocks), dim3(NTHREADS), 0, stream, g, tiles_i, ksplits,
                        split_stride, flags);
@@ -749,6 +1106,22 @@ extern "C" int mt_gemm_single_launch(int mode, const void* A, const void* B, voi
   g.I = M; g.J = N; g.KK = K;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.active_steps = 1;
+  if (p8_wanted(M, N, 1)) {
+    const int t_i = (M + BIGT - 1) / BIGT, t_j = (N + BIGT - 1) / BIGT;
+    const int nb = ((t_i * t_j + 7) / 8) * 8;
+#define MT_P8_GO(M, S) \
+  hipLaunchKernelGGL((mt_gemm_p8_kernel<M, S>), dim3(nb), dim3(P8_THREADS), 0, stream, g, t_i, t_j, 1, (size_t)0, flags, p8_opts[1])
+    const int sc = p8_opts[0] < 0 ? (mode == 0 ? 1 : 0) : p8_opts[0];
+#define MT_P8_PICK(M) \
+  switch (sc) { case 1: MT_P8_GO(M, 1); break; case 2: MT_P8_GO(M, 2); break; case 4: MT_P8_GO(M, 4); break; \
+                case 5: MT_P8_GO(M, 5); break; case 6: MT_P8_GO(M, 6); break; case 8: MT_P8_GO(M, 8); break; \
+                case 9: MT_P8_GO(M, 9); break; case 16: MT_P8_GO(M, 16); break; case 17: MT_P8_GO(M, 17); break; \
+                default: MT_P8_GO(M, 0); break; }
+    if (mode == 0) { MT_P8_PICK(0) } else { MT_P8_PICK(1) }
+#undef MT_P8_PICK
+#undef MT_P8_GO
+    return (int)hipGetLastError();
+  }
   const int n = tiles_i * tiles_j;
   const int nblocks = ((n + 7) / 8) * 8;
   dim3 grid(nblocks), block(NTHREADS);

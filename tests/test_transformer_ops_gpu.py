@@ -318,6 +318,42 @@ def test_dense_bf16_matches_library_linear(rows, in_f, out_f):
     torch.testing.assert_close(b.grad, br.grad, rtol=1e-2, atol=1e-3 * float(br.grad.abs().max()))
 
 
+@pytest.mark.parametrize("rows,in_f,out_f", [(1032, 520, 776), (2048, 1024, 512), (520, 8, 1032)])
+def test_eight_wave_256_tiles_equal_the_128_tiles_bitwise(rows, in_f, out_f):
+    """A large single GEMM runs on 256 x 256 tiles with eight waves; an element's contraction is summed in the same order
+    as on 128-tiles, so forward output, input gradient, weight and bias gradient are bit-identical (edges included: none
+    of the three shapes is a multiple of 256 everywhere) -- and match an f32 reference."""
+    from mitune.ops import lib as L
+    from mitune.ops.linear import linear
+    so = L.load()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x0 = torch.randn(rows, in_f, device="cuda", generator=g).to(torch.bfloat16)
+    w0 = torch.randn(out_f, in_f, device="cuda", generator=g) * 0.05
+    b0 = torch.randn(out_f, device="cuda", generator=g)
+    dy = torch.randn(rows, out_f, device="cuda", generator=g).to(torch.bfloat16)
+    got = {}
+    before = so.mt_gemm_p8_min_tiles(-1)
+    try:
+        for limit in (0, 1):
+            so.mt_gemm_p8_min_tiles(limit)
+            x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = linear(x, w, b)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            got[limit] = (y.detach(), x.grad, w.grad, b.grad)
+    finally:
+        so.mt_gemm_p8_min_tiles(before)
+    for a, c in zip(got[0], got[1]):
+        assert torch.equal(a, c)
+    xr, wr = x0.float().requires_grad_(True), w0.to(torch.bfloat16).float().requires_grad_(True)
+    yr = xr @ wr.t() + b0
+    yr.backward(dy.float())
+    torch.testing.assert_close(got[1][0].float(), yr, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(got[1][1].float(), xr.grad, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(got[1][2], wr.grad, rtol=1e-2, atol=1e-3 * float(wr.grad.abs().max()))
+
+
 @pytest.mark.parametrize("rows,in_f,out_f", [(40000, 128, 384), (3072, 512, 2048), (3072, 2048, 512), (70000, 64, 64), (40001, 68, 36)])
 def test_dense_f32_matches_float64_reference(rows, in_f, out_f):
     from mitune.ops.linear import DenseF32, linear
