@@ -30,7 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", nargs="+", default=["4096,4096,4096", "8192,8192,8192", "16384,8192,8192"])
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--sched", type=int, nargs="+", default=[-1], help="-1: chosen by mode, 0: two barriers per K-tile, 1: one, 2: woven refill")
+    ap.add_argument("--sched", type=int, nargs="+", default=[-1], help="-1: chosen by mode, 0: two barriers per K-tile, 1: one; +8 / +16: timing-only ablations")
     ap.add_argument("--band", type=int, nargs="+", default=[4], help="row tiles per band of the tile order")
     args = ap.parse_args()
     so = L.load()

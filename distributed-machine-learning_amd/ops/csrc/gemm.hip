@@ -35,6 +35,10 @@
 // wgrad can split its contraction (the batch) over several workgroups: split s writes its partial sums to
 // slab s of the gradient buffer and the optimiser adds the slabs in order (deterministic, no atomics);
 // that trades bytes for latency when a pack has too few tiles to fill 256 CUs.
+//
+// One large GEMM (hundreds of 256 x 256 tiles; the layers of a data-parallel trial) takes the eight-wave 256-tile kernel
+// in the second half of this file: same images and fragment reads, half the staged bytes per flop, fragment reads issued a
+// group of MFMAs ahead, and a banded tile order that keeps an XCD's resident tiles on few operand panels.
 #include "mt_bodies.h"
 
 #define BM 128
@@ -339,8 +343,9 @@ __device__ __forceinline__ void gemm_tile(const MtGemmGroup* __restrict__ groups
 // 256 x 256 output tiles (experimental; selected only when a caller passes nstage = 256).
 //
 // Measured slower than the 128-tile forms with this simple two-barrier K-loop and one wave per SIMD (256 slots of
-// 512^3: forward 166 us vs 122 us): a 256-tile only pays with a finely interleaved ds_read / LDS-DMA / MFMA schedule
-// across two waves per SIMD.  Kept because it is numerically verified and is the starting point for that schedule.
+// 512^3: forward 166 us vs 122 us): a 256-tile only pays with ds_reads, LDS-DMA and MFMAs interleaved across two waves per
+// SIMD -- the eight-wave kernel further down, which serves single large GEMMs.  This grouped four-wave form is kept for
+// packs because it is numerically verified and selectable per launch.
 //
 // With K <= 512 a tile is a chain of at most 8 K-steps, each waiting on one global->LDS round trip, so a CU's
 // rate is (output area per resident tile) / (round-trip time).  A 128x128 tile moves 32 KB per K-step for 2*128*128*64
@@ -598,20 +603,18 @@ __device__ __forceinline__ void p8_read_b(bf16x8 (&b)[4], const uint8_t* imgB, i
     else b[n] = frag_mnmajor(imgB, col0 + n * 16, ks, lane);
   }
 }
-template <bool PRIO = false, bool DRY = false>
+template <bool DRY = false>
 __device__ __forceinline__ void p8_mma(f32x4 (&acc)[8][4], int mh, const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
   if constexpr (DRY) {       // timing-only ablation: fragments stay live, matrix pipe idle
 #pragma unroll
     for (int m = 0; m < 4; ++m) asm volatile("" ::"v"(a[m]), "v"(b[m]));
     return;
   }
-  if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n)
       acc[mh * 4 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[n], a[m], acc[mh * 4 + m][n], 0, 0, 0);
-  if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // One 256 x 256 tile (ti, tj) of the group; split: which part of the contraction (weight gradient only).
@@ -620,9 +623,8 @@ __device__ __forceinline__ void gemm_tile_p8(const MtGemmGroup& g, int ti, int t
                                              size_t split_stride, uint8_t* lds) {
   constexpr bool A_KMAJ = (MODE != 2);
   constexpr bool B_KMAJ = (MODE == 0);
-  constexpr int BASE = SCHED & 3;
+  constexpr int BASE = SCHED & 1;
   constexpr bool DRY = (SCHED & 8) != 0, NOFILL = (SCHED & 16) != 0;      // timing-only ablations
-  constexpr bool PRIO = (SCHED & 4) != 0;      // raise the wave's priority while it issues a group of MFMAs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int i0 = ti * BIGT, j0 = tj * BIGT;
@@ -661,8 +663,7 @@ __device__ __forceinline__ void gemm_tile_p8(const MtGemmGroup& g, int ti, int t
     stage_tile<B_KMAJ, 2>(st + 49152, B, g.ldb, j0 + 128, g.J, kt * BK, g.KK, wave_u, ln);
   };
 
-  if constexpr (BASE != 1) {
-  constexpr bool WEAVE = (BASE == 2);      // refill issued unconditionally (past the end: zeros) and woven into the MFMAs
+  if constexpr (BASE == 0) {
   // Two barriers per K-tile: B1 publishes tile it, B2 (after this wave's last read of it) frees the stage, whose refill
   // then has the second half of this tile and the whole next one to land.
   if (n_it > 0) issue(0, kt_lo);
@@ -672,7 +673,7 @@ __device__ __forceinline__ void gemm_tile_p8(const MtGemmGroup& g, int ti, int t
     const uint8_t* st = lds + cur * BIG_STAGE_BYTES;
     const uint8_t* imgA = st + offA;
     const uint8_t* imgB = st + offB;
-    if (WEAVE || it + 1 < n_it) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (it + 1 < n_it) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     bf16x8 a0[4], a1[4], a2[4], a3[4], b0[4], b1[4];
@@ -681,34 +682,21 @@ __device__ __forceinline__ void gemm_tile_p8(const MtGemmGroup& g, int ti, int t
     __builtin_amdgcn_sched_barrier(0);
     p8_read_a<A_KMAJ>(a1, imgA, 1, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
-    p8_mma<PRIO, DRY>(acc, 0, a0, b0);
+    p8_mma<DRY>(acc, 0, a0, b0);
     __builtin_amdgcn_sched_barrier(0);
     p8_read_a<A_KMAJ>(a2, imgA, 0, 1, lane);
     __builtin_amdgcn_sched_barrier(0);
-    p8_mma<PRIO, DRY>(acc, 1, a1, b0);
+    p8_mma<DRY>(acc, 1, a1, b0);
     __builtin_amdgcn_sched_barrier(0);
     p8_read_b<B_KMAJ>(b1, imgB, bcol0, 1, lane);
     p8_read_a<A_KMAJ>(a3, imgA, 1, 1, lane);
     if (want_db) db_acc += colsum_stage(st + (tid >> 8) * 16384, tid & 255);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();              // every wave holds its fragments: the stage may be refilled
-    if (!NOFILL && (WEAVE || it + 2 < n_it)) issue(cur, kt_lo + it + 2);
-    if (!WEAVE) __builtin_amdgcn_sched_barrier(0);
-    p8_mma<PRIO, DRY>(acc, 0, a2, b1);
-    if (WEAVE) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {            // 2 MFMAs, then a slice of the refill's address arithmetic and one DMA
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x006, 14, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    p8_mma<PRIO, DRY>(acc, 1, a3, b1);
-  }
-  if (WEAVE) {       // the refills past the last tile must not land in the epilogue's staging images
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!NOFILL && it + 2 < n_it) issue(cur, kt_lo + it + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    p8_mma<DRY>(acc, 0, a2, b1);
+    p8_mma<DRY>(acc, 1, a3, b1);
   }
   } else {
   // One barrier per K-tile: it publishes tile it+1 (this wave's pieces of it are back: vmcnt(0), nothing younger is in
@@ -732,20 +720,20 @@ __device__ __forceinline__ void gemm_tile_p8(const MtGemmGroup& g, int ti, int t
       p8_read_a<A_KMAJ>(a0, imgA, 0, 0, lane);
       p8_read_b<B_KMAJ>(b0, imgB, bcol0, 0, lane);
       __builtin_amdgcn_sched_barrier(0);
-      p8_mma<PRIO, DRY>(acc, 1, a3, b1);                      // (ks1, rows hi) of the previous tile
+      p8_mma<DRY>(acc, 1, a3, b1);                      // (ks1, rows hi) of the previous tile
       __builtin_amdgcn_sched_barrier(0);
       p8_read_a<A_KMAJ>(a1, imgA, 1, 0, lane);
       __builtin_amdgcn_sched_barrier(0);
-      p8_mma<PRIO, DRY>(acc, 0, a0, b0);
+      p8_mma<DRY>(acc, 0, a0, b0);
       __builtin_amdgcn_sched_barrier(0);
       p8_read_a<A_KMAJ>(a2, imgA, 0, 1, lane);
       p8_read_b<B_KMAJ>(b1, imgB, bcol0, 1, lane);
       __builtin_amdgcn_sched_barrier(0);
-      p8_mma<PRIO, DRY>(acc, 1, a1, b0);
+      p8_mma<DRY>(acc, 1, a1, b0);
       __builtin_amdgcn_sched_barrier(0);
       p8_read_a<A_KMAJ>(a3, imgA, 1, 1, lane);
       __builtin_amdgcn_sched_barrier(0);
-      p8_mma<PRIO, DRY>(acc, 0, a2, b1);
+      p8_mma<DRY>(acc, 0, a2, b1);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (want_db) db_acc += colsum_stage(st + (tid >> 8) * 16384, tid & 255);
@@ -753,7 +741,7 @@ __device__ __forceinline__ void gemm_tile_p8(const MtGemmGroup& g, int ti, int t
     __builtin_amdgcn_s_barrier();
     if (!NOFILL && it + 2 < n_it) issue(cur, kt_lo + it + 2);
   }
-  p8_mma<PRIO, DRY>(acc, 1, a3, b1);
+  p8_mma<DRY>(acc, 1, a3, b1);
 
   }
   // ------------------------------------------------------------------------------ epilogues
@@ -885,8 +873,12 @@ static int p8_min_tiles() {
 }
 // schedule (-1: by mode -- one barrier per K-tile when both operands are K-major, two otherwise: the forward GEMM gains
 // 4-8 % from the single barrier, the input- and weight-gradient GEMMs lose 10-15 % to the shorter time their refills get;
-// 0 / 1 / 2 force the two-barrier / one-barrier / woven form, +4 raises the wave priority around MFMA groups (measured:
-// no effect), +8 / +16 are timing-only ablations without MFMAs / without refills) and the band height in tiles.
+// 0 / 1 force the two-barrier / one-barrier form, +8 / +16 are timing-only ablations without MFMAs / without refills)
+// and the band height in tiles.  Tried on 8192^3 and 16384 x 8192^2 and dropped: a raised wave priority around the MFMA
+// groups (no change), the refill's address arithmetic woven between MFMAs with scheduling-group directives (no change),
+// and five 32-deep stages filling all 160 KiB of LDS so that four tiles instead of one are in flight (forward 7-10 %
+// slower: 64-byte operand rows request every 128-byte line twice; weight gradient 30 % slower).  Timing-only runs put
+// the loop without refills at 690 us and the refills without MFMAs at 540 us for the 8192^3 forward GEMM that takes 880.
 static int p8_opts[2] = {-1, 4};
 extern "C" int mt_gemm_p8_option(int which, int value) {      // experiments: returns the value in force before
   if (which < 0 || which > 1) return -2;
@@ -1049,10 +1041,6 @@ extern "C" int mt_wgrad_single_launch(const void* dY, const void* X, float* C, f
                      p8_opts[1])
     switch (p8_opts[0] < 0 ? 0 : p8_opts[0]) {
       case 1: MT_P8_GO(2, 1); break;
-      case 2: MT_P8_GO(2, 2); break;
-      case 4: MT_P8_GO(2, 4); break;
-      case 5: MT_P8_GO(2, 5); break;
-      case 6: MT_P8_GO(2, 6); break;
       default: MT_P8_GO(2, 0); break;
     }
 #undef MT_P8_GO
@@ -1113,10 +1101,8 @@ extern "C" int mt_gemm_single_launch(int mode, const void* A, const void* B, voi
   hipLaunchKernelGGL((mt_gemm_p8_kernel<M, S>), dim3(nb), dim3(P8_THREADS), 0, stream, g, t_i, t_j, 1, (size_t)0, flags, p8_opts[1])
     const int sc = p8_opts[0] < 0 ? (mode == 0 ? 1 : 0) : p8_opts[0];
 #define MT_P8_PICK(M) \
-  switch (sc) { case 1: MT_P8_GO(M, 1); break; case 2: MT_P8_GO(M, 2); break; case 4: MT_P8_GO(M, 4); break; \
-                case 5: MT_P8_GO(M, 5); break; case 6: MT_P8_GO(M, 6); break; case 8: MT_P8_GO(M, 8); break; \
-                case 9: MT_P8_GO(M, 9); break; case 16: MT_P8_GO(M, 16); break; case 17: MT_P8_GO(M, 17); break; \
-                default: MT_P8_GO(M, 0); break; }
+  switch (sc) { case 1: MT_P8_GO(M, 1); break; case 8: MT_P8_GO(M, 8); break; case 9: MT_P8_GO(M, 9); break; \
+                case 16: MT_P8_GO(M, 16); break; case 17: MT_P8_GO(M, 17); break; default: MT_P8_GO(M, 0); break; }
     if (mode == 0) { MT_P8_PICK(0) } else { MT_P8_PICK(1) }
 #undef MT_P8_PICK
 #undef MT_P8_GO

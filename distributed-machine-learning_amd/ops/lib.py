@@ -232,6 +232,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_slab_sum_launch.argtypes = [c_void_p, c_void_p, C.c_long, C.c_int, c_size_t, c_void_p]
     lib.mt_gemm_p8_min_tiles.argtypes = [C.c_int]
     lib.mt_gemm_p8_min_tiles.restype = C.c_int
+    lib.mt_gemm_p8_option.argtypes = [C.c_int, C.c_int]
+    lib.mt_gemm_p8_option.restype = C.c_int
     lib.mt_wgrad_f32_single_launch.restype = lib.mt_slab_sum_launch.restype = C.c_int
     if lib.mt_table_meta_sizeof() != TABLE_META_DTYPE.itemsize:
         raise KernelLibraryError("MtTableMeta layout mismatch between lib.py and the library")

@@ -332,20 +332,24 @@ def test_eight_wave_256_tiles_equal_the_128_tiles_bitwise(rows, in_f, out_f):
     b0 = torch.randn(out_f, device="cuda", generator=g)
     dy = torch.randn(rows, out_f, device="cuda", generator=g).to(torch.bfloat16)
     got = {}
-    before = so.mt_gemm_p8_min_tiles(-1)
+    before, sched = so.mt_gemm_p8_min_tiles(-1), so.mt_gemm_p8_option(0, -2)
     try:
-        for limit in (0, 1):
+        # 128-tiles; 256-tiles with the schedule chosen by mode, with two barriers per K-tile, with one
+        for key, limit, option in ((0, 0, -1), (1, 1, -1), (2, 1, 0), (3, 1, 1)):
             so.mt_gemm_p8_min_tiles(limit)
+            so.mt_gemm_p8_option(0, option)
             x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 y = linear(x, w, b)
             y.backward(dy)
             torch.cuda.synchronize()
-            got[limit] = (y.detach(), x.grad, w.grad, b.grad)
+            got[key] = (y.detach(), x.grad, w.grad, b.grad)
     finally:
         so.mt_gemm_p8_min_tiles(before)
-    for a, c in zip(got[0], got[1]):
-        assert torch.equal(a, c)
+        so.mt_gemm_p8_option(0, sched)
+    for key in (1, 2, 3):
+        for a, c in zip(got[0], got[key]):
+            assert torch.equal(a, c), key
     xr, wr = x0.float().requires_grad_(True), w0.to(torch.bfloat16).float().requires_grad_(True)
     yr = xr @ wr.t() + b0
     yr.backward(dy.float())
