@@ -891,11 +891,14 @@ extern "C" int mt_gemm_p8_min_tiles(int set) {      // set >= 0 replaces the thr
   if (set >= 0) p8_limit = set;
   return was;
 }
-static bool p8_wanted(int rows, int cols, int ksplits) {
+// Also needed: a contraction of at least four K-tiles per workgroup (66560 x 576 x 192, an FT-Transformer projection: 48 us
+// against 43 us on 128-tiles; 4096 x 4096 x 256: 18 us against 21 us) and an output at least two tiles wide and high.  With
+// fewer tiles than CUs the 128-tiles win by up to 1.5x (16384 x 512 x 2048: 128 tiles, 68 us against 45 us).
+static bool p8_wanted(int rows, int cols, int depth, int ksplits) {
   const int lim = p8_min_tiles();
   if (lim <= 0) return false;
   const long n = (long)((rows + BIGT - 1) / BIGT) * ((cols + BIGT - 1) / BIGT) * ksplits;
-  return rows >= 2 * BIGT && cols >= 2 * BIGT && n >= lim;
+  return rows >= 2 * BIGT && cols >= 2 * BIGT && depth / ksplits >= 4 * BK && n >= lim;
 }
 
 template <int MODE, int NSTAGE>
@@ -1033,7 +1036,7 @@ extern "C" int mt_wgrad_single_launch(const void* dY, const void* X, float* C, f
   g.active_steps = 1;
   const int nblocks = tiles_i * tiles_j * ksplits;
   const int flags = db != nullptr ? MT_GEMM_FLAG_DBIAS : 0;
-  if (p8_wanted(out, in, ksplits)) {
+  if (p8_wanted(out, in, M, ksplits)) {
     const int t_i = (out + BIGT - 1) / BIGT, t_j = (in + BIGT - 1) / BIGT;
     const int nb = ((t_i * t_j * ksplits + 7) / 8) * 8;
 #define MT_P8_GO(M, S) \
@@ -1094,7 +1097,7 @@ extern "C" int mt_gemm_single_launch(int mode, const void* A, const void* B, voi
   g.I = M; g.J = N; g.KK = K;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.active_steps = 1;
-  if (p8_wanted(M, N, 1)) {
+  if (p8_wanted(M, N, K, 1)) {
     const int t_i = (M + BIGT - 1) / BIGT, t_j = (N + BIGT - 1) / BIGT;
     const int nb = ((t_i * t_j + 7) / 8) * 8;
 #define MT_P8_GO(M, S) \
