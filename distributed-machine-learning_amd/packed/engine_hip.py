@@ -66,6 +66,10 @@ def _chain_rule(text: str):
 
 
 F32_CHAIN_RULE = _chain_rule(os.environ.get("MITUNE_F32_CHAIN_RULE", "128:4,32:2"))
+# Chains by batch size: a trial's batch size sets how many steps its epoch has (N // batch), so a chain that mixes batch sizes
+# runs the step count of its smallest batch with ever fewer live slots in every launch.  With one chain per batch size the
+# chains of large batches finish early and the long chain of small batches carries no dead tiles ("0": the mixed deal).
+CHAINS_BY_BATCH = os.environ.get("MITUNE_CHAINS_BY_BATCH", "1") != "0"
 DTYPES = ("bf16", "f32")
 
 
@@ -444,7 +448,7 @@ class HipPackEngine(PackEngine):
     def _build_gemm_tables(self, eval_mode: bool, ids: List[int], tag: str) -> Dict[str, Any]:
         members = [(slot, self.slots[slot]) for slot in ids]
         Lmax = max(len(s.spec.hidden_sizes) for _, s in members)
-        ksplits, ksplits0 = (1, 1) if eval_mode else self._choose_ksplits(ids)
+        ksplits, ksplits0 = (1, 1) if eval_mode else (getattr(self, "_pack_ksplits", None) or self._choose_ksplits(ids))
         self._ksplits, self._ksplits0 = ksplits, ksplits0
         T = self.capacity
         out: Dict[str, Any] = {"n_hidden": Lmax}
@@ -604,22 +608,54 @@ class HipPackEngine(PackEngine):
                 self.lib.mt_mlp_graph_destroy(ch.graph)
                 ch.graph = None
 
+    def _partition(self, n: int) -> List[List[int]]:
+        """Slot ids per chain.  Mixed deal: round-robin in (batch size, size) order, every chain gets a similar mix and the
+        same step count.  By batch size (exact-f32 packs of several batch sizes): one chain per batch size -- merged from
+        the small-pack end if there are more batch sizes than streams -- and, while the chain rule asks for more chains,
+        the chain with the most steps x slots (the critical path) split in two."""
+        order = sorted(self.slots, key=lambda k: (self.slots[k].spec.batch_size, -self.slots[k].layout.total, k))
+        by_batch: Dict[int, List[int]] = {}
+        for k in order:
+            by_batch.setdefault(min(self.slots[k].spec.batch_size, self.n_train), []).append(k)
+        # (packs too small for the chain rule stay one chain: 13 + 3 survivors as two chains ran 35 % slower than as one)
+        if not (CHAINS_BY_BATCH and self.f32 and not self.n_streams_override and len(by_batch) > 1 and n > 1):
+            return [sorted(order[c::n]) for c in range(n)]
+        groups = [by_batch[b] for b in sorted(by_batch)]            # ascending batch size = descending step count
+        while len(groups) > MAX_STREAMS:                             # merge the two neighbours with the fewest slots
+            i = min(range(len(groups) - 1), key=lambda j: len(groups[j]) + len(groups[j + 1]))
+            groups[i:i + 2] = [groups[i] + groups[i + 1]]
+
+        def load(g: List[int]) -> int:
+            return len(g) * max(self.n_train // min(self.slots[k].spec.batch_size, self.n_train) for k in g)
+
+        while len(groups) < min(n, MAX_STREAMS):
+            i = max(range(len(groups)), key=lambda j: (len(groups[j]) > 1, load(groups[j])))
+            if len(groups[i]) < 2:
+                break
+            groups[i:i + 1] = [groups[i][0::2], groups[i][1::2]]
+        return [sorted(g) for g in groups]
+
     def _build_chains(self) -> None:
         torch.cuda.synchronize(self.device)      # nothing may still be replaying a graph that is about to go
         self._drop_graphs()
-        n = self._n_chains()
-        # deal slots round-robin in (batch size, size) order so every chain gets a similar mix and step count
-        order = sorted(self.slots, key=lambda k: (self.slots[k].spec.batch_size, -self.slots[k].layout.total, k))
+        parts = self._partition(self._n_chains())
+        n = len(parts)
+        self._pack_ksplits = self._choose_ksplits(None)       # from the whole pack: how it is cut into chains changes no arithmetic
         self._chains = []
         for c in range(n):
             ch = _Chain()
-            ch.ids = sorted(order[c::n])
+            ch.ids = parts[c]
             ch.tag = f"t{c}_"
             ch.plan = self._build_plan(False, ch.ids, ch.tag, None if c == 0 else self._chain_scratch[c - 1])
             ch.steps = 0
             ch.counter = self._counters[c:c + 1]
             ch.graph = None
             self._chains.append(ch)
+        self._pack_ksplits = None
+        if os.environ.get("MITUNE_CHAIN_DEBUG"):
+            import sys
+            print(f"[mitune] chains: {[(len(ch.ids), sorted({self.slots[k].spec.batch_size for k in ch.ids})) for ch in self._chains]}",
+                  file=sys.stderr, flush=True)
         if n > 1:
             from .streams import pick_streams
             self._streams, _ = pick_streams(self.device, MAX_STREAMS)     # streams that land on different hardware queues
