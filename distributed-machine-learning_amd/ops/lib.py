@@ -69,6 +69,21 @@ class MlpPlan(C.Structure):
                 ("fwd_big", c_int32 * MT_MAX_LAYERS), ("bwd_big", c_int32 * MT_MAX_LAYERS)]
 
 
+class ResidentArgs(C.Structure):
+    """Mirror of ``MtResidentArgs`` (csrc/resident.hip): what the resident epoch kernel of an exact-f32 MLP pack reads."""
+    _fields_ = [("fwd", c_void_p * MT_MAX_LAYERS), ("dgrad", c_void_p * MT_MAX_LAYERS), ("wgrad", c_void_p * MT_MAX_LAYERS),
+                ("gather", c_void_p), ("head", c_void_p), ("opt", c_void_p), ("slot_list", c_void_p),
+                ("groups", c_void_p), ("wgs", c_void_p), ("P", c_void_p), ("G", c_void_p), ("M", c_void_p),
+                ("V", c_void_p), ("X", c_void_p), ("Y", c_void_p), ("head_scratch", c_void_p), ("sync", c_void_p),
+                ("error", c_void_p), ("timeout_ticks", C.c_uint64), ("slot_stride", c_size_t), ("n_rows", c_uint32),
+                ("F", c_int32), ("Fpad", c_int32), ("hb", c_int32), ("n_hidden", c_int32), ("max_chunks", c_int32),
+                ("rec", c_int32)]
+
+
+RES_GROUP_DTYPE = np.dtype([("first", "<i4"), ("count", "<i4"), ("nwg", "<i4"), ("pad", "<i4")], align=True)
+RES_WG_DTYPE = np.dtype([("group", "<i4"), ("member", "<i4")], align=True)
+
+
 class DpPlan(C.Structure):
     """Mirror of ``MtDpPlan`` (csrc/dp.hip): one data-parallel MLP trial's step, as the C++ driver walks it."""
     _fields_ = [("n_hidden", c_int32), ("batch", c_int32), ("F", c_int32), ("hb", c_int32), ("n_rows", c_uint32),
@@ -297,6 +312,12 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     for fn in (lib.mt_gemm_launch, lib.mt_gather_launch, lib.mt_head_loss_launch, lib.mt_head_eval_launch,
                lib.mt_optim_launch, lib.mt_mlp_train_steps, lib.mt_mlp_eval):
         fn.restype = C.c_int
+    if lib.mt_resident_args_sizeof() != C.sizeof(ResidentArgs):
+        raise KernelLibraryError("MtResidentArgs layout mismatch between lib.py and the library")
+    lib.mt_mlp_resident_capacity.argtypes = [C.c_int]
+    lib.mt_mlp_resident_capacity.restype = C.c_int
+    lib.mt_mlp_resident_launch.argtypes = [C.POINTER(ResidentArgs), C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_mlp_resident_launch.restype = C.c_int
     _lib = lib
     return lib
 

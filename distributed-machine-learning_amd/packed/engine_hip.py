@@ -71,6 +71,14 @@ F32_CHAIN_RULE = _chain_rule(os.environ.get("MITUNE_F32_CHAIN_RULE", "128:4,32:2
 # chains of large batches finish early and the long chain of small batches carries no dead tiles ("0": the mixed deal).
 CHAINS_BY_BATCH = os.environ.get("MITUNE_CHAINS_BY_BATCH", "1") != "0"
 DTYPES = ("bf16", "f32")
+# Resident epochs (exact-f32 packs): instead of one chain of grouped launches per step, ONE launch per epoch in which
+# groups of workgroups each train their own list of trials, step after step, synchronised only inside the group
+# (ops/csrc/resident.hip).  "auto": packs of up to RES_MAX_SLOTS trials whose shapes the kernel covers; "0": never.
+RESIDENT = os.environ.get("MITUNE_RESIDENT", "auto")
+RES_MAX_SLOTS = int(os.environ.get("MITUNE_RES_MAX_SLOTS", "64"))
+RES_GMIN = int(os.environ.get("MITUNE_RES_GMIN", "8"))            # fewest workgroups a group is given
+RES_TILE = int(os.environ.get("MITUNE_RES_TILE", "0"))            # 64 or 32; 0: by pack size
+RES_TIMEOUT_S = float(os.environ.get("MITUNE_RES_TIMEOUT_S", "20"))
 
 
 def ceil8(x: int) -> int:
@@ -146,6 +154,66 @@ def balanced_tiles(groups: List[Tuple[int, int, int, int]], ksplits: int = 1) ->
         for k, (gi, ti, tj) in enumerate(buckets[b]):
             out[k * N_XCD + b] = (gi, ti, tj)
     return out
+
+
+def resident_layout(costs: List[float], useful: List[int], n_wgs: int, gmin: int = 8):
+    """Cut ``n_wgs`` resident workgroups into groups and deal the trials of a pack to them.
+
+    ``costs[i]`` is trial i's arithmetic for the epoch, ``useful[i]`` the largest number of work items any of its phases
+    has (more workgroups than that would idle at every barrier).  There are as many groups as trials, or as many as
+    ``n_wgs // gmin`` when that is fewer; trials go to groups heaviest first, each to the group with the least work so
+    far (so a group's list is trained one trial after the other), and a group gets workgroups in proportion to its
+    work, at least ``gmin`` and at most what its widest trial can use.  Returns ``(groups, order, wgs)``: ``groups`` as
+    ``(first, count, nwg)`` into ``order`` (indices into ``costs``), and ``wgs`` -- one ``(group, member)`` per workgroup
+    of the grid, -1 for padding -- laid out so that a group's members are consecutive positions of one XCD wherever it
+    fits (workgroup b runs on XCD ``b % 8``; position p = xcd * per_xcd + index <-> b = index * 8 + xcd).
+    """
+    n = len(costs)
+    if n == 0 or n_wgs < gmin:
+        raise ValueError("no trials or fewer workgroups than one group takes")
+    n_groups = max(1, min(n, n_wgs // gmin))
+    lists: List[List[int]] = [[] for _ in range(n_groups)]
+    load = [0.0] * n_groups
+    for i in sorted(range(n), key=lambda k: (-costs[k], k)):
+        g = min(range(n_groups), key=lambda k: (load[k], k))
+        lists[g].append(i)
+        load[g] += max(costs[i], 1e-9)
+    total = sum(load)
+    cap = [max(gmin, max(useful[i] for i in lst)) for lst in lists]
+    nwg = [gmin] * n_groups
+    spare = n_wgs - gmin * n_groups
+    # proportional shares above the floor, capped; what the caps give back goes round once more
+    for _ in range(3):
+        open_ = [g for g in range(n_groups) if nwg[g] < cap[g]]
+        if spare <= 0 or not open_:
+            break
+        wsum = sum(load[g] for g in open_)
+        given = 0
+        for g in open_:
+            add = min(cap[g] - nwg[g], int(spare * load[g] / wsum))
+            nwg[g] += add
+            given += add
+        if given == 0:
+            break
+        spare -= given
+    used = sum(nwg)
+    per = (used + N_XCD - 1) // N_XCD
+    grid = per * N_XCD
+    wgs = np.zeros(grid, dtype=L.RES_WG_DTYPE)
+    wgs["group"] = -1
+    groups, order = [], []
+    # positions: big groups first, each XCD filled in turn; a group that does not fit the rest of an XCD simply runs over
+    pos = 0
+    for g in sorted(range(n_groups), key=lambda k: (-nwg[k], k)):
+        gi = len(groups)
+        groups.append((len(order), len(lists[g]), nwg[g]))
+        order.extend(lists[g])
+        for m in range(nwg[g]):
+            p = pos + m
+            xcd, idx = divmod(p, per)
+            wgs[idx * N_XCD + xcd] = (gi, m)
+        pos += nwg[g]
+    return groups, order, wgs
 
 
 class HipPackEngine(PackEngine):
@@ -233,6 +301,11 @@ class HipPackEngine(PackEngine):
         self._chain_scratch = [torch.zeros_like(self.head_scratch) for _ in range(MAX_STREAMS - 1)]
         self._chains: List[_Chain] = []
         self.n_streams_override = int(os.environ.get("MITUNE_STREAMS", kw.get("streams", 0)) or 0)
+        self._res: Optional[Dict[str, Any]] = None      # resident-epoch launch state of the current pack (or None)
+        self._res_sync = torch.zeros(max(T, 8), device=dev, dtype=torch.int32)
+        self._res_error = torch.zeros(1, device=dev, dtype=torch.int32)
+        self._res_launched = False
+        self.resident_epochs = 0
         self._train_loss: Dict[int, float] = {}
         self._loss_pending = False          # the epoch's loss accumulators have not been read by the host yet
         self._round_steps: Dict[int, int] = {}
@@ -668,14 +741,126 @@ class HipPackEngine(PackEngine):
                 if not ch.graph:
                     raise L.KernelLibraryError(f"hipGraph capture of a training block failed with code {err.value}")
 
+    # ------------------------------------------------------------------ resident epochs
+    def _resident_reason(self) -> Optional[str]:
+        """None when this pack can train as one resident launch per epoch, else why not."""
+        if RESIDENT == "0" or not self.f32:
+            return "off"
+        if self.n_streams_override:
+            return "explicit stream count"
+        if RESIDENT != "1" and len(self.slots) > RES_MAX_SLOTS:
+            return "pack too large"
+        if self.Fpad // 4 > 256:
+            return "rows too wide for the gather"
+        for s in self.slots.values():
+            if s.spec.gradient_clipping > 0:
+                return "gradient clipping needs the norm of the whole gradient before the update"
+            if s.layout.hidden[-1] > 512:
+                return "last hidden layer wider than 512"
+        return None
+
+    def _slot_cost(self, s: "_HSlot", edge: int) -> Tuple[float, int]:
+        """(arithmetic of one epoch, most work items in any phase) of a trial under tile edge ``edge``."""
+        lay, b = s.layout, min(s.spec.batch_size, self.n_train)
+        steps = self.n_train // b
+        t = lambda v: (v + edge - 1) // edge      # noqa: E731
+        macs, items = lay.hidden[-1], 0
+        for l, h in enumerate(lay.hidden):
+            k = lay.in_dims[l]
+            macs += h * k
+            items = max(items, t(b) * t(h), t(h) * t(k) + (t(b) * t(k) if l > 0 else 0))
+        return 6.0 * macs * b * steps, items
+
+    def _build_resident(self) -> None:
+        ids = sorted(self.slots)
+        cap64, cap32 = (int(self.lib.mt_mlp_resident_capacity(e)) for e in (64, 32))
+        if cap64 <= 0 or cap32 <= 0:
+            raise L.KernelLibraryError("the runtime reports no occupancy for the resident epoch kernel")
+        edge = RES_TILE if RES_TILE in (32, 64) else (32 if len(ids) * 24 <= cap32 else 64)
+        n_wgs = cap32 if edge == 32 else cap64
+        cu = [self._slot_cost(self.slots[k], edge) for k in ids]
+        groups, order, wgs = resident_layout([c for c, _ in cu], [u for _, u in cu], n_wgs, RES_GMIN)
+        self._pack_ksplits = (1, 1)            # unsplit weight gradients: every tile holds its whole contraction
+        try:
+            plan = self._build_plan(False, ids, "r_")
+        finally:
+            self._pack_ksplits = None
+        a = L.ResidentArgs()
+        for l in range(plan.n_hidden):
+            a.fwd[l], a.dgrad[l], a.wgrad[l] = plan.fwd_groups[l], plan.dgrad_groups[l], plan.wgrad_groups[l]
+        garr = np.array([(f, c, n, 0) for f, c, n in groups], dtype=L.RES_GROUP_DTYPE)
+        a.slot_list = self._upload("r_slot_list", np.array([ids[i] for i in order], dtype=np.int32))
+        a.groups = self._upload("r_groups", garr)
+        a.wgs = self._upload("r_wgs", wgs)
+        a.head = plan.head
+        a.P, a.G, a.M, a.V = plan.P, plan.G, plan.M, plan.V
+        a.X, a.Y = plan.X, plan.Y
+        a.head_scratch = plan.head_scratch
+        a.sync, a.error = self._res_sync.data_ptr(), self._res_error.data_ptr()
+        a.timeout_ticks = int(RES_TIMEOUT_S * 1e8)              # 100 MHz clock
+        a.slot_stride, a.n_rows = plan.slot_stride, plan.n_rows
+        a.F, a.Fpad, a.hb, a.n_hidden = plan.F, plan.Fpad, plan.hb, plan.n_hidden
+        rows = max(s.spec.batch_size for s in self.slots.values())
+        width = max(max(s.spec.hidden_sizes) for s in self.slots.values())
+        a.max_chunks, a.rec = (rows + 31) // 32, ceil8(width) + 8      # layout of the head kernel's partial records
+        if len(groups) > self._res_sync.numel():
+            raise L.KernelLibraryError("more resident groups than arrival counters")
+        self._res = {"args": a, "plan": plan, "ids": ids, "n_wgs": len(wgs), "n_groups": len(groups), "edge": edge,
+                     "groups": groups}
+        if os.environ.get("MITUNE_CHAIN_DEBUG"):
+            import sys
+            print(f"[mitune] resident: {len(ids)} trials, {len(groups)} groups of {sorted({n for _, _, n in groups})} "
+                  f"workgroups, grid {len(wgs)}, tile {edge}", file=sys.stderr, flush=True)
+
+    def _check_resident(self) -> None:
+        """Raise if the previous resident launch gave up at a barrier (reads one word: waits for that launch)."""
+        if not self._res_launched:
+            return
+        self._res_launched = False
+        if int(self._res_error.item()) != 0:
+            self._res_error.zero_()
+            raise L.KernelLibraryError(
+                f"a resident training epoch was abandoned: a group of workgroups waited more than {RES_TIMEOUT_S} s for "
+                "its members (is another process running resident kernels on this GPU?); the trials of this pack "
+                "are in an undefined state.  MITUNE_RESIDENT=0 selects the grouped launches.")
+
+    def _prepare(self) -> None:
+        """(Re)build whatever the current membership of the pack needs: the resident launch or the chains, and the
+        validation plan."""
+        self._res = None
+        if self._resident_reason() is None:
+            torch.cuda.synchronize(self.device)
+            self._drop_graphs()
+            self._chains = []
+            self._build_resident()
+        else:
+            self._build_chains()
+        self._tables["eval_plan"] = self._build_plan(eval_mode=True)
+        self._dirty = False
+
+    def _train_epoch_resident(self, main) -> None:
+        r = self._res
+        a, plan = r["args"], r["plan"]
+        self._epoch_tables(plan, r["ids"], "r_")
+        a.gather, a.opt = plan.gather, plan.opt
+        L.check(self.lib.mt_mlp_resident_launch(C.byref(a), r["n_wgs"], r["n_groups"], r["edge"], main.cuda_stream),
+                "mt_mlp_resident_launch")
+        self._res_launched = True
+        self.resident_epochs += 1
+
     # ------------------------------------------------------------------ training / evaluation
     def train_epoch(self):
         if not self.slots:
             return
-        if self._dirty or not self._chains:
-            self._build_chains()
-            self._tables["eval_plan"] = self._build_plan(eval_mode=True)
-            self._dirty = False
+        self._check_resident()
+        if self._dirty or (not self._chains and self._res is None):
+            self._prepare()
+        if self._res is not None:
+            self.loss_acc.zero_()
+            main = torch.cuda.current_stream(self.device)
+            self._train_epoch_resident(main)
+            self._finish_epoch(main)
+            return
         for ch in self._chains:
             ch.steps = self._epoch_tables(ch.plan, ch.ids, ch.tag)
         self.loss_acc.zero_()
@@ -707,6 +892,9 @@ class HipPackEngine(PackEngine):
                                                        ch.steps - nb * GRAPH_STEPS, st.cuda_stream),
                         "mt_mlp_train_steps_at")
                 main.wait_stream(st)
+        self._finish_epoch(main)
+
+    def _finish_epoch(self, main) -> None:
         L.check(self.lib.mt_stamp_launch(self._stamps[1:].data_ptr(), main.cuda_stream), "mt_stamp_launch")
         self._round_steps = {}
         for slot, s in self.slots.items():
@@ -731,9 +919,7 @@ class HipPackEngine(PackEngine):
 
     def _enqueue_eval(self) -> None:
         if self._dirty or "eval_plan" not in self._tables:
-            self._build_chains()
-            self._tables["eval_plan"] = self._build_plan(eval_mode=True)
-            self._dirty = False
+            self._prepare()
         plan = self._tables["eval_plan"]
         self.metrics.zero_()
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -776,3 +962,4 @@ class HipPackEngine(PackEngine):
         if self._chains:
             torch.cuda.synchronize(self.device)
             self._drop_graphs()
+        self._check_resident()
