@@ -63,20 +63,32 @@ struct MtResidentArgs {
   int32_t F, Fpad, hb;
   int32_t n_hidden;             // layers the tables cover (a slot may use fewer: its group entries are empty)
   int32_t max_chunks, rec;      // layout of the head kernel's partial records
+  int32_t sync_mode;            // 0: the barrier described at res_group_barrier; 1, 2: its measurement variants
+  unsigned long long* prof;     // null, or 8 words: member 0 of group 0 adds its ticks in {forward, head, backward, optimiser,
+                                // barriers} and its step count
 };
 
-// Barrier among the nwg workgroups of one group.  Every wave publishes its stores device-wide before its workgroup
-// arrives, and refreshes its view after the last arrival: the members of a group may sit on different XCDs.
+// Barrier among the nwg workgroups of one group; the members may sit on different XCDs, so what they wrote has to become
+// visible device-wide.  Every wave first waits for its own stores to reach the L2 (the vector cache is write-through);
+// after the workgroup barrier ONE wave publishes (device-scope release: L2 write-back), arrives, waits for the last
+// arrival and refreshes (device-scope acquire: the vector cache of this CU, which all waves of the workgroup share, and
+// stale L2 lines are dropped).  sync_mode 1 runs the fences in every wave instead (for comparison), 2 drops them
+// (measurement of the bare barrier only: results are undefined when a group spans XCDs).
 __device__ __forceinline__ bool res_group_barrier(unsigned int* counter, unsigned int target, int* error,
-                                                  unsigned long long timeout_ticks, int* ok_s) {
-  __threadfence();
+                                                  unsigned long long timeout_ticks, int* ok_s, int sync_mode) {
+  if (sync_mode == 1) __threadfence();
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (sync_mode != 2) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-back is complete before the arrival shows
+    }
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int ok = 1;
     const unsigned long long t0 = wall_clock64();
     unsigned int spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 63u) == 0u) {
         if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
@@ -87,20 +99,24 @@ __device__ __forceinline__ bool res_group_barrier(unsigned int* counter, unsigne
         }
       }
     }
+    if (sync_mode != 2) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the invalidate is complete before the other waves go on
+    }
     *ok_s = ok;
   }
   __syncthreads();
-  __threadfence();
+  if (sync_mode == 1) __threadfence();
   return *ok_s != 0;
 }
 
 template <int T>
 __device__ __forceinline__ int res_tiles(int n) { return (n + T - 1) / T; }
 
-template <int T>
+template <int T, int NS>
 __global__ __launch_bounds__(F32_THREADS) void mt_mlp_resident_kernel(MtResidentArgs a) {
-  // the GEMM tile's two stages; the head body's reduction arrays alias the front of it
-  __shared__ __attribute__((aligned(16))) uint8_t lds[(2 * 2 * T * 128) > 8704 ? (2 * 2 * T * 128) : 8704];
+  // the GEMM tile's NS stages; the head body's reduction arrays alias the front of it
+  __shared__ __attribute__((aligned(16))) uint8_t lds[(NS * 2 * T * 128) > 8704 ? (NS * 2 * T * 128) : 8704];
   __shared__ int ok_s;
   float (*red)[512] = reinterpret_cast<float (*)[512]>(lds);
   float (*red_s)[2] = reinterpret_cast<float (*)[2]>(lds + HL_WAVES * 512 * 4);
@@ -111,10 +127,22 @@ __global__ __launch_bounds__(F32_THREADS) void mt_mlp_resident_kernel(MtResident
   const int w = me.member, nwg = grp.nwg;
   unsigned int* counter = a.sync + me.group;
   unsigned int target = 0u;
-#define RES_BARRIER()                                                                                   \
+  const bool prof = a.prof != nullptr && me.group == 0 && w == 0;
+  unsigned long long tick = prof ? wall_clock64() : 0ull, acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+#define RES_MARK(k)                                          \
+  do {                                                       \
+    if (prof) {                                              \
+      const unsigned long long now_ = wall_clock64();        \
+      acc[k] += now_ - tick;                                 \
+      tick = now_;                                           \
+    }                                                        \
+  } while (0)
+#define RES_BARRIER(k)                                                                                  \
   do {                                                                                                  \
+    RES_MARK(k);                                                                                        \
     target += (unsigned int)nwg;                                                                        \
-    if (!res_group_barrier(counter, target, a.error, a.timeout_ticks, &ok_s)) return;                   \
+    if (!res_group_barrier(counter, target, a.error, a.timeout_ticks, &ok_s, a.sync_mode)) return;      \
+    RES_MARK(4);                                                                                        \
   } while (0)
 
   const int cpr = a.Fpad / 4;                     // gather: 16-byte chunks per row, rows per 256-thread block
@@ -134,7 +162,7 @@ __global__ __launch_bounds__(F32_THREADS) void mt_mlp_resident_kernel(MtResident
 
     for (int k = w; k < gather_items; k += nwg)
       mt_gather_body<true>(a.gather, a.slot_list, a.X, a.Y, a.n_rows, a.F, a.Fpad, a.hb, 0, k, by);
-    RES_BARRIER();
+    RES_BARRIER(3);
 
     for (int step = 0; step < nsteps; ++step) {
       // ---- forward
@@ -144,17 +172,17 @@ __global__ __launch_bounds__(F32_THREADS) void mt_mlp_resident_kernel(MtResident
         for (int k = w; k < n; k += nwg) {
           MtTile t;
           t.group = slot; t.ti = (int16_t)(k / tj_n); t.tj = (int16_t)(k % tj_n);
-          f32_gemm_tile<0, 2, T>(a.fwd[l], t, step, MT_GEMM_FLAG_RELU, 0, 0, 1, 0, lds);
+          f32_gemm_tile<0, NS, T>(a.fwd[l], t, step, MT_GEMM_FLAG_RELU, 0, 0, 1, 0, lds);
           __syncthreads();
         }
-        RES_BARRIER();
+        RES_BARRIER(0);
       }
       // ---- head + loss + gradient entering the last hidden layer (partial records per 32 rows)
       for (int k = w; k < head_items; k += nwg) {
         mt_head_loss_body<1, true>(a.head, a.slot_list, step, a.head_scratch, a.max_chunks, a.rec, k, by, red, red_s);
         __syncthreads();
       }
-      RES_BARRIER();
+      RES_BARRIER(1);
       // ---- backward, last layer first: weight-gradient tiles, input-gradient tiles, and (once) the head reduction
       for (int l = L - 1; l >= 0; --l) {
         const MtGemmGroup* wg = a.wgrad[l];
@@ -171,17 +199,17 @@ __global__ __launch_bounds__(F32_THREADS) void mt_mlp_resident_kernel(MtResident
           t.group = slot;
           if (k < n_w) {
             t.ti = (int16_t)(k / wj_n); t.tj = (int16_t)(k % wj_n);
-            f32_gemm_tile<2, 2, T>(wg, t, step, MT_GEMM_FLAG_DBIAS, 0, 0, 1, 0, lds);
+            f32_gemm_tile<2, NS, T>(wg, t, step, MT_GEMM_FLAG_DBIAS, 0, 0, 1, 0, lds);
           } else if (k < n_w + n_d) {
             const int q = k - n_w;
             t.ti = (int16_t)(q / dj_n); t.tj = (int16_t)(q % dj_n);
-            f32_gemm_tile<1, 2, T>(a.dgrad[l], t, step, MT_GEMM_FLAG_MASK, 0, 0, 1, 0, lds);
+            f32_gemm_tile<1, NS, T>(a.dgrad[l], t, step, MT_GEMM_FLAG_MASK, 0, 0, 1, 0, lds);
           } else {
             mt_head_reduce_body(a.head, a.slot_list, step, a.head_scratch, a.max_chunks, a.rec, by);
           }
           __syncthreads();
         }
-        RES_BARRIER();
+        RES_BARRIER(2);
       }
       // ---- optimiser blocks, and the next step's mini-batch
       const int n = opt_items + (step + 1 < nsteps ? gather_items : 0);
@@ -192,24 +220,40 @@ __global__ __launch_bounds__(F32_THREADS) void mt_mlp_resident_kernel(MtResident
         else
           mt_gather_body<true>(a.gather, a.slot_list, a.X, a.Y, a.n_rows, a.F, a.Fpad, a.hb, step + 1, k - opt_items, by);
       }
-      RES_BARRIER();
+      RES_BARRIER(3);
+    }
+    if (prof && threadIdx.x == 0) {
+      for (int k = 0; k < 5; ++k) a.prof[k] += acc[k], acc[k] = 0ull;
+      a.prof[5] += (unsigned long long)nsteps;
     }
   }
 #undef RES_BARRIER
+#undef RES_MARK
 }
 
 extern "C" int mt_resident_args_sizeof() { return (int)sizeof(MtResidentArgs); }
 
-// Workgroups of the resident kernel the whole chip holds at once (tile edge 64 or 32); 0 on error.
+// tile_edge: 64 or 32 (two-stage tile pipeline), 65 or 33 (the same edges on the three-stage, one-barrier pipeline).
+#define RES_DISPATCH(EDGE, CALL)                       \
+  switch (EDGE) {                                      \
+    case 64: { CALL(64, 2); } break;                   \
+    case 32: { CALL(32, 2); } break;                   \
+    case 65: { CALL(64, 3); } break;                   \
+    default: { CALL(32, 3); } break;                   \
+  }
+
+static bool res_edge_ok(int e) { return e == 64 || e == 32 || e == 65 || e == 33; }
+
+// Workgroups of the resident kernel the whole chip holds at once; 0 on error.
 extern "C" int mt_mlp_resident_capacity(int tile_edge) {
   int per_cu = 0, dev = 0;
   hipDeviceProp_t prop;
+  if (!res_edge_ok(tile_edge)) return 0;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  hipError_t e;
-  if (tile_edge == 32)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mt_mlp_resident_kernel<32>, F32_THREADS, 0);
-  else
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mt_mlp_resident_kernel<64>, F32_THREADS, 0);
+  hipError_t e = hipSuccess;
+#define RES_OCC(T_, NS_) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mt_mlp_resident_kernel<T_, NS_>, F32_THREADS, 0)
+  RES_DISPATCH(tile_edge, RES_OCC)
+#undef RES_OCC
   if (e != hipSuccess || per_cu <= 0) return 0;
   return per_cu * prop.multiProcessorCount;
 }
@@ -223,12 +267,11 @@ extern "C" int mt_mlp_resident_launch(const MtResidentArgs* args, int n_wgs, int
   if (args->n_hidden < 1 || args->n_hidden > RES_MAX_LAYERS) return -10;
   if ((args->Fpad & 7) || args->Fpad / 4 > 256 || args->Fpad < args->F) return -2;
   if (args->sync == nullptr || args->error == nullptr || args->timeout_ticks == 0ull) return -3;
-  if (tile_edge != 64 && tile_edge != 32) return -7;
+  if (!res_edge_ok(tile_edge)) return -7;
   if (n_wgs > mt_mlp_resident_capacity(tile_edge)) return -8;      // a group barrier needs the whole grid on the chip
   if (hipMemsetAsync(args->sync, 0, sizeof(unsigned int) * (size_t)n_groups, stream) != hipSuccess) return -9;
-  if (tile_edge == 32)
-    hipLaunchKernelGGL(mt_mlp_resident_kernel<32>, dim3(n_wgs), dim3(F32_THREADS), 0, stream, *args);
-  else
-    hipLaunchKernelGGL(mt_mlp_resident_kernel<64>, dim3(n_wgs), dim3(F32_THREADS), 0, stream, *args);
+#define RES_GO(T_, NS_) hipLaunchKernelGGL((mt_mlp_resident_kernel<T_, NS_>), dim3(n_wgs), dim3(F32_THREADS), 0, stream, *args)
+  RES_DISPATCH(tile_edge, RES_GO)
+#undef RES_GO
   return (int)hipGetLastError();
 }

@@ -77,7 +77,7 @@ class ResidentArgs(C.Structure):
                 ("V", c_void_p), ("X", c_void_p), ("Y", c_void_p), ("head_scratch", c_void_p), ("sync", c_void_p),
                 ("error", c_void_p), ("timeout_ticks", C.c_uint64), ("slot_stride", c_size_t), ("n_rows", c_uint32),
                 ("F", c_int32), ("Fpad", c_int32), ("hb", c_int32), ("n_hidden", c_int32), ("max_chunks", c_int32),
-                ("rec", c_int32)]
+                ("rec", c_int32), ("sync_mode", c_int32), ("prof", c_void_p)]
 
 
 RES_GROUP_DTYPE = np.dtype([("first", "<i4"), ("count", "<i4"), ("nwg", "<i4"), ("pad", "<i4")], align=True)

@@ -73,8 +73,13 @@ CHAINS_BY_BATCH = os.environ.get("MITUNE_CHAINS_BY_BATCH", "1") != "0"
 DTYPES = ("bf16", "f32")
 # Resident epochs (exact-f32 packs): instead of one chain of grouped launches per step, ONE launch per epoch in which
 # groups of workgroups each train their own list of trials, step after step, synchronised only inside the group
-# (ops/csrc/resident.hip).  "auto": packs of up to RES_MAX_SLOTS trials whose shapes the kernel covers; "0": never.
-RESIDENT = os.environ.get("MITUNE_RESIDENT", "auto")
+# (ops/csrc/resident.hip).  Bit-identical to the grouped launches, and OFF by default: on 16 late-round survivors it
+# measured 436 us per step of the longest trial against 140 us for the grouped launches.  A group barrier costs 8-16 us
+# (device-scope write-back and invalidate, the wait for the slowest member) and there are 2L + 2 of them per step, and with
+# the two workgroups per CU that the kernel's registers allow, a tile's K-loop runs at memory latency (about 1.4 us per
+# 32-deep step, where five co-resident workgroups of a grouped launch overlap it).  "auto": packs of up to RES_MAX_SLOTS
+# trials whose shapes the kernel covers; "1": any such pack; "0": never.
+RESIDENT = os.environ.get("MITUNE_RESIDENT", "0")
 RES_MAX_SLOTS = int(os.environ.get("MITUNE_RES_MAX_SLOTS", "64"))
 RES_GMIN = int(os.environ.get("MITUNE_RES_GMIN", "8"))            # fewest workgroups a group is given
 RES_TILE = int(os.environ.get("MITUNE_RES_TILE", "0"))            # 64 or 32; 0: by pack size
@@ -776,9 +781,14 @@ class HipPackEngine(PackEngine):
         cap64, cap32 = (int(self.lib.mt_mlp_resident_capacity(e)) for e in (64, 32))
         if cap64 <= 0 or cap32 <= 0:
             raise L.KernelLibraryError("the runtime reports no occupancy for the resident epoch kernel")
-        edge = RES_TILE if RES_TILE in (32, 64) else (32 if len(ids) * 24 <= cap32 else 64)
-        n_wgs = cap32 if edge == 32 else cap64
-        cu = [self._slot_cost(self.slots[k], edge) for k in ids]
+        edge = RES_TILE if RES_TILE in (32, 33, 64, 65) else (32 if len(ids) * 24 <= cap32 else 64)
+        n_wgs = int(self.lib.mt_mlp_resident_capacity(edge))
+        if n_wgs <= 0:
+            raise L.KernelLibraryError("the runtime reports no occupancy for the resident epoch kernel")
+        cap_env = int(os.environ.get("MITUNE_RES_WGS", "0"))
+        if cap_env > 0:
+            n_wgs = min(n_wgs, cap_env)
+        cu = [self._slot_cost(self.slots[k], 32 if edge in (32, 33) else 64) for k in ids]
         groups, order, wgs = resident_layout([c for c, _ in cu], [u for _, u in cu], n_wgs, RES_GMIN)
         self._pack_ksplits = (1, 1)            # unsplit weight gradients: every tile holds its whole contraction
         try:
@@ -803,6 +813,10 @@ class HipPackEngine(PackEngine):
         rows = max(s.spec.batch_size for s in self.slots.values())
         width = max(max(s.spec.hidden_sizes) for s in self.slots.values())
         a.max_chunks, a.rec = (rows + 31) // 32, ceil8(width) + 8      # layout of the head kernel's partial records
+        a.sync_mode = int(os.environ.get("MITUNE_RES_SYNC", "0"))
+        if os.environ.get("MITUNE_RES_PROF"):
+            self._res_prof = torch.zeros(8, device=self.device, dtype=torch.int64)
+            a.prof = self._res_prof.data_ptr()
         if len(groups) > self._res_sync.numel():
             raise L.KernelLibraryError("more resident groups than arrival counters")
         self._res = {"args": a, "plan": plan, "ids": ids, "n_wgs": len(wgs), "n_groups": len(groups), "edge": edge,

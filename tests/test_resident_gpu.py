@@ -107,9 +107,11 @@ def test_packs_the_resident_kernel_does_not_cover_fall_back(monkeypatch):
     assert n == 0
 
 
-def test_membership_changes_between_resident_epochs():
+def test_membership_changes_between_resident_epochs(monkeypatch):
     """Evict one trial and load another between epochs: the launch state is rebuilt, survivors continue unchanged."""
+    from mitune.packed import engine_hip
     from mitune.packed.engine_hip import HipPackEngine
+    monkeypatch.setattr(engine_hip, "RESIDENT", "auto")
     tr = _trainable(epochs=3)
 
     def go(swap):
