@@ -126,11 +126,16 @@ def main():
                     t66 = min(p64.time(fn, args.iters, 1, 65) for _ in range(3))       # 64-tiles, three-stage pipeline
                     p32 = Problem(mode, T, args.batch, args.width, ks, edge=32, dtype=torch.float32)
                     t32 = min(p32.time(fn, args.iters, 1, 32) for _ in range(3))
+                    t64d = min(p64.time(fn, args.iters, 1, 66) for _ in range(3))      # 64-tiles, four stages, one barrier
+                    t32d = min(p32.time(fn, args.iters, 1, 33) for _ in range(3))      # 32-tiles, eight stages, one barrier
+                    ku = {c: min((p64 if c == 67 else p32).time(fn, args.iters, 1, c) for _ in range(3)) for c in (35,)}
                     print(f"f32 slots {T:4d}  {names[mode]}  ksplits {ks}  batch {args.batch} width {args.width}  "
                           f"128-tile {t128:8.2f} us ({p128.flop / t128 / 1e6:6.1f} TF/s, {p128.ntiles} tiles)  "
                           f"64-tile {t64:8.2f} us ({p64.flop / t64 / 1e6:6.1f} TF/s, {p64.ntiles} tiles)  "
                           f"64-tile 3-stage {t66:8.2f} us ({p64.flop / t66 / 1e6:6.1f} TF/s)  "
-                          f"32-tile {t32:8.2f} us ({p32.flop / t32 / 1e6:6.1f} TF/s, {p32.ntiles} tiles)", flush=True)
+                          f"32-tile {t32:8.2f} us ({p32.flop / t32 / 1e6:6.1f} TF/s, {p32.ntiles} tiles)  "
+                          f"64-tile 4-stage {t64d:8.2f} us  32-tile 8-stage {t32d:8.2f} us  "
+                          f"32-tile 8-stage 4 K-steps per barrier {ku[35]:7.2f} us", flush=True)
         return
     fn = so.mt_gemm_launch
     for T in args.slots:

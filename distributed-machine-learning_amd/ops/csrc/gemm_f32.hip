@@ -27,19 +27,19 @@
 // output columns of one row (16-byte epilogue stores).
 #include "mt_gemm_f32_tile.h"
 
-template <int MODE, int NSTAGE, int T>
+template <int MODE, int NSTAGE, int T, int KU = 1>
 __global__ __launch_bounds__(F32_THREADS) void mt_gemm_f32_kernel(const MtGemmGroup* __restrict__ groups,
                                                                   const MtTile* __restrict__ tiles, int step, int flags,
                                                                   int arow0, int i_override, int ksplits,
                                                                   size_t split_stride, const int* __restrict__ step_base) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * 2 * T * 128];
-  f32_gemm_tile<MODE, NSTAGE, T>(groups, tiles[blockIdx.x], mt_step(step, step_base), flags, arow0, i_override, ksplits,
-                                 split_stride, lds);
+  f32_gemm_tile<MODE, NSTAGE, T, KU>(groups, tiles[blockIdx.x], mt_step(step, step_base), flags, arow0, i_override,
+                                     ksplits, split_stride, lds);
 }
 
 // Backward of one layer in ONE launch (weight-gradient tiles, input-gradient tiles, and optionally the head
 // kernel's partial-record reduction as extra workgroups), as in gemm.hip.
-template <int NSTAGE, int T>
+template <int NSTAGE, int T, int KU = 1>
 __global__ __launch_bounds__(F32_THREADS) void mt_gemm_f32_bwd_kernel(const MtGemmGroup* __restrict__ wgroups,
                                                                       const MtTile* __restrict__ wtiles, int n_wtiles,
                                                                       const MtGemmGroup* __restrict__ dgroups,
@@ -51,42 +51,55 @@ __global__ __launch_bounds__(F32_THREADS) void mt_gemm_f32_bwd_kernel(const MtGe
   const int step = mt_step(step_imm, step_base);
   const int b = (int)blockIdx.x;
   if (b < n_wtiles)
-    f32_gemm_tile<2, NSTAGE, T>(wgroups, wtiles[b], step, MT_GEMM_FLAG_DBIAS, 0, 0, ksplits, split_stride, lds);
+    f32_gemm_tile<2, NSTAGE, T, KU>(wgroups, wtiles[b], step, MT_GEMM_FLAG_DBIAS, 0, 0, ksplits, split_stride, lds);
   else if (b < n_wtiles + n_dtiles)
-    f32_gemm_tile<1, NSTAGE, T>(dgroups, dtiles[b - n_wtiles], step, MT_GEMM_FLAG_MASK, 0, 0, 1, 0, lds);
+    f32_gemm_tile<1, NSTAGE, T, KU>(dgroups, dtiles[b - n_wtiles], step, MT_GEMM_FLAG_MASK, 0, 0, 1, 0, lds);
   else
     mt_head_reduce_body(hr.slots, hr.ids, step, hr.scratch, hr.max_chunks, hr.rec, b - n_wtiles - n_dtiles);
 }
 
-// tile_edge: 128 or 64 (both on the two-stage, two-barrier pipeline: 32 KB of LDS per 64-tile workgroup, so five of
-// them fit a CU and a launch of four tiles per CU has no second round; measured 7-22 % faster than the three-stage,
-// one-barrier form, which 65 still selects for comparison); the tile list must have been built with the same edge.
+// tile_edge selects tile and pipeline: 128, 64, 32 = that edge on the two-stage, two-barrier pipeline (a 64-tile workgroup
+// holds 32 KB of LDS, so five fit a CU: the throughput forms); 65 = 64-tiles, three stages, one barrier (kept for
+// comparison: 7-22 % slower than 64); 66 = 64-tiles, four stages and 33 = 32-tiles, eight stages (64 KB of LDS either
+// way) and 35 = 33 with four K-steps per barrier: deep-prefetch forms for launches of a few tiles per CU.  Measured on
+// 13-slot launches they change nothing that matters (weight gradient of 16 tiles over 1024 rows: 19.4 us with two stages,
+// 20.0 with eight, 17.4 with four K-steps per barrier), which shows that such a tile is bound by the dependent chain inside
+// a K-step (LDS fragment reads -> MFMAs on one accumulator), not by memory latency or barriers; the engine does not
+// select them.  The tile list must have been built with the same edge.
+#define MT_F32_FORMS(CALL)                    \
+  switch (tile_edge) {                        \
+    case 128: { CALL(2, 128); } break;        \
+    case 64: { CALL(2, 64); } break;          \
+    case 65: { CALL(3, 64); } break;          \
+    case 66: { CALL(4, 64); } break;          \
+    case 33: { CALL(8, 32); } break;          \
+    case 35: { CALL(8, 32, 4); } break;       \
+    default: { CALL(2, 32); } break;          \
+  }
+
+static bool f32_edge_ok(int e) { return e == 128 || (e >= 64 && e <= 66) || e == 32 || e == 33 || e == 35; }
+
 extern "C" int mt_gemm_f32_launch(int mode, const MtGemmGroup* groups, const MtTile* tiles, int ntiles, int step,
                                   int flags, int arow0, int i_override, int ksplits, size_t split_stride, int tile_edge,
                                   hipStream_t stream) {
   if (ntiles <= 0) return 0;
   if (ksplits < 1 || ksplits > 127 || (mode != 2 && ksplits != 1)) return -5;
-  if (tile_edge != 128 && tile_edge != 64 && tile_edge != 65 && tile_edge != 32) return -7;      // 65: 64-tiles, three stages
+  if (!f32_edge_ok(tile_edge)) return -7;
+  if (mode < 0 || mode > 2) return -1;
   dim3 grid(ntiles), block(F32_THREADS);
-#define MT_F32_GO(M, N, T_, KS, SS)                                                                                       \
-  hipLaunchKernelGGL((mt_gemm_f32_kernel<M, N, T_>), grid, block, 0, stream, groups, tiles, step, flags, arow0, i_override, \
-                     KS, SS, mt_step_base_tls)
-  const bool big = tile_edge == 128, two = tile_edge == 64;
-  if (tile_edge == 32) {        // latency form: launches of a few hundred 64-tiles fill the chip four times better
-    switch (mode) {
-      case 0: MT_F32_GO(0, 2, 32, 1, (size_t)0); break;
-      case 1: MT_F32_GO(1, 2, 32, 1, (size_t)0); break;
-      case 2: MT_F32_GO(2, 2, 32, ksplits, split_stride); break;
-      default: return -1;
-    }
-    return (int)hipGetLastError();
-  }
-  switch (mode) {
-    case 0: if (big) MT_F32_GO(0, 2, 128, 1, (size_t)0); else if (two) MT_F32_GO(0, 2, 64, 1, (size_t)0); else MT_F32_GO(0, 3, 64, 1, (size_t)0); break;
-    case 1: if (big) MT_F32_GO(1, 2, 128, 1, (size_t)0); else if (two) MT_F32_GO(1, 2, 64, 1, (size_t)0); else MT_F32_GO(1, 3, 64, 1, (size_t)0); break;
-    case 2: if (big) MT_F32_GO(2, 2, 128, ksplits, split_stride); else if (two) MT_F32_GO(2, 2, 64, ksplits, split_stride); else MT_F32_GO(2, 3, 64, ksplits, split_stride); break;
-    default: return -1;
-  }
+#define MT_F32_GO(...)                                                                                                    \
+  do {                                                                                                                    \
+    if (mode == 0)                                                                                                        \
+      hipLaunchKernelGGL((mt_gemm_f32_kernel<0, __VA_ARGS__>), grid, block, 0, stream, groups, tiles, step, flags, arow0,       \
+                         i_override, 1, (size_t)0, mt_step_base_tls);                                                     \
+    else if (mode == 1)                                                                                                   \
+      hipLaunchKernelGGL((mt_gemm_f32_kernel<1, __VA_ARGS__>), grid, block, 0, stream, groups, tiles, step, flags, arow0,       \
+                         i_override, 1, (size_t)0, mt_step_base_tls);                                                     \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((mt_gemm_f32_kernel<2, __VA_ARGS__>), grid, block, 0, stream, groups, tiles, step, flags, arow0,       \
+                         i_override, ksplits, split_stride, mt_step_base_tls);                                            \
+  } while (0)
+  MT_F32_FORMS(MT_F32_GO)
 #undef MT_F32_GO
   return (int)hipGetLastError();
 }
@@ -97,20 +110,13 @@ extern "C" int mt_gemm_f32_bwd_head_launch(const MtGemmGroup* wgroups, const MtT
                                            hipStream_t stream) {
   if (n_wtiles + n_dtiles + hr.n_slots <= 0) return 0;
   if (ksplits < 1 || ksplits > 127) return -5;
-  if (tile_edge != 128 && tile_edge != 64 && tile_edge != 65 && tile_edge != 32) return -7;
+  if (!f32_edge_ok(tile_edge)) return -7;
   dim3 grid(n_wtiles + n_dtiles + hr.n_slots), block(F32_THREADS);
-  if (tile_edge == 32)
-    hipLaunchKernelGGL((mt_gemm_f32_bwd_kernel<2, 32>), grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles,
-                       n_dtiles, step, ksplits, split_stride, mt_step_base_tls, hr);
-  else if (tile_edge == 64)
-    hipLaunchKernelGGL((mt_gemm_f32_bwd_kernel<2, 64>), grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles,
-                       n_dtiles, step, ksplits, split_stride, mt_step_base_tls, hr);
-  else if (tile_edge == 128)
-    hipLaunchKernelGGL((mt_gemm_f32_bwd_kernel<2, 128>), grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles,
-                       n_dtiles, step, ksplits, split_stride, mt_step_base_tls, hr);
-  else
-    hipLaunchKernelGGL((mt_gemm_f32_bwd_kernel<3, 64>), grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles,
-                       n_dtiles, step, ksplits, split_stride, mt_step_base_tls, hr);
+#define MT_F32_BWD(...)                                                                                                 \
+  hipLaunchKernelGGL((mt_gemm_f32_bwd_kernel<__VA_ARGS__>), grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles, \
+                     n_dtiles, step, ksplits, split_stride, mt_step_base_tls, hr)
+  MT_F32_FORMS(MT_F32_BWD)
+#undef MT_F32_BWD
   return (int)hipGetLastError();
 }
 

@@ -108,16 +108,24 @@ __device__ __forceinline__ float f32_colsum_stage(const uint8_t* ldsA, int tid) 
 
 template <int N>
 __device__ __forceinline__ void f32_wait_vm() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else static_assert(N == 0, "unsupported vmcnt");
+  static_assert(N >= 0 && N < 64, "vmcnt is a six-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Wait until at most `ahead` K-tiles (of DMA LDS-DMA instructions each; loads return in order) are still in flight;
+// `ahead` is wave-uniform and at most MAXA.
+template <int DMA, int MAXA>
+__device__ __forceinline__ void f32_wait_ahead(int ahead) {
+  if constexpr (MAXA == 0) {
+    f32_wait_vm<0>();
+  } else {
+    if (ahead >= MAXA) f32_wait_vm<DMA * MAXA>();
+    else f32_wait_ahead<DMA, MAXA - 1>(ahead);
+  }
 }
 
 // One T x T output tile.  ksplits > 1 (wgrad only): tile.ti carries the split index in bits 8..14.
-template <int MODE, int NSTAGE, int T>
+template <int MODE, int NSTAGE, int T, int KU = 1>
 __device__ __forceinline__ void f32_gemm_tile(const MtGemmGroup* __restrict__ groups, const MtTile tile, int step,
                                               int flags, int arow0, int i_override, int ksplits, size_t split_stride,
                                               uint8_t* lds) {
@@ -182,22 +190,36 @@ __device__ __forceinline__ void f32_gemm_tile(const MtGemmGroup* __restrict__ gr
       if (it + 2 < n_it) issue(cur, kt_lo + it + 2);
     }
   } else {
-    // NSTAGE (3) stages, one barrier per K-step: it publishes tile `it` and proves everybody is done with tile
-    // it-1, whose stage is refilled right away with tile it + NSTAGE - 1.
-    static_assert(NSTAGE == 3, "one-barrier form is built for three stages");
+    // NSTAGE (3 or more) stages, one barrier per K-step: it publishes tile `it` and proves everybody is done with tile
+    // it-1, whose stage is refilled right away with tile it + NSTAGE - 1.  Deep forms (6-8 stages of 32-tiles, 4 of
+    // 64-tiles) are for launches of a few tiles per CU: with nothing else resident to hide it, a K-step costs one memory
+    // latency unless its operands were asked for that many steps earlier.
+    // KU > 1: KU K-steps share one barrier (they are waited for, published and computed together), which divides the
+    // barrier and LDS round trips of a short tile by KU.
+    static_assert(NSTAGE >= 3 && NSTAGE >= 2 * KU && DMA_PER_TILE * (NSTAGE - 2 * KU) < 64,
+                  "one-barrier form: three stages or more, room for two groups of K-steps, vmcnt in range");
 #pragma unroll
-    for (int p = 0; p < NSTAGE - 1; ++p)
+    for (int p = 0; p < NSTAGE - KU; ++p)
       if (p < n_it) issue(p, kt_lo + p);
-    for (int it = 0; it < n_it; ++it) {
-      if (n_it - 1 - it >= 1) f32_wait_vm<DMA_PER_TILE>();
-      else f32_wait_vm<0>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of tile it-1 are back
+    for (int it = 0; it < n_it; it += KU) {
+      const int issued = (it + NSTAGE - KU < n_it) ? it + NSTAGE - KU : n_it;
+      const int need = (it + KU < n_it) ? it + KU : n_it;
+      f32_wait_ahead<DMA_PER_TILE, NSTAGE - 2 * KU>(issued - need);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of the previous K-steps are back
       __builtin_amdgcn_s_barrier();
-      const int nxt = it + NSTAGE - 1;
-      if (nxt < n_it) issue(nxt % NSTAGE, kt_lo + nxt);
-      const uint8_t* ldsA = lds + (it % NSTAGE) * STAGE;
-      f32_mma_stage<T, A_KMAJ, B_KMAJ>(acc, ldsA, ldsA + IMG, wr, wc, lane);
-      if (want_db) db_acc += f32_colsum_stage<T>(ldsA, tid);
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int nxt = it + NSTAGE - KU + u;
+        if (nxt < n_it) issue(nxt % NSTAGE, kt_lo + nxt);
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        if (it + u < n_it) {
+          const uint8_t* ldsA = lds + ((it + u) % NSTAGE) * STAGE;
+          f32_mma_stage<T, A_KMAJ, B_KMAJ>(acc, ldsA, ldsA + IMG, wr, wc, lane);
+          if (want_db) db_acc += f32_colsum_stage<T>(ldsA, tid);
+        }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // the bias-gradient reduction reuses stage 0

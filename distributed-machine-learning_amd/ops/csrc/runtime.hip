@@ -84,7 +84,8 @@ struct MtMlpPlan {
   size_t gsplit_stride;
   int32_t ksplits0;       // contraction splits of layer 0's wgrad (its tile list is built with this count)
   int32_t f32;            // 1: exact-f32 pack (f32 activations, GEMMs read P, Pb is null); 0: bf16 MFMA with f32 masters
-  // tile edge of this layer's forward / backward tile lists: 0 = 128; 1 = 256 (bf16 packs only); 2 = 64, 3 = 32 (f32 packs only)
+  // tile edge of this layer's forward / backward tile lists: 0 = 128; 1 = 256 (bf16 packs only); 2 = 64, 3 = 32, 4 = 32 deep,
+  // 5 = 64 deep (f32 packs only)
   int32_t fwd_big[MT_MAX_LAYERS];
   int32_t bwd_big[MT_MAX_LAYERS];
 };
@@ -97,7 +98,17 @@ thread_local const int* mt_step_base_tls = nullptr;
     if (_e != 0) return _e;  \
   } while (0)
 
-static inline int f32_edge(int code) { return code == 2 ? 64 : (code == 3 ? 32 : 128); }
+// plan code -> tile_edge argument of the f32 launchers: 0 = 128-tiles, 2 = 64, 3 = 32 (two stages); 4 = 32-tiles with eight
+// stages, 5 = 64-tiles with four (the latency forms)
+static inline int f32_edge(int code) {
+  switch (code) {
+    case 2: return 64;
+    case 3: return 32;
+    case 4: return 33;
+    case 5: return 66;
+    default: return 128;
+  }
+}
 
 static int plan_gather(const MtMlpPlan* p, int step, hipStream_t stream) {
   return (p->f32 ? mt_gather_f32_launch : mt_gather_launch)(p->gather, p->active_ids, p->n_active, p->max_batch, p->X, p->Y,

@@ -301,7 +301,16 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
-@pytest.mark.parametrize("edge", [128, 64, 32])
+# launch codes of the f32 GEMM: the tile edge itself on the two-stage pipeline; 65 / 66 = 64-tiles with three / four stages,
+# 33 = 32-tiles with eight stages, 35 = the same with four K-steps per barrier (one-barrier pipeline)
+F32_FORMS = [128, 64, 32, 65, 66, 33, 35]
+
+
+def _tile_of(code):
+    return {65: 64, 66: 64, 33: 32, 35: 32}.get(code, code)
+
+
+@pytest.mark.parametrize("edge", F32_FORMS)
 @pytest.mark.parametrize("relu", [False, True])
 def test_gemm_f32_forward_nt(lib, relu, edge):
     if NSTAGE != 2:
@@ -319,7 +328,7 @@ def test_gemm_f32_forward_nt(lib, relu, edge):
         groups[gi] = L.gemm_group(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, m, n, k, ldk, ldk, ldn, 0, 1)
         keep.append((x, w, b, y)); dims.append((gi, m, n))
     groups[len(F32_SHAPES)]["active_steps"] = 0
-    tiles = _tiles_edge(L, dims, edge)
+    tiles = _tiles_edge(L, dims, _tile_of(edge))
     gt, tt = _up(groups), _up(tiles)
     L.check(so.mt_gemm_f32_launch(0, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, int(relu), 0, 0, 1, 0, edge, _stream()),
             "gemm_f32")
@@ -334,7 +343,7 @@ def test_gemm_f32_forward_nt(lib, relu, edge):
         assert torch.all(y[:, rounded:] == 7.0)
 
 
-@pytest.mark.parametrize("edge", [128, 64, 32])
+@pytest.mark.parametrize("edge", F32_FORMS)
 def test_gemm_f32_forward_identity_asymmetric(lib, edge):
     if NSTAGE != 2:
         pytest.skip("the f32 kernels have one pipeline form per tile edge")
@@ -346,14 +355,14 @@ def test_gemm_f32_forward_identity_asymmetric(lib, edge):
     y = torch.zeros(n, n, device="cuda")
     groups = np.zeros(1, dtype=L.GEMM_GROUP_DTYPE)
     groups[0] = L.gemm_group(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, n, n, n, n, n, n, 0, 1)
-    tiles = _tiles_edge(L, [(0, n, n)], edge)
+    tiles = _tiles_edge(L, [(0, n, n)], _tile_of(edge))
     gt, tt = _up(groups), _up(tiles)
     L.check(so.mt_gemm_f32_launch(0, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, 0, 0, 0, 1, 0, edge, _stream()), "gemm_f32")
     torch.cuda.synchronize()
     assert torch.equal(y, w.t())          # exact: every product is x * 1 or x * 0
 
 
-@pytest.mark.parametrize("edge", [128, 64, 32])
+@pytest.mark.parametrize("edge", F32_FORMS)
 @pytest.mark.parametrize("mask", [False, True])
 def test_gemm_f32_dgrad_nn(lib, mask, edge):
     if NSTAGE != 2:
@@ -370,7 +379,7 @@ def test_gemm_f32_dgrad_nn(lib, mask, edge):
         dx = torch.full((m, ldk), 7.0, device="cuda")
         groups[gi] = L.gemm_group(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), h.data_ptr(), 0, m, k, n, ldn, ldk, ldk, ldk, 1)
         keep.append((dy, w, h, dx)); dims.append((gi, m, k))
-    tiles = _tiles_edge(L, dims, edge)
+    tiles = _tiles_edge(L, dims, _tile_of(edge))
     gt, tt = _up(groups), _up(tiles)
     L.check(so.mt_gemm_f32_launch(1, gt.data_ptr(), tt.data_ptr(), len(tiles), 0, int(mask), 0, 0, 1, 0, edge, _stream()),
             "gemm_f32")
@@ -382,7 +391,7 @@ def test_gemm_f32_dgrad_nn(lib, mask, edge):
         torch.testing.assert_close(dx[:, :k].double(), ref, rtol=2e-6, atol=2e-5)
 
 
-@pytest.mark.parametrize("edge", [128, 64, 32])
+@pytest.mark.parametrize("edge", F32_FORMS)
 @pytest.mark.parametrize("ksplits", [1, 3])
 def test_gemm_f32_wgrad_tn(lib, ksplits, edge):
     if NSTAGE != 2:
@@ -401,7 +410,7 @@ def test_gemm_f32_wgrad_tn(lib, ksplits, edge):
         db_all = arena[:, 590 * 600:590 * 600 + n]
         groups[gi] = L.gemm_group(dy.data_ptr(), x.data_ptr(), arena.data_ptr(), 0, db_all.data_ptr(), n, k, m, ldn, ldk, ldk, 0, 1)
         keep.append((dy, x, dw_all, db_all)); dims.append((gi, n, k))
-    tiles = _tiles_edge(L, dims, edge)
+    tiles = _tiles_edge(L, dims, _tile_of(edge))
     if ksplits > 1:
         base = tiles[1:]
         reps = []
