@@ -34,8 +34,9 @@ from ..tune.session import CONTINUE, PAUSE, RESTART, STOP
 from ..tune.trial import Trial
 
 class RankLostError(RuntimeError):
-    """The per-epoch exchange between ranks failed: a peer process is gone or the fabric timed out.  The runner saves
-    the experiment state on the way out; restart every rank with ``resume=True``."""
+    """The per-epoch exchange between ranks failed (a peer process is gone or the fabric timed out) and the group could
+    not be re-formed from the survivors, or the trainable asks for ``on_rank_loss="raise"``.  The runner saves the
+    experiment state on the way out; restart every rank with ``resume=True``."""
 
 
 _REC = 6   # trial_index, epoch, train_loss, validation_loss, validation_mse, validation_mape
@@ -199,12 +200,22 @@ class PackedExecutor(Executor):
             # so that every rank knows every rank's cost per trial and all of them weigh a move the same way
             rows_local.append([-2.0, t2 - t0, float(len(local)), t1 - t0, 0.0, 0.0])
             table = torch.tensor(rows_local, dtype=torch.float64)         # one conversion, not one per slot
+        lost_trials: List[Trial] = []
         try:
             gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
             gathered = gathered.cpu()
         except Exception as e:          # noqa: BLE001 - RCCL / gloo raise backend-specific types
-            raise RankLostError(f"rank {self.rank} of {self.world}: metric exchange after epoch {self.stats['epochs'] + 1} "
-                                f"failed ({type(e).__name__}: {e})") from e
+            what = (f"rank {self.rank} of {self.world}: metric exchange after epoch {self.stats['epochs'] + 1} "
+                    f"failed ({type(e).__name__}: {e})")
+            if self.t.on_rank_loss != "repair":
+                raise RankLostError(what) from e
+            lost_trials = self._repair(what, e)
+            try:        # the round's results of the trials that are still there, over the re-formed group
+                gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
+                gathered = gathered.cpu()
+            except Exception as e2:     # noqa: BLE001
+                raise RankLostError(f"{what}; the exchange over the re-formed group failed too "
+                                    f"({type(e2).__name__}: {e2})") from e2
         t3 = time.time()
         if device_table is not None:                  # the device's own clock split the round into training and validation
             mine_row = gathered[self.rank, -1]
@@ -263,7 +274,48 @@ class PackedExecutor(Executor):
             self._awaiting[tid] = None
             self._n_undecided += 1
             events.append(Event("result", tr, result=result))
+        # trials that sat on a rank that is gone: back to the runner, which queues them for a restart on the survivors
+        events.extend(Event("lost", tr) for tr in lost_trials)
         return events
+
+    # ------------------------------------------------------------------ a rank is gone
+    def _repair(self, what: str, cause: Exception) -> List[Trial]:
+        """Re-form the group from the surviving ranks and re-number everything that names a rank.  Returns the trials the
+        lost ranks held.  Every survivor runs this with the same tables and (from ``shrink``) the same survivor list, so
+        the replicated state stays replicated."""
+        old_world = self.world
+        try:
+            survivors = self.comm.shrink()
+        except Exception as e:          # noqa: BLE001 - no way to re-form the group: the whole job restarts
+            raise RankLostError(f"{what}; the group could not be re-formed ({type(e).__name__}: {e})") from cause
+        lost = sorted(set(range(old_world)) - set(survivors))
+        new_of = {old: new for new, old in enumerate(survivors)}
+        self.rank, self.world = self.comm.rank, self.comm.world_size
+        self._free = [self._free[old] for old in survivors]
+        lost_trials: List[Trial] = []
+        for tid, (r, slot) in sorted(self._place.items()):
+            tr = self._live[tid]
+            if r in new_of:
+                self._place[tid] = (new_of[r], slot)
+                tr.placement = {"rank": new_of[r], "slot": slot}
+            else:
+                del self._place[tid]
+                del self._live[tid]
+                lost_trials.append(tr)
+        lost_trials.sort(key=lambda t: t.index)
+        trials = self.runner.trials if self.runner is not None else list(self._live.values()) + lost_trials
+        for tr in trials:               # in-memory checkpoints are named by the rank that holds them
+            src = getattr(tr, "checkpoint_rank", None)
+            if src is not None:
+                tr.checkpoint_rank = new_of.get(src)
+                if tr.checkpoint_rank is None:
+                    tr.checkpoint = None
+        self.stats["world_size"] = self.world
+        self.stats["ranks_lost"] = self.stats.get("ranks_lost", 0) + len(lost)
+        self.stats["trials_recovered"] = self.stats.get("trials_recovered", 0) + len(lost_trials)
+        if self.runner is not None:
+            self.runner.on_ranks_lost(is_primary=(self.rank == 0))
+        return lost_trials
 
     def _prefetch(self, t_issue: float) -> None:
         """Prepare upcoming trials while the issued epoch runs.  As many as are likely to get a slot when this epoch

@@ -31,6 +31,8 @@ class PackedTrainable:
     on_nonfinite: str = "stop"                           # NaN/inf loss in a slot: "stop" | "error" | "ignore"
     rebalance_gap: int = 2                               # move trials between GPUs once live-trial counts differ by
                                                          # this much (0 = a trial never leaves its first GPU)
+    on_rank_loss: str = "repair"                         # a peer process vanished: "repair" = the survivors re-form the
+                                                         # group and restart its trials; "raise" = stop with RankLostError
     name: str = "packed"
     model_kwargs: Dict[str, Any] = field(default_factory=dict)
 
@@ -42,6 +44,8 @@ class PackedTrainable:
                 raise ValueError("datasets must be X [N, F] (or sequences [N, S, F]) float and y [N] float")
         if self.train[0].shape[1:] != self.val[0].shape[1:]:
             raise ValueError("train/val feature shapes differ")
+        if self.on_rank_loss not in ("repair", "raise"):
+            raise ValueError("on_rank_loss must be 'repair' or 'raise'")
         if self.model == "mlp" and self.train[0].dim() != 2:
             raise ValueError("the MLP family trains on tabular X [N, F]")
 

@@ -15,8 +15,11 @@ process together through shared lists (no sockets) for fast unit tests of replic
 """
 from __future__ import annotations
 
+import json
 import os
+import tempfile
 import threading
+import time
 from typing import Any, List, Optional, Sequence
 
 import torch
@@ -47,6 +50,12 @@ class Comm:
         raise NotImplementedError
 
     def broadcast_object(self, obj: Any, src: int = 0) -> Any:
+        raise NotImplementedError
+
+    def shrink(self) -> List[int]:
+        """After a failed collective: re-form the group from the ranks that are still there.  Every survivor calls it;
+        on return ``rank`` / ``world_size`` are the new ones and the result lists the survivors' OLD ranks in new-rank
+        order.  Backends that cannot do this raise ``NotImplementedError`` (the job then has to restart)."""
         raise NotImplementedError
 
     def close(self) -> None:
@@ -99,11 +108,16 @@ class TorchDistComm(Comm):
 
     def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None,
                  init_method: Optional[str] = None, rank: Optional[int] = None,
-                 world_size: Optional[int] = None, timeout_s: float = 600.0):
+                 world_size: Optional[int] = None, timeout_s: float = 600.0, rendezvous_dir: Optional[str] = None,
+                 settle_s: float = 3.0):
         import datetime
         import torch.distributed as dist
         self.dist = dist
         self._own = False
+        self.timeout_s, self.settle_s, self._generation = float(timeout_s), float(settle_s), 0
+        # where the survivors of a lost rank find each other (shrink): a directory every rank of the node can write
+        self.rendezvous_dir = rendezvous_dir or os.environ.get("MITUNE_RENDEZVOUS_DIR") or os.path.join(
+            tempfile.gettempdir(), f"mitune_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}")
         if not dist.is_initialized():
             rank = int(os.environ.get("RANK", 0)) if rank is None else rank
             world_size = int(os.environ.get("WORLD_SIZE", 1)) if world_size is None else world_size
@@ -133,6 +147,13 @@ class TorchDistComm(Comm):
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
         self.device = device
+        if self.world_size > 1:
+            # a name for this job's rendezvous that every rank knows before anything fails (a directory left by an
+            # earlier job on the same port must not be mistaken for this one's)
+            import uuid
+            box = [uuid.uuid4().hex[:12] if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, device=self.device if self.backend == "nccl" else None)
+            self.rendezvous_dir = os.path.join(self.rendezvous_dir, box[0])
 
     def _dev(self, t: torch.Tensor) -> torch.Tensor:
         return t if t.device == self.device else t.to(self.device)
@@ -187,6 +208,68 @@ class TorchDistComm(Comm):
         if self._own and self.dist.is_initialized():
             self.dist.destroy_process_group()
 
+    def shrink(self) -> List[int]:
+        """Survivors of a failed collective meet through files in ``rendezvous_dir`` (the store of the old group lives in
+        rank 0's process, which may be the one that died): each drops its old group first -- closing its connections is
+        what makes the failure reach ranks that were not talking to the dead one -- then writes ``alive.<old rank>`` into
+        a fresh generation directory.  When every old rank has shown up, or nobody new has for ``settle_s`` seconds, the
+        lowest rank present publishes the member list (created atomically, first writer wins); a rank that arrives after
+        that finds itself left out and raises.  The members then form a new group over a file store in that directory."""
+        import datetime
+        dist, old_rank, old_world = self.dist, self.rank, self.world_size
+        backend = self.backend
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:       # noqa: BLE001 - a group with a dead peer may refuse an orderly shutdown
+            pass
+        self._generation += 1
+        gdir = os.path.join(self.rendezvous_dir, f"gen{self._generation}")
+        os.makedirs(gdir, exist_ok=True)
+        members_path = os.path.join(gdir, "members.json")
+        with open(os.path.join(gdir, f"alive.{old_rank}"), "w") as f:
+            f.write(str(os.getpid()))
+
+        def alive() -> List[int]:
+            return sorted(int(n.split(".", 1)[1]) for n in os.listdir(gdir) if n.startswith("alive."))
+
+        t0 = time.time()
+        seen, last_change = alive(), time.time()
+        while not os.path.exists(members_path):
+            now_alive = alive()
+            if now_alive != seen:
+                seen, last_change = now_alive, time.time()
+            settled = len(seen) == old_world or time.time() - last_change >= self.settle_s
+            if settled and seen and seen[0] == old_rank:
+                tmp = os.path.join(gdir, f"members.tmp.{old_rank}")
+                with open(tmp, "w") as f:
+                    json.dump(seen, f)
+                try:
+                    os.link(tmp, members_path)        # fails if someone else published first: theirs stands
+                except FileExistsError:
+                    pass
+                break
+            if time.time() - t0 > self.timeout_s:
+                raise RuntimeError(f"rank {old_rank}: no member list appeared in {gdir} within {self.timeout_s} s")
+            time.sleep(0.05)
+        while not os.path.exists(members_path):
+            time.sleep(0.01)
+        with open(members_path) as f:
+            members = [int(r) for r in json.load(f)]
+        if old_rank not in members:
+            raise RuntimeError(f"rank {old_rank} reached the rendezvous after the survivors {members} had re-formed the group")
+        new_rank, new_world = members.index(old_rank), len(members)
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = self.device
+            single_node_bootstrap(new_world)
+        store = dist.FileStore(os.path.join(gdir, "store"), new_world)
+        dist.init_process_group(backend=backend, store=store, rank=new_rank, world_size=new_world,
+                                timeout=datetime.timedelta(seconds=self.timeout_s), **kw)
+        self._own = True
+        self.rank, self.world_size = new_rank, new_world
+        return members
+
 
 class _ThreadHub:
     def __init__(self, n: int):
@@ -195,6 +278,16 @@ class _ThreadHub:
         self.slots: List[Any] = [None] * n
         self.mail = {}
         self.cv = threading.Condition()
+        self.dead: set = set()
+        self.lock = threading.Lock()
+        self.successor: Optional["_ThreadHub"] = None
+        self.members: List[int] = []
+
+    def leave(self, rank: int) -> None:
+        """A rank vanishes: whoever waits in a collective, now or later, gets an error."""
+        with self.lock:
+            self.dead.add(rank)
+        self.barrier.abort()
 
 
 class ThreadComm(Comm):
@@ -215,6 +308,18 @@ class ThreadComm(Comm):
         vals = list(self.hub.slots)
         self.hub.barrier.wait()
         return vals
+
+    def shrink(self) -> List[int]:
+        hub = self.hub
+        with hub.lock:
+            if hub.successor is None:
+                hub.members = [r for r in range(hub.n) if r not in hub.dead]
+                hub.successor = _ThreadHub(len(hub.members))
+            members, new = hub.members, hub.successor
+        if self.rank not in members:
+            raise RuntimeError(f"rank {self.rank} is not among the survivors {members}")
+        self.hub, self.rank, self.world_size = new, members.index(self.rank), len(members)
+        return list(members)
 
     def all_gather(self, t):
         return torch.stack([v.clone() for v in self._exchange(t.detach().clone())])

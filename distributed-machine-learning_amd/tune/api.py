@@ -199,17 +199,19 @@ def run(run_or_experiment: Any,
     experiment_id = name or tname
     ex.experiment_id = experiment_id
 
-    logger_objs: List[Logger] = []
-    if rank == 0:       # result.json / progress.csv / tfevents have one writer
-        for lg in (loggers if loggers is not None else (DEFAULT_LOGGERS + (TBXLogger,) if experiment_dir else ())):
-            logger_objs.append(lg() if isinstance(lg, type) else lg)
+    def make_loggers() -> List[Logger]:
+        return [lg() if isinstance(lg, type) else lg
+                for lg in (loggers if loggers is not None else (DEFAULT_LOGGERS + (TBXLogger,) if experiment_dir else ()))]
+
+    # result.json / progress.csv / tfevents have one writer: rank 0 (a rank that becomes rank 0 builds its own then)
+    logger_objs: List[Logger] = make_loggers() if rank == 0 else []
 
     runner = TrialRunner(
         ex, search_alg, scheduler, logger_objs, trainable_name=tname, experiment_dir=experiment_dir,
         metric=metric, mode=mode, stop=stop, max_failures=max_failures,
         keep_checkpoints_num=keep_checkpoints_num, checkpoint_at_end=checkpoint_at_end,
         max_trials=max_trials, progress=ProgressReporter(verbose, progress_period_s, metric, mode),
-        time_budget_s=time_budget_s, fail_fast=fail_fast, is_primary=(rank == 0))
+        time_budget_s=time_budget_s, fail_fast=fail_fast, is_primary=(rank == 0), logger_factory=make_loggers)
     if hasattr(ex, "bind_runner"):
         ex.bind_runner(runner)
 

@@ -36,7 +36,8 @@ class TrialRunner:
                  stop: StopCriterion = None, max_failures: int = 0, keep_checkpoints_num: Optional[int] = None,
                  checkpoint_at_end: bool = False, max_trials: Optional[int] = None,
                  progress: Optional[Any] = None, state_save_period_s: float = 10.0,
-                 time_budget_s: Optional[float] = None, fail_fast: bool = False, is_primary: bool = True):
+                 time_budget_s: Optional[float] = None, fail_fast: bool = False, is_primary: bool = True,
+                 logger_factory: Optional[Callable[[], List[Logger]]] = None):
         self.executor, self.searcher = executor, searcher
         self.scheduler = scheduler or FIFOScheduler()
         self.loggers = list(loggers)
@@ -50,6 +51,7 @@ class TrialRunner:
         self.time_budget_s, self.fail_fast = time_budget_s, fail_fast
         # one process per GPU runs an identical runner; only the primary (rank 0) writes experiment_state.json
         self.is_primary = bool(is_primary)
+        self.logger_factory = logger_factory     # builds the loggers on a rank that BECOMES primary (rank 0 was lost)
         self.trials: List[Trial] = []
         self._by_id: Dict[str, Trial] = {}
         self._pending_q: "collections.deque[Trial]" = collections.deque()    # PENDING trials in arrival order
@@ -176,6 +178,8 @@ class TrialRunner:
                 self._on_done(e)
             elif e.kind == "error":
                 self._on_error(e)
+            elif e.kind == "lost":
+                self._on_lost(e)
         now = time.time()
         if self.experiment_dir and now - self._last_save > self.state_save_period_s:
             self.save_state()
@@ -302,6 +306,36 @@ class TrialRunner:
             self._set_status(trial, PENDING)      # retried from its newest checkpoint
             return
         self._finish(trial, ERROR)
+
+    def _on_lost(self, ev: Event) -> None:
+        """The rank that trained this trial is gone (not the trial's fault: no failure is counted).  It goes back to the
+        queue and restarts on a surviving rank from its newest checkpoint on disk -- the experiment directory is shared by
+        the ranks of a node -- or, without one, from its initial weights: training is deterministic in (seed, trial), so
+        the restarted trial re-reports the iterations it had already reported with the same numbers, and schedulers that
+        record one value per rung ignore the repeats."""
+        trial = ev.trial
+        self._pending_decision.pop(trial.trial_id, None)
+        self.stats["num_lost"] = self.stats.get("num_lost", 0) + 1
+        cp = ckpt.latest_checkpoint(trial.logdir) if trial.logdir else None
+        it = 0
+        if cp:
+            try:
+                it = int(ckpt.load_checkpoint(cp).get("training_iteration", 0))
+            except Exception:       # noqa: BLE001 - a checkpoint cut off by the crash counts as none
+                it = 0
+        trial.checkpoint, trial.checkpoint_iter, trial.checkpoint_rank = None, it, None
+        trial.restore_from, trial.restore_pending = None, True
+        trial.results = [r for r in trial.results if r.get("training_iteration", 0) <= it]
+        trial.last_result = trial.results[-1] if trial.results else {}
+        self._set_status(trial, PENDING)
+
+    def on_ranks_lost(self, is_primary: bool) -> None:
+        """The executor re-formed its group without some ranks.  If the primary was among them, the new rank 0 takes over
+        ``experiment_state.json`` and the loggers (which append to the files the old primary wrote)."""
+        if is_primary and not self.is_primary:
+            self.is_primary = True
+            if self.logger_factory is not None and not self.loggers:
+                self.loggers = list(self.logger_factory())
 
     # ------------------------------------------------------------------ persistence
     def save_state(self) -> None:

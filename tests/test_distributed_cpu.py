@@ -194,7 +194,8 @@ def _rank_loss_worker(rank, world, port, out_dir):
 
     comm = TorchDistComm(backend="gloo", rank=rank, world_size=world, timeout_s=30.0)
     train, val = _data()
-    tr = PackedTrainable(train=train, val=val, max_epochs=6, engine="torch", capacity=3, name="rankloss")
+    tr = PackedTrainable(train=train, val=val, max_epochs=6, engine="torch", capacity=3, name="rankloss",
+                         on_rank_loss="raise")
     ex = PackedExecutor(tr, comm=comm, device=torch.device("cpu"), capacity=3, seed=0, engine=DyingEngine(tr, "cpu", 3, 0))
     try:
         mitune.run(tr, config=SPACE, num_samples=6, executor=ex, seed=0, verbose=0,
@@ -218,6 +219,115 @@ def test_a_vanished_rank_is_reported_and_the_state_is_left_resumable(tmp_path):
     state = json.load(open(tmp_path / "exp" / "rankloss" / "experiment_state.json"))
     done = [t for t in state["trials"] if t.get("training_iteration", t.get("last_result", {}).get("training_iteration", 0))]
     assert len(state["trials"]) >= 6 and done
+
+
+# ----------------------------------------------------------------------------------------- a lost rank is repaired
+class _Vanish(BaseException):
+    pass
+
+
+def _trajectories(an):
+    return {t.trial_id: {r["training_iteration"]: r["validation_loss"] for r in t.results} for t in an.trials}
+
+
+def _repair_search(comm, dies, out_dir=None, checkpoint_freq=0, vanish=None):
+    """12 trials over the ranks of ``comm``; the rank for which ``dies`` is true vanishes inside its third epoch."""
+    from mitune.packed.engine import TorchPackEngine
+
+    class DyingEngine(TorchPackEngine):
+        epochs_done = 0
+
+        def train_epoch(self):
+            if dies and self.epochs_done == 2:
+                vanish()
+            super().train_epoch()
+            self.epochs_done += 1
+
+    train, val = _data()
+    tr = PackedTrainable(train=train, val=val, max_epochs=4, engine="torch", capacity=4, name="repair",
+                         checkpoint_freq=checkpoint_freq)
+    ex = PackedExecutor(tr, comm=comm, device=torch.device("cpu"), capacity=4, seed=0, engine=DyingEngine(tr, "cpu", 4, 0))
+    sched = ASHAScheduler(metric="validation_loss", mode="min", max_t=4, reduction_factor=2)
+    an = mitune.run(tr, config=SPACE, num_samples=12, scheduler=sched, executor=ex, seed=0, verbose=0,
+                    local_dir=out_dir, name="repair" if out_dir else None)
+    return an
+
+
+def test_survivors_of_a_lost_rank_re_form_the_group_and_finish_the_search():
+    """Three in-process ranks; rank 1 vanishes in its third epoch.  The other two shrink the group, restart its trials
+    from their initial weights and finish: both agree on everything, every trial terminates, and wherever a trial
+    reports an iteration that the undisturbed single-rank search also saw, the numbers are bit-identical."""
+    ref = _trajectories(_repair_search(LocalComm(), False))
+    comms = ThreadComm.make(3)
+    out = {}
+
+    def body(r):
+        c = comms[r]
+
+        def vanish():
+            c.hub.leave(c.rank)
+            raise _Vanish()
+        try:
+            an = _repair_search(c, r == 1, vanish=vanish)
+            out[r] = (_trajectories(an), {t.trial_id: t.status for t in an.trials}, dict(an.stats), c.world_size)
+        except _Vanish:
+            pass
+
+    ths = [threading.Thread(target=body, args=(r,)) for r in range(3)]
+    [t.start() for t in ths]
+    [t.join(timeout=300) for t in ths]
+    assert sorted(out) == [0, 2]
+    (tr0, st0, stats0, w0), (tr2, st2, stats2, w2) = out[0], out[2]
+    assert tr0 == tr2 and st0 == st2 and w0 == w2 == 2
+    assert len(st0) == 12 and set(st0.values()) == {"TERMINATED"}
+    assert stats0["ranks_lost"] == 1 and stats0["trials_recovered"] >= 1 and stats0["num_lost"] == stats0["trials_recovered"]
+    common = 0
+    for tid, hist in tr0.items():
+        for it, v in hist.items():
+            if it in ref.get(tid, {}):
+                assert v == ref[tid][it], (tid, it)
+                common += 1
+    assert common >= 12
+    assert any(max(h) == 4 for h in tr0.values())
+
+
+def _gloo_repair_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MITUNE_RENDEZVOUS_DIR=os.path.join(out_dir, "rdzv"))
+    from mitune.parallel.comm import TorchDistComm
+    comm = TorchDistComm(backend="gloo", rank=rank, world_size=world, timeout_s=20.0, settle_s=2.0)
+    an = _repair_search(comm, rank == 0, out_dir=os.path.join(out_dir, "exp"), checkpoint_freq=1,
+                        vanish=lambda: os._exit(0))          # the PRIMARY vanishes, without any goodbye
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump({"traj": _trajectories(an), "status": {t.trial_id: t.status for t in an.trials},
+                   "stats": {k: an.stats.get(k) for k in ("ranks_lost", "trials_recovered", "num_lost", "world_size")},
+                   "new_rank": comm.rank, "world": comm.world_size}, f)
+    comm.close()
+
+
+def test_gloo_processes_survive_the_loss_of_the_primary_rank(tmp_path):
+    """Three gloo processes with per-epoch checkpoints on a shared directory; rank 0 -- the primary, whose process also
+    hosts the group's store -- exits hard in its third epoch.  Ranks 1 and 2 find each other through the rendezvous
+    directory, form a two-rank group, restart rank 0's trials from their newest checkpoints, and the new rank 0 takes over
+    the experiment state file."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gloo_repair_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert not (tmp_path / "rank0.json").exists()
+    a = json.load(open(tmp_path / "rank1.json"))
+    b = json.load(open(tmp_path / "rank2.json"))
+    assert a["traj"] == b["traj"] and a["status"] == b["status"] and a["stats"] == b["stats"]
+    assert (a["new_rank"], b["new_rank"], a["world"]) == (0, 1, 2)
+    assert len(a["status"]) == 12 and set(a["status"].values()) == {"TERMINATED"}
+    assert a["stats"]["ranks_lost"] == 1 and a["stats"]["trials_recovered"] >= 1
+    ref = _trajectories(_repair_search(LocalComm(), False))
+    for tid, hist in a["traj"].items():
+        for it, v in hist.items():
+            if int(it) in ref.get(tid, {}):
+                assert v == ref[tid][int(it)], (tid, it)
+    state = json.load(open(tmp_path / "exp" / "repair" / "experiment_state.json"))
+    assert len(state["trials"]) == 12 and all(t["status"] == "TERMINATED" for t in state["trials"])
 
 
 # ----------------------------------------------------------------------------------------- data-parallel trials
