@@ -149,11 +149,17 @@ class TorchDistComm(Comm):
         self.device = device
         if self.world_size > 1:
             # a name for this job's rendezvous that every rank knows before anything fails (a directory left by an
-            # earlier job on the same port must not be mistaken for this one's)
+            # earlier job on the same port must not be mistaken for this one's); it travels through the group's
+            # key-value store, not through a collective
             import uuid
-            box = [uuid.uuid4().hex[:12] if self.rank == 0 else None]
-            dist.broadcast_object_list(box, src=0, device=self.device if self.backend == "nccl" else None)
-            self.rendezvous_dir = os.path.join(self.rendezvous_dir, box[0])
+            try:
+                store = dist.distributed_c10d._get_default_store()
+                if self.rank == 0:
+                    store.set("mitune/rendezvous_token", uuid.uuid4().hex[:12])
+                token = store.get("mitune/rendezvous_token").decode()
+            except Exception:       # noqa: BLE001 - no store to ask: the port alone names the job
+                token = "job"
+            self.rendezvous_dir = os.path.join(self.rendezvous_dir, token)
 
     def _dev(self, t: torch.Tensor) -> torch.Tensor:
         return t if t.device == self.device else t.to(self.device)
