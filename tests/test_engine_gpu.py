@@ -195,6 +195,75 @@ def test_two_ranks_rebalance_hip_packs_after_uneven_stopping():
     assert res == res0
 
 
+def test_hip_packs_survive_a_vanished_rank():
+    """Two executors with HIP packs (ranks wired through threads); rank 1 vanishes before its third epoch.  Rank 0 shrinks
+    the group to itself, loads the lost trials into its own pack from their initial weights and finishes the search; what
+    any trial reports at an iteration equals what the undisturbed one-rank search reports there, bit for bit."""
+    import threading
+    import mitune
+    from mitune import tune
+    from mitune.packed import PackedExecutor, PackedTrainable
+    from mitune.packed.engine_hip import HipPackEngine
+    from mitune.parallel.comm import LocalComm, ThreadComm
+    from mitune.schedulers import ASHAScheduler
+
+    train, val = _data(n=8000, f=16, seed=6)
+    space = {"width": tune.choice([32, 64, 128]), "num_layers": tune.choice([1, 2]),
+             "learning_rate": tune.loguniform(1e-3, 1e-2), "batch_size": tune.choice([128, 256])}
+
+    class Vanish(BaseException):
+        pass
+
+    def search(comm, dies):
+        class Dying(HipPackEngine):
+            epochs_done = 0
+
+            def train_epoch(self):
+                if dies and self.epochs_done == 2:
+                    comm.hub.leave(comm.rank)
+                    raise Vanish()
+                super().train_epoch()
+                self.epochs_done += 1
+
+        tr = PackedTrainable(train=train, val=val, max_epochs=4, val_chunk=2048, capacity=8, dtype="f32",
+                             model_kwargs={"max_width": 128, "max_layers": 2, "max_batch": 256})
+        dev = torch.device("cuda", 0)
+        ex = PackedExecutor(tr, comm=comm, device=dev, capacity=8, seed=0, engine=Dying(tr, dev, 8, 0))
+        an = mitune.run(tr, config=space, num_samples=8, executor=ex, seed=0, verbose=0,
+                        scheduler=ASHAScheduler(metric="validation_loss", mode="min", max_t=4, reduction_factor=2))
+        return ({t.trial_id: {r["training_iteration"]: (r["validation_loss"], r["train_loss"]) for r in t.results}
+                 for t in an.trials}, {t.trial_id: t.status for t in an.trials}, dict(an.stats))
+
+    ref, _, _ = search(LocalComm(torch.device("cuda", 0)), False)
+    comms = ThreadComm.make(2)
+    out, errs = {}, []
+
+    def body(r):
+        try:
+            out[r] = search(comms[r], r == 1)
+        except Vanish:
+            pass
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=body, args=(r,)) for r in range(2)]
+    [t.start() for t in ths]
+    [t.join(timeout=100) for t in ths]
+    if errs:
+        raise errs[0]
+    assert sorted(out) == [0]
+    traj, status, stats = out[0]
+    assert len(status) == 8 and set(status.values()) == {"TERMINATED"}
+    assert stats["ranks_lost"] == 1 and stats["trials_recovered"] >= 1 and stats["world_size"] == 1
+    same = 0
+    for tid, hist in traj.items():
+        for it, v in hist.items():
+            if it in ref[tid]:
+                assert v == ref[tid][it], (tid, it)
+                same += 1
+    assert same >= 8
+
+
 def test_end_to_end_packed_search_on_gpu(tmp_path):
     import mitune
     from mitune import tune
