@@ -7,6 +7,7 @@ Epochs are separated by the host synchronisation at the end of each epoch (a gap
 mt_* kernel).  Output is a small text table meant to be committed under profiles/.
 """
 import csv
+import os
 import sys
 from collections import defaultdict
 
@@ -21,6 +22,13 @@ def main():
             if "mt_" not in name:
                 continue
             short = name.split("(")[0].replace("void ", "")
+            if os.environ.get("TRACE_BY_GRID"):       # one line per launch shape: the layers of a pack differ in grid size
+                grid = r.get("Grid_Size") or r.get("Grid_Size_X") or "?"
+                wg = r.get("Workgroup_Size") or r.get("Workgroup_Size_X") or "256"
+                try:
+                    short += f" [{int(grid) // max(int(wg), 1)} wg]"
+                except ValueError:
+                    short += f" [{grid}]"
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short))
     rows.sort()
     epochs, cur, last_end = [], [], None
@@ -47,7 +55,7 @@ def main():
             agg[n][0] += 1
             agg[n][1] += e - s
         for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            print(f"    {n:<34} calls {c:>6}  mean {t / c / 1e3:>8.2f} us  total {t / 1e6:>8.1f} ms")
+            print(f"    {n:<46} calls {c:>6}  mean {t / c / 1e3:>8.2f} us  total {t / 1e6:>8.1f} ms")
 
 
 if __name__ == "__main__":
