@@ -20,6 +20,7 @@
 // kind 0: softmax(QK^T * scale); kind 1: relu(QK^T * scale) / (rowsum + eps).
 // keep: optional uint8 [BH][S][S] attention-dropout mask (1 = keep), applied with scale 1/(1-p).
 #include "mt_common.h"
+#include <stdlib.h>
 
 #define AT_THREADS 256
 // Q/K/V/dO images are [rows_pad][64] bf16 (8 chunks of 16 B per row) or, when both head dims are <= 32, [rows_pad][32]
@@ -422,6 +423,184 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const void* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Exact-f32 form for short sequences (S <= 32, heads of at most 64 elements; f32 operands): every product and sum is an
+// f32 fused multiply-add in a fixed order, exp and log are the accurate library functions -- the arithmetic of an eager
+// f32 attention, nothing rounded to bf16.  These problems are tiny (the reference's sample model attends over 10
+// tokens with heads of 8-32 elements: a 10 x 10 score tile), so the vector ALUs do them in less time than the matrix
+// path spends on its 32-row padded images.  Same interface, same saved row statistic, same dropout stream (element
+// index in the [BH, S, S] mask) as the matrix form; one workgroup per (batch, head).
+#define ATX_MAX_S 32
+#define ATX_MAX_D 64
+#define ATX_PD 65          // row pitch (floats) of the Q / K / V / dO images: odd, so a column walk hits every bank once
+#define ATX_PS 33          // row pitch of the S x S images
+#define ATX_FWD_LDS ((3 * ATX_MAX_S * ATX_PD + ATX_MAX_S * ATX_PS) * 4)
+#define ATX_BWD_LDS ((4 * ATX_MAX_S * ATX_PD + 3 * ATX_MAX_S * ATX_PS + ATX_MAX_S) * 4)
+
+__device__ __forceinline__ void atx_stage(float* dst, const float* __restrict__ src, int S, int d, long ld, int tid) {
+  for (int q = tid; q < S * d; q += AT_THREADS) {
+    const int r = q / d, c = q - r * d;
+    dst[r * ATX_PD + c] = src[(size_t)r * ld + c];
+  }
+}
+
+__device__ __forceinline__ float atx_keep(const uint8_t* __restrict__ keep, bool seeded, uint32_t s0, uint32_t s1,
+                                          uint32_t thresh, size_t at, float keep_scale) {
+  if (keep != nullptr) return keep[at] ? keep_scale : 0.f;
+  if (seeded) return mt_rng_hash(s0, s1, (uint32_t)at) >= thresh ? keep_scale : 0.f;
+  return 1.f;
+}
+
+__device__ __forceinline__ void attn_fwd_exact_body(float* lds, const float* __restrict__ Q, const float* __restrict__ K,
+                                                    const float* __restrict__ V, const uint8_t* __restrict__ keep,
+                                                    float* __restrict__ O, float* __restrict__ stat, int S, int dk, int dv,
+                                                    float scale, float keep_scale, int kind, int H, long ldq, long ldv,
+                                                    long ldo, bool seeded, uint32_t s0, uint32_t s1, uint32_t thresh,
+                                                    int bh) {
+  float *q = lds, *k = q + ATX_MAX_S * ATX_PD, *v = k + ATX_MAX_S * ATX_PD, *sc = v + ATX_MAX_S * ATX_PD;
+  const int tid = threadIdx.x;
+  const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
+  atx_stage(q, Q + qoff, S, dk, ldq, tid);
+  atx_stage(k, K + qoff, S, dk, ldq, tid);
+  atx_stage(v, V + voff, S, dv, ldv, tid);
+  __syncthreads();
+  for (int p = tid; p < S * S; p += AT_THREADS) {
+    const int i = p / S, j = p - i * S;
+    float acc = 0.f;
+    for (int d = 0; d < dk; ++d) acc = fmaf(q[i * ATX_PD + d], k[j * ATX_PD + d], acc);
+    sc[i * ATX_PS + j] = acc * scale;
+  }
+  __syncthreads();
+  if (tid < S) {
+    float* row = sc + tid * ATX_PS;
+    float norm;
+    if (kind == 0) {
+      float m = row[0];
+      for (int j = 1; j < S; ++j) m = fmaxf(m, row[j]);
+      float l = 0.f;
+      for (int j = 0; j < S; ++j) { const float e = expf(row[j] - m); row[j] = e; l += e; }
+      norm = 1.f / l;
+      stat[(size_t)bh * S + tid] = m + logf(l);
+    } else {
+      float z = 0.f;
+      for (int j = 0; j < S; ++j) { const float a = fmaxf(row[j], 0.f); row[j] = a; z += a; }
+      z += AT_RELU_EPS;
+      norm = 1.f / z;
+      stat[(size_t)bh * S + tid] = z;
+    }
+    const size_t at = ((size_t)bh * S + tid) * S;
+    for (int j = 0; j < S; ++j) row[j] = row[j] * norm * atx_keep(keep, seeded, s0, s1, thresh, at + j, keep_scale);
+  }
+  __syncthreads();
+  for (int p = tid; p < S * dv; p += AT_THREADS) {
+    const int i = p / dv, n = p - i * dv;
+    float acc = 0.f;
+    for (int j = 0; j < S; ++j) acc = fmaf(sc[i * ATX_PS + j], v[j * ATX_PD + n], acc);
+    O[ooff + (size_t)i * ldo + n] = acc;
+  }
+}
+
+__device__ __forceinline__ void attn_bwd_exact_body(float* lds, const float* __restrict__ Q, const float* __restrict__ K,
+                                                    const float* __restrict__ V, const float* __restrict__ dO,
+                                                    const uint8_t* __restrict__ keep, const float* __restrict__ stat,
+                                                    float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV,
+                                                    int S, int dk, int dv, float scale, float keep_scale, int kind, int H,
+                                                    long ldq, long ldv, long ldo, bool seeded, uint32_t s0, uint32_t s1,
+                                                    uint32_t thresh, int bh) {
+  float *q = lds, *k = q + ATX_MAX_S * ATX_PD, *v = k + ATX_MAX_S * ATX_PD, *go = v + ATX_MAX_S * ATX_PD;
+  float *pr = go + ATX_MAX_S * ATX_PD, *ds = pr + ATX_MAX_S * ATX_PS, *pm = ds + ATX_MAX_S * ATX_PS;
+  float* delta = pm + ATX_MAX_S * ATX_PS;
+  const int tid = threadIdx.x;
+  const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
+  atx_stage(q, Q + qoff, S, dk, ldq, tid);
+  atx_stage(k, K + qoff, S, dk, ldq, tid);
+  atx_stage(v, V + voff, S, dv, ldv, tid);
+  atx_stage(go, dO + ooff, S, dv, ldo, tid);
+  __syncthreads();
+  for (int p = tid; p < S * S; p += AT_THREADS) {       // probabilities again, and the gradient reaching them
+    const int i = p / S, j = p - i * S;
+    float s = 0.f, dp = 0.f;
+    for (int d = 0; d < dk; ++d) s = fmaf(q[i * ATX_PD + d], k[j * ATX_PD + d], s);
+    for (int n = 0; n < dv; ++n) dp = fmaf(go[i * ATX_PD + n], v[j * ATX_PD + n], dp);
+    s *= scale;
+    const float st = stat[(size_t)bh * S + i];
+    const float pv = (kind == 0) ? expf(s - st) : fmaxf(s, 0.f) / st;
+    const float mk = atx_keep(keep, seeded, s0, s1, thresh, ((size_t)bh * S + i) * S + j, keep_scale);
+    pr[i * ATX_PS + j] = pv;
+    ds[i * ATX_PS + j] = dp * mk;            // gradient w.r.t. the un-dropped probability
+    pm[i * ATX_PS + j] = pv * mk;            // the dropped probability feeds dV
+  }
+  __syncthreads();
+  if (tid < S) {
+    float a = 0.f;
+    for (int j = 0; j < S; ++j) a = fmaf(ds[tid * ATX_PS + j], pr[tid * ATX_PS + j], a);
+    delta[tid] = a;
+  }
+  __syncthreads();
+  for (int p = tid; p < S * S; p += AT_THREADS) {
+    const int i = p / S, j = p - i * S;
+    const float pv = pr[i * ATX_PS + j], g = ds[i * ATX_PS + j] - delta[i];
+    float r;
+    if (kind == 0) r = pv * g * scale;
+    else r = (pv > 0.f) ? g * (1.f / stat[(size_t)bh * S + i]) * scale : 0.f;
+    ds[i * ATX_PS + j] = r;
+  }
+  __syncthreads();
+  for (int p = tid; p < S * dk; p += AT_THREADS) {       // dQ = dS . K and dK = dS^T . Q
+    const int i = p / dk, d = p - i * dk;
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < S; ++j) {
+      a = fmaf(ds[i * ATX_PS + j], k[j * ATX_PD + d], a);
+      b = fmaf(ds[j * ATX_PS + i], q[j * ATX_PD + d], b);
+    }
+    dQ[qoff + (size_t)i * ldq + d] = a;
+    dK[qoff + (size_t)i * ldq + d] = b;
+  }
+  for (int p = tid; p < S * dv; p += AT_THREADS) {       // dV = (dropped P)^T . dO
+    const int j = p / dv, n = p - j * dv;
+    float a = 0.f;
+    for (int i = 0; i < S; ++i) a = fmaf(pm[i * ATX_PS + j], go[i * ATX_PD + n], a);
+    dV[voff + (size_t)j * ldv + n] = a;
+  }
+}
+
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_exact_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                                       const float* __restrict__ V,
+                                                                       const uint8_t* __restrict__ keep,
+                                                                       float* __restrict__ O, float* __restrict__ stat, int S,
+                                                                       int dk, int dv, float scale, float keep_scale,
+                                                                       int kind, int H, long ldq, long ldv, long ldo,
+                                                                       const int64_t* __restrict__ seed, uint32_t thresh) {
+  __shared__ __attribute__((aligned(16))) float lds[ATX_FWD_LDS / 4];
+  uint32_t s0 = 0u, s1 = 0u;
+  if (seed != nullptr) { const uint64_t sv = (uint64_t)seed[0]; s0 = (uint32_t)sv; s1 = (uint32_t)(sv >> 32); }
+  attn_fwd_exact_body(lds, Q, K, V, keep, O, stat, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo, seed != nullptr, s0,
+                      s1, thresh, blockIdx.x);
+}
+
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_exact_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                                       const float* __restrict__ V,
+                                                                       const float* __restrict__ dO,
+                                                                       const uint8_t* __restrict__ keep,
+                                                                       const float* __restrict__ stat, float* __restrict__ dQ,
+                                                                       float* __restrict__ dK, float* __restrict__ dV, int S,
+                                                                       int dk, int dv, float scale, float keep_scale,
+                                                                       int kind, int H, long ldq, long ldv, long ldo,
+                                                                       const int64_t* __restrict__ seed, uint32_t thresh) {
+  __shared__ __attribute__((aligned(16))) float lds[ATX_BWD_LDS / 4];
+  uint32_t s0 = 0u, s1 = 0u;
+  if (seed != nullptr) { const uint64_t sv = (uint64_t)seed[0]; s0 = (uint32_t)sv; s1 = (uint32_t)(sv >> 32); }
+  attn_bwd_exact_body(lds, Q, K, V, dO, keep, stat, dQ, dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo,
+                      seed != nullptr, s0, s1, thresh, blockIdx.x);
+}
+
+// MITUNE_ATTN_EXACT=0 sends f32 operands of short sequences through the matrix form too (operands rounded to bf16).
+static bool at_exact_on() {
+  static const bool on = [] { const char* e = getenv("MITUNE_ATTN_EXACT"); return !(e && e[0] == '0'); }();
+  return on;
+}
+static bool at_exact_fits(int S, int dk, int dv) { return S <= ATX_MAX_S && dk <= ATX_MAX_D && dv <= ATX_MAX_D; }
+
+// ---------------------------------------------------------------------------------------------------------------
 // Grouped form for packs of sequence-model trials: one launch covers the attention of one encoder layer of EVERY
 // resident trial.  Workgroup (x, y) is (batch, head) problem x of trial slot ids[y]; each slot brings its own head
 // count, head width, dropout rate and seed.  Operands are the slot's fused projection output [B*S][3d] = q | k | v
@@ -477,6 +656,42 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_kernel(const M
                                  (long)d, seeded, s0, s1, a.thresh, blockIdx.x);
 }
 
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_grouped_exact_kernel(const MtAttnSlot* __restrict__ slots,
+                                                                               const int32_t* __restrict__ ids, int S,
+                                                                               int step_imm, int b_override, int train,
+                                                                               const int* __restrict__ step_base) {
+  __shared__ __attribute__((aligned(16))) float lds[ATX_FWD_LDS / 4];
+  const int step = mt_step(step_imm, step_base);
+  const MtAttnSlot a = slots[ids[blockIdx.y]];
+  if (step >= a.active_steps) return;
+  const int B = b_override > 0 ? b_override : a.B;
+  if ((int)blockIdx.x >= B * a.H) return;
+  const int d = a.H * a.dk;
+  const bool seeded = train && a.thresh != 0u && a.seed != nullptr;
+  uint32_t s0 = 0u, s1 = 0u;
+  if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
+  attn_fwd_exact_body(lds, a.qkv, a.qkv + d, a.qkv + 2 * d, nullptr, a.o, a.stat, S, a.dk, a.dk, a.scale,
+                      seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1, a.thresh, blockIdx.x);
+}
+
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_exact_kernel(const MtAttnSlot* __restrict__ slots,
+                                                                               const int32_t* __restrict__ ids, int S,
+                                                                               int step_imm,
+                                                                               const int* __restrict__ step_base) {
+  __shared__ __attribute__((aligned(16))) float lds[ATX_BWD_LDS / 4];
+  const int step = mt_step(step_imm, step_base);
+  const MtAttnSlot a = slots[ids[blockIdx.y]];
+  if (step >= a.active_steps) return;
+  if ((int)blockIdx.x >= a.B * a.H) return;
+  const int d = a.H * a.dk;
+  const bool seeded = a.thresh != 0u && a.seed != nullptr;
+  uint32_t s0 = 0u, s1 = 0u;
+  if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
+  attn_bwd_exact_body(lds, a.qkv, a.qkv + d, a.qkv + 2 * d, a.d_o, nullptr, a.stat, a.dqkv, a.dqkv + d, a.dqkv + 2 * d, S,
+                      a.dk, a.dk, a.scale, seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1,
+                      a.thresh, blockIdx.x);
+}
+
 extern "C" int mt_attn_slot_sizeof() { return (int)sizeof(MtAttnSlot); }
 
 static int nkb_for(int S) { return ((S + 31) / 32) * 2; }   // pad the sequence to a multiple of 32
@@ -502,6 +717,12 @@ extern "C" int mt_attn_fwd_strided_launch(const void* Q, const void* K, const vo
   const uint32_t thresh = (seed != nullptr && p > 0.f) ? (uint32_t)((double)p * 4294967296.0) : 0u;
   if (thresh == 0u) seed = nullptr;
   dim3 grid(BH), block(AT_THREADS);
+  if (f32 && at_exact_on() && at_exact_fits(S, dk, dv)) {
+    hipLaunchKernelGGL(mt_attn_fwd_exact_kernel, grid, block, 0, stream, (const float*)Q, (const float*)K, (const float*)V,
+                       (const uint8_t*)keep, (float*)O, stat, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo, seed,
+                       thresh);
+    return (int)hipGetLastError();
+  }
   const bool narrow = dk <= 32 && dv <= 32;
 #define AT_FWD2(N, P, F)                                                                                        \
   hipLaunchKernelGGL((mt_attn_fwd_kernel<N, P, F>), grid, block, 0, stream, Q, K, V, (const uint8_t*)keep, O, stat, S, dk, \
@@ -532,6 +753,12 @@ extern "C" int mt_attn_bwd_strided_launch(const void* Q, const void* K, const vo
   const uint32_t thresh = (seed != nullptr && p > 0.f) ? (uint32_t)((double)p * 4294967296.0) : 0u;
   if (thresh == 0u) seed = nullptr;
   dim3 grid(BH), block(AT_THREADS);
+  if (f32 && at_exact_on() && at_exact_fits(S, dk, dv)) {
+    hipLaunchKernelGGL(mt_attn_bwd_exact_kernel, grid, block, 0, stream, (const float*)Q, (const float*)K, (const float*)V,
+                       (const float*)dO, (const uint8_t*)keep, stat, dQ, dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq,
+                       ldv, ldo, seed, thresh);
+    return (int)hipGetLastError();
+  }
   const bool narrow = dk <= 32 && dv <= 32;
 #define AT_BWD2(N, P, F)                                                                                        \
   hipLaunchKernelGGL((mt_attn_bwd_kernel<N, P, F>), grid, block, 0, stream, Q, K, V, dO, (const uint8_t*)keep, stat, dQ, \
@@ -573,6 +800,11 @@ extern "C" int mt_attn_fwd_grouped_launch(const MtAttnSlot* slots, const int32_t
   if (n_active <= 0 || max_bh <= 0) return 0;
   if (S < 1 || S > 128) return -2;
   dim3 grid(max_bh, n_active), block(AT_THREADS);
+  if (at_exact_on() && S <= ATX_MAX_S) {      // the slots' operands are f32 and their heads at most 64 wide
+    hipLaunchKernelGGL(mt_attn_fwd_grouped_exact_kernel, grid, block, 0, stream, slots, ids, S, step, b_override, train,
+                       mt_step_base_tls);
+    return (int)hipGetLastError();
+  }
 #define AT_GF(N, P) hipLaunchKernelGGL((mt_attn_fwd_grouped_kernel<N, P>), grid, block, 0, stream, slots, ids, S, step, \
                                        b_override, train, mt_step_base_tls)
 #define AT_GFW(N) do { if (wide) AT_GF(N, 8); else AT_GF(N, 4); } while (0)
@@ -593,6 +825,10 @@ extern "C" int mt_attn_bwd_grouped_launch(const MtAttnSlot* slots, const int32_t
   if (n_active <= 0 || max_bh <= 0) return 0;
   if (S < 1 || S > 128) return -2;
   dim3 grid(max_bh, n_active), block(AT_THREADS);
+  if (at_exact_on() && S <= ATX_MAX_S) {
+    hipLaunchKernelGGL(mt_attn_bwd_grouped_exact_kernel, grid, block, 0, stream, slots, ids, S, step, mt_step_base_tls);
+    return (int)hipGetLastError();
+  }
 #define AT_GB(N, P) hipLaunchKernelGGL((mt_attn_bwd_grouped_kernel<N, P>), grid, block, 0, stream, slots, ids, S, step, \
                                        mt_step_base_tls)
 #define AT_GBW(N) do { if (wide) AT_GB(N, 8); else AT_GB(N, 4); } while (0)

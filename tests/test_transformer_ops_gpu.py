@@ -128,6 +128,30 @@ def test_strided_self_attention_on_projection_outputs(B, S, h, dk, dv, drop, kin
         assert torch.allclose(a, r, rtol=tol, atol=tol * max(1.0, r.abs().max().item())), name
 
 
+@pytest.mark.parametrize("kind", ["softmax", "relu"])
+@pytest.mark.parametrize("B,S,h,dk,dv,drop", [(6, 10, 4, 8, 8, 0.0), (4, 10, 2, 32, 32, 0.1), (3, 17, 3, 5, 20, 0.2),
+                                              (2, 32, 2, 64, 64, 0.0), (5, 1, 2, 16, 16, 0.0), (2, 31, 8, 24, 12, 0.3)])
+def test_short_sequence_f32_attention_is_exact_f32(B, S, h, dk, dv, drop, kind):
+    """f32 operands, at most 32 tokens, heads of at most 64 elements: nothing is rounded to bf16.  Against a float64
+    reference on the SAME (unrounded) operands the error is f32 summation error only."""
+    from mitune.ops.attention import attention_reference
+    from mitune.ops.attention_hip import FusedSelfAttention
+    g = torch.Generator(device="cuda").manual_seed(21)
+    qk = torch.randn(B, S, 2 * h * dk, device="cuda", generator=g).requires_grad_()
+    v = torch.randn(B, S, h * dv, device="cuda", generator=g).requires_grad_()
+    keep = (torch.rand(B, h, S, S, device="cuda", generator=g) >= drop).to(torch.uint8) if drop > 0 else None
+    do = torch.randn(B, S, h * dv, device="cuda", generator=g)
+    out = FusedSelfAttention.apply(qk, v, h, kind, keep, drop)
+    out.backward(do)
+    qr, vr = qk.detach().double().requires_grad_(), v.detach().double().requires_grad_()
+    q, k = qr.chunk(2, dim=-1)
+    sp = lambda t, d: t.reshape(B, S, h, d).transpose(1, 2)          # noqa: E731
+    ref = attention_reference(sp(q, dk), sp(k, dk), sp(vr, dv), kind, keep, drop).transpose(1, 2).reshape(B, S, h * dv)
+    ref.backward(do.double())
+    for a, r, name in ((out.detach(), ref.detach(), "out"), (qk.grad, qr.grad, "dqk"), (v.grad, vr.grad, "dv")):
+        torch.testing.assert_close(a.double(), r, rtol=2e-5, atol=2e-5 * max(1.0, float(r.abs().max())), msg=lambda m, n=name: f"{n}: {m}")
+
+
 @pytest.mark.parametrize("B,S,h,dk,dv,dtype", [(3, 50, 4, 16, 16, torch.float32), (2, 65, 8, 24, 24, torch.bfloat16),
                                                 (2, 20, 2, 8, 16, torch.float32), (1, 128, 4, 32, 64, torch.bfloat16),
                                                 (2, 96, 16, 3, 12, torch.float32), (2, 96, 32, 5, 10, torch.bfloat16),
