@@ -146,9 +146,10 @@ def main():
                 t2 = [prob.time(fn, args.iters, 1, 2) for _ in range(3)]
                 t4 = [prob.time(fn, args.iters, 1, 4) for _ in range(3)]
                 tb = [big.time(fn, args.iters, 1, 256) for _ in range(3)]
-                us = min(min(t2), min(t4), min(tb))
+                t8 = [big.time(fn, args.iters, 1, 258) for _ in range(3)]      # 256-tiles on eight waves, pipelined reads
+                us = min(min(t2), min(t4), min(tb), min(t8))
                 print(f"slots {T:4d}  {names[mode]}  ksplits {ks}  tiles {prob.ntiles:5d}  2-stage {min(t2):8.2f} us  "
-                      f"4-stage {min(t4):8.2f} us  256-tile {min(tb):8.2f} us  best {prob.flop / us / 1e6:8.1f} TFLOP/s",
+                      f"4-stage {min(t4):8.2f} us  256-tile {min(tb):8.2f} us  256-tile 8-wave {min(t8):8.2f} us  best {prob.flop / us / 1e6:8.1f} TFLOP/s",
                       flush=True)
                 if args.ablate and ks == 1:
                     for label, fl in (("no-mfma", 1 | 256), ("no-steady-loads", 1 | 512), ("no-epilogue", 1 | 1024),

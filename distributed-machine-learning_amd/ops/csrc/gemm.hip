@@ -862,6 +862,49 @@ __global__ __launch_bounds__(P8_THREADS) void mt_gemm_p8_kernel(MtGemmGroup g, i
   gemm_tile_p8<MODE, SCHED>(g, first + r % rows, r / rows, sp, flags, ksplits, split_stride, lds);
 }
 
+// The same tile for PACKS (tile lists of 256-tiles, one workgroup of eight waves per entry): a pack's layers of 512 columns
+// and more are eight or more K-tiles long, enough for the pipelined loop to pay (nstage 258 of the grouped launchers).
+template <int MODE, int SCHED>
+__device__ __forceinline__ void gemm_tile_p8_grouped(const MtGemmGroup* __restrict__ groups, const MtTile tile, int step,
+                                                     int flags, int arow0, int i_override, int ksplits, size_t split_stride,
+                                                     uint8_t* lds) {
+  if (tile.group < 0) return;
+  MtGemmGroup g = groups[tile.group];
+  if (step >= g.active_steps) return;
+  if (i_override > 0) {
+    g.I = i_override;
+    g.A = reinterpret_cast<const uint16_t*>(g.A) + (size_t)arow0 * g.lda;
+  }
+  const int split = (MODE == 2) ? (tile.ti >> 8) : 0;
+  const int ti = (MODE == 2) ? (tile.ti & 0xFF) : (int)tile.ti;
+  gemm_tile_p8<MODE, SCHED>(g, ti, tile.tj, split, flags, ksplits, split_stride, lds);
+}
+
+template <int MODE, int SCHED>
+__global__ __launch_bounds__(P8_THREADS) void mt_gemm_p8_grouped_kernel(const MtGemmGroup* __restrict__ groups,
+                                                                        const MtTile* __restrict__ tiles, int step, int flags,
+                                                                        int arow0, int i_override, int ksplits,
+                                                                        size_t split_stride,
+                                                                        const int* __restrict__ step_base) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BIG_STAGE_BYTES];
+  gemm_tile_p8_grouped<MODE, SCHED>(groups, tiles[blockIdx.x], mt_step(step, step_base), flags, arow0, i_override, ksplits,
+                                    split_stride, lds);
+}
+
+__global__ __launch_bounds__(P8_THREADS) void mt_gemm_p8_grouped_bwd_kernel(const MtGemmGroup* __restrict__ wgroups,
+                                                                            const MtTile* __restrict__ wtiles, int n_wtiles,
+                                                                            const MtGemmGroup* __restrict__ dgroups,
+                                                                            const MtTile* __restrict__ dtiles, int step_imm,
+                                                                            int ksplits, size_t split_stride,
+                                                                            const int* __restrict__ step_base) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BIG_STAGE_BYTES];
+  const int step = mt_step(step_imm, step_base);
+  if ((int)blockIdx.x < n_wtiles)
+    gemm_tile_p8_grouped<2, 0>(wgroups, wtiles[blockIdx.x], step, MT_GEMM_FLAG_DBIAS, 0, 0, ksplits, split_stride, lds);
+  else
+    gemm_tile_p8_grouped<1, 0>(dgroups, dtiles[blockIdx.x - n_wtiles], step, MT_GEMM_FLAG_MASK, 0, 0, 1, 0, lds);
+}
+
 // Large single GEMMs take the eight-wave 256-tile form once they have this many 256-tiles (0: never).
 static int p8_limit = -1;
 static int p8_min_tiles() {
@@ -931,7 +974,8 @@ __global__ __launch_bounds__(NTHREADS) void mt_gemm_bwd_kernel(const MtGemmGroup
 }
 
 // nstage: 2 = throughput form (two workgroups per CU), 4 = latency form (one workgroup per CU, three
-// tiles in flight); 0 lets the launcher choose from the tile count.  256 = the tile list holds 256x256 tiles.
+// tiles in flight); 0 lets the launcher choose from the tile count.  256 / 258 = the tile list holds 256x256 tiles (four
+// waves and the simple two-barrier loop / eight waves with pipelined fragment reads).
 static int pick_nstage(int nstage, int ntiles) {
   if (nstage == 2 || nstage == 4) return nstage;
   return ntiles <= 320 ? 4 : 2;
@@ -943,6 +987,19 @@ extern "C" int mt_gemm_launch(int mode, const MtGemmGroup* groups, const MtTile*
   if (ntiles <= 0) return 0;
   if (ksplits < 1 || ksplits > 127 || (mode != 2 && ksplits != 1)) return -5;
   dim3 grid(ntiles), block(NTHREADS);
+  if (nstage == 258) {      // 256-tiles on eight waves (one barrier per K-tile when both operands are K-major, else two)
+    dim3 block8(P8_THREADS);
+    switch (mode) {
+      case 0: hipLaunchKernelGGL((mt_gemm_p8_grouped_kernel<0, 1>), grid, block8, 0, stream, groups, tiles, step, flags, arow0,
+                                 i_override, 1, (size_t)0, mt_step_base_tls); break;
+      case 1: hipLaunchKernelGGL((mt_gemm_p8_grouped_kernel<1, 0>), grid, block8, 0, stream, groups, tiles, step, flags, arow0,
+                                 i_override, 1, (size_t)0, mt_step_base_tls); break;
+      case 2: hipLaunchKernelGGL((mt_gemm_p8_grouped_kernel<2, 0>), grid, block8, 0, stream, groups, tiles, step, flags, arow0,
+                                 i_override, ksplits, split_stride, mt_step_base_tls); break;
+      default: return -1;
+    }
+    return (int)hipGetLastError();
+  }
   if (nstage == 256) {
 #define MT_GEMM_BIG(M, KS, SS) \
   hipLaunchKernelGGL((mt_gemm256_kernel<M>), grid, block, 0, stream, groups, tiles, step, flags, arow0, i_override, KS, SS, \
@@ -977,8 +1034,13 @@ extern "C" int mt_gemm_bwd_head_launch(const MtGemmGroup* wgroups, const MtTile*
                                        hipStream_t stream) {
   if (n_wtiles + n_dtiles + hr.n_slots <= 0) return 0;
   if (ksplits < 1 || ksplits > 127) return -5;
-  if (nstage == 256 && hr.n_slots > 0) return -6;
+  if ((nstage == 256 || nstage == 258) && hr.n_slots > 0) return -6;
   dim3 grid(n_wtiles + n_dtiles + hr.n_slots), block(NTHREADS);
+  if (nstage == 258) {
+    hipLaunchKernelGGL(mt_gemm_p8_grouped_bwd_kernel, grid, dim3(P8_THREADS), 0, stream, wgroups, wtiles, n_wtiles, dgroups,
+                       dtiles, step, ksplits, split_stride, mt_step_base_tls);
+    return (int)hipGetLastError();
+  }
   if (nstage == 256) {
     hipLaunchKernelGGL(mt_gemm256_bwd_kernel, grid, block, 0, stream, wgroups, wtiles, n_wtiles, dgroups, dtiles, step,
                        ksplits, split_stride, mt_step_base_tls);

@@ -9,6 +9,7 @@
 //   dgrad(+ReLU mask) of layer l in ONE launch } -> [grad sq-norm partials] -> fused per-trial optimiser
 //   (+bf16 shadow refresh), i.e. 2L + 4 (+1) launches regardless of how many trials share the GPU.
 #include "mt_bodies.h"
+#include <stdlib.h>
 
 #define MT_MAX_LAYERS 8
 
@@ -110,6 +111,12 @@ static inline int f32_edge(int code) {
   }
 }
 
+// 256-tile launches of bf16 packs: the eight-wave pipelined form (258), or with MITUNE_BIG_FORM=256 the four-wave one
+static int big_form() {
+  static const int form = [] { const char* e = getenv("MITUNE_BIG_FORM"); return (e && atoi(e) == 256) ? 256 : 258; }();
+  return form;
+}
+
 static int plan_gather(const MtMlpPlan* p, int step, hipStream_t stream) {
   return (p->f32 ? mt_gather_f32_launch : mt_gather_launch)(p->gather, p->active_ids, p->n_active, p->max_batch, p->X, p->Y,
                                                             p->n_rows, p->F, p->Fpad, p->hb, step, stream);
@@ -120,7 +127,7 @@ static int plan_forward(const MtMlpPlan* p, int l, int step, int arow0, int rows
     return mt_gemm_f32_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], step, MT_GEMM_FLAG_RELU, arow0, rows,
                               1, 0, f32_edge(p->fwd_big[l]), stream);
   return mt_gemm_launch(0, p->fwd_groups[l], p->fwd_tiles[l], p->fwd_ntiles[l], step, MT_GEMM_FLAG_RELU, arow0, rows, 1, 0,
-                        p->fwd_big[l] ? 256 : 0, stream);
+                        p->fwd_big[l] ? big_form() : 0, stream);
 }
 
 static int mlp_enqueue_steps(const MtMlpPlan* p, int step0, int nsteps, hipStream_t stream, bool first_gather) {
@@ -156,7 +163,7 @@ static int mlp_enqueue_steps(const MtMlpPlan* p, int step0, int nsteps, hipStrea
                                            rider, stream));
       else
         MT_TRY(mt_gemm_bwd_head_launch(p->wgrad_groups[l], p->wgrad_tiles[l], p->wgrad_ntiles[l], p->dgrad_groups[l],
-                                       p->dgrad_tiles[l], nd, step, ks, p->gsplit_stride, p->bwd_big[l] ? 256 : 0, rider,
+                                       p->dgrad_tiles[l], nd, step, ks, p->gsplit_stride, p->bwd_big[l] ? big_form() : 0, rider,
                                        stream));
     }
     MT_TRY(mt_optim_gather_launch(p->P, p->G, p->M, p->V, p->Pb, p->slot_stride, p->opt, p->active_ids, p->n_active,

@@ -39,10 +39,14 @@ N_XCD = 8
 MAX_KSPLITS = 4        # weight-gradient slabs kept per slot (split-K over the batch for small packs)
 MAX_STREAMS = 4        # concurrent step chains, one HIP stream each
 BIG_TILE = 256         # tile edge of the throughput-form GEMM kernels
-# 256-tiles are OFF by default (threshold 0 disables them): with the simple two-barrier K-loop they measured slower than
-# the 128-tile forms at every pack size (256 slots x 512^3: fwd 166 vs 122 us, dgrad 309 vs 135, wgrad 242 vs 160);
-# MITUNE_BIG_MIN_TILES=<n> turns them on for launches with at least n such tiles.
-BIG_MIN_TILES = int(os.environ.get("MITUNE_BIG_MIN_TILES", "0"))
+# 256-tiles (bf16 packs): a launch takes them when it has at least BIG_MIN_TILES of them AND they do not pad much more
+# than 128-tiles would: a 256-tile costs BIG_COST 128-tiles (four of them at the eight-wave kernel's better rate), so a
+# pack of 512-wide layers qualifies (4 x 3.5 = 14 against 16) and one with many layers of 64-128 columns does not (a
+# 256-tile over a 64-column layer is three quarters padding).  Eight-wave kernel on 256 slots x 512^3: forward 110 us
+# against 124 on 128-tiles, input gradient 129 / 136, weight gradient 135 / 161 (the earlier four-wave 256-tile form:
+# 167 / 309 / 242, which is why this stayed off until the eight-wave form existed).  0 disables.
+BIG_MIN_TILES = int(os.environ.get("MITUNE_BIG_MIN_TILES", "256"))
+BIG_COST = float(os.environ.get("MITUNE_BIG_COST", "3.5"))
 KSPLITS_SMALL = int(os.environ.get("MITUNE_KSPLITS_SMALL", str(MAX_KSPLITS)))     # wgrad splits of packs with <= 128 tiles
 GRAPH_STEPS = 25       # steps per captured hipGraph block (3125 = 125 blocks; shorter epochs run the rest directly)
 # Exact-f32 packs: launches with fewer 128-tiles than this use 64x64 tiles instead.  The f32 matrix instruction is 16x
@@ -584,9 +588,11 @@ class HipPackEngine(PackEngine):
                 out[f"big_fwd{l}"], out[f"big_bwd{l}"] = code[edge_f], code[edge_b]
             else:
                 # 256-tiles halve the bytes staged per flop; they pay once a launch still has enough of them to fill the chip
-                big_f = BIG_MIN_TILES > 0 and count(fl, BIG_TILE) >= BIG_MIN_TILES
-                big_b = (BIG_MIN_TILES > 0 and (not eval_mode) and ksplits0 == 1
-                         and count(dl, BIG_TILE) + count(wl, BIG_TILE) >= BIG_MIN_TILES)
+                big_f = (BIG_MIN_TILES > 0 and count(fl, BIG_TILE) >= BIG_MIN_TILES
+                         and count(fl, BIG_TILE) * BIG_COST <= count(fl, TILE))
+                nb_big, nb_128 = count(dl, BIG_TILE) + count(wl, BIG_TILE), count(dl, TILE) + count(wl, TILE)
+                big_b = (BIG_MIN_TILES > 0 and (not eval_mode) and ksplits0 == 1 and ksplits == 1
+                         and nb_big >= BIG_MIN_TILES and nb_big * BIG_COST <= nb_128)
                 out[f"big_fwd{l}"], out[f"big_bwd{l}"] = int(big_f), int(big_b)
                 edge_f, edge_b = (BIG_TILE if big_f else TILE), (BIG_TILE if big_b else TILE)
             ft = balanced_tiles(tiled(fl, edge_f))

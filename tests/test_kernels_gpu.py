@@ -30,7 +30,7 @@ def _up(arr: np.ndarray) -> torch.Tensor:
 def _tiles(L, dims):
     """dims: list of (group, I, J) -> plain (unbalanced) tile list incl. one padding entry."""
     rows = [(-1, 0, 0)]
-    edge = 256 if NSTAGE == 256 else 128
+    edge = 256 if NSTAGE in (256, 258) else 128        # 258: 256-tiles on eight waves
     for g, i, j in dims:
         for ti in range((i + edge - 1) // edge):
             for tj in range((j + edge - 1) // edge):
@@ -45,7 +45,7 @@ def _rand_bf16(*shape, scale=1.0, gen=None):
 NSTAGE = 0          # 0: launcher picks the pipeline depth; the parametrised test below forces both forms
 
 
-@pytest.fixture(params=[2, 4, 256], autouse=True)
+@pytest.fixture(params=[2, 4, 256, 258], autouse=True)
 def _both_pipeline_depths(request, monkeypatch):
     monkeypatch.setattr(sys.modules[__name__], "NSTAGE", request.param)
 
