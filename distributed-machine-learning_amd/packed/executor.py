@@ -106,6 +106,7 @@ class PackedExecutor(Executor):
         self._n_undecided = 0
         self._hostname = socket.gethostname()
         self._diverged: set = set()
+        self._lost_pending: List[Trial] = []      # trials of ranks lost while moving trials: reported with the next round
         self._t_total: Dict[str, float] = {}
         self.runner = None
         self.stats: Dict[str, Any] = {"epochs": 0, "slot_epochs": 0, "train_s": 0.0, "eval_s": 0.0,
@@ -200,7 +201,7 @@ class PackedExecutor(Executor):
             # so that every rank knows every rank's cost per trial and all of them weigh a move the same way
             rows_local.append([-2.0, t2 - t0, float(len(local)), t1 - t0, 0.0, 0.0])
             table = torch.tensor(rows_local, dtype=torch.float64)         # one conversion, not one per slot
-        lost_trials: List[Trial] = []
+        lost_trials, self._lost_pending = self._lost_pending, []
         try:
             gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
             gathered = gathered.cpu()
@@ -209,7 +210,7 @@ class PackedExecutor(Executor):
                     f"failed ({type(e).__name__}: {e})")
             if self.t.on_rank_loss != "repair":
                 raise RankLostError(what) from e
-            lost_trials = self._repair(what, e)
+            lost_trials = lost_trials + self._repair(what, e)
             try:        # the round's results of the trials that are still there, over the re-formed group
                 gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
                 gathered = gathered.cpu()
@@ -450,14 +451,17 @@ class PackedExecutor(Executor):
             if load[hi] - load[lo] < gap or not self._free[lo]:
                 break
             tid = max((t for t, (r, _) in self._place.items() if r == hi), key=lambda t: self._live[t].index)
-            self._move(self._live[tid], lo)
+            if not self._move(self._live[tid], lo):
+                continue        # a rank vanished during the move and the group was re-formed: plan again for the survivors
             moved = True
         if moved:
             self.stats["migrate_s"] += time.time() - t0
 
-    def _move(self, tr: Trial, dst: int) -> None:
+    def _move(self, tr: Trial, dst: int) -> bool:
+        """Move one trial to rank ``dst``; False if a rank was lost on the way (the group has been re-formed and every
+        placement re-numbered: the caller plans again)."""
         src, sslot = self._place[tr.trial_id]
-        dslot = self._free[dst].pop(0)
+        dslot = self._free[dst][0]            # taken for good only once the state has arrived
         eng = self.engine
         try:
             if hasattr(eng, "export_raw"):
@@ -468,8 +472,13 @@ class PackedExecutor(Executor):
             else:
                 payload = self.comm.broadcast_object(eng.export(sslot) if self.rank == src else None, src=src)
         except Exception as e:          # noqa: BLE001 - RCCL / gloo raise backend-specific types
-            raise RankLostError(f"rank {self.rank} of {self.world}: moving trial {tr.trial_id} from rank {src} to "
-                                f"rank {dst} failed ({type(e).__name__}: {e})") from e
+            what = (f"rank {self.rank} of {self.world}: moving trial {tr.trial_id} from rank {src} to "
+                    f"rank {dst} failed ({type(e).__name__}: {e})")
+            if self.t.on_rank_loss != "repair":
+                raise RankLostError(what) from e
+            self._lost_pending.extend(self._repair(what, e))
+            return False
+        self._free[dst].pop(0)
         if self.rank == dst:
             if hasattr(eng, "import_raw"):
                 eng.import_raw(dslot, tr.index, tr.config, payload)
@@ -482,6 +491,7 @@ class PackedExecutor(Executor):
         self._place[tr.trial_id] = (dst, dslot)
         tr.placement = {"rank": dst, "slot": dslot}
         self.stats["migrations"] += 1
+        return True
 
     def shutdown(self) -> None:
         self.engine.close()

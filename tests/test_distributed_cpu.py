@@ -291,6 +291,56 @@ def test_survivors_of_a_lost_rank_re_form_the_group_and_finish_the_search():
     assert any(max(h) == 4 for h in tr0.values())
 
 
+def test_a_rank_lost_while_handing_a_trial_over_is_repaired_too():
+    """Three in-process ranks; after the first epoch only rank 1's four trials are left, so two of them are to move.  Rank 1
+    vanishes while exporting the first one.  The others re-form the group, plan again (nothing left to move), get the four
+    trials back as lost and train them from their initial weights to the end."""
+    from mitune.packed.engine import TorchPackEngine
+
+    class KeepRankOne(ASHAScheduler):
+        def on_batch_result(self, runner, trials, results):
+            return [self.STOP if (t.index % 3 != 1 or r["training_iteration"] >= 3) else self.CONTINUE
+                    for t, r in zip(trials, results)]
+
+    comms = ThreadComm.make(3)
+    out = {}
+
+    def body(r):
+        c = comms[r]
+
+        class DyingEngine(TorchPackEngine):
+            def export(self, slot):
+                if r == 1:
+                    c.hub.leave(c.rank)
+                    raise _Vanish()
+                return super().export(slot)
+
+        try:
+            train, val = _data()
+            tr = PackedTrainable(train=train, val=val, max_epochs=3, engine="torch", capacity=4, name="move_loss")
+            ex = PackedExecutor(tr, comm=c, device=torch.device("cpu"), capacity=4, seed=0,
+                                engine=DyingEngine(tr, "cpu", 4, 0))
+            an = mitune.run(tr, config=SPACE, num_samples=12, executor=ex, seed=0, verbose=0,
+                            scheduler=KeepRankOne(metric="validation_loss", mode="min", max_t=3))
+            out[r] = ({t.trial_id: (t.status, t.training_iteration, t.last_result["validation_loss"]) for t in an.trials},
+                      dict(an.stats))
+        except _Vanish:
+            pass
+
+    ths = [threading.Thread(target=body, args=(r,)) for r in range(3)]
+    [t.start() for t in ths]
+    [t.join(timeout=300) for t in ths]
+    assert sorted(out) == [0, 2]
+    assert out[0][0] == out[2][0]
+    res, stats = out[0]
+    assert all(st == "TERMINATED" for st, _, _ in res.values())
+    assert sorted(it for _, it, _ in res.values()) == [1] * 8 + [3] * 4
+    assert stats["ranks_lost"] == 1 and stats["trials_recovered"] == 4 and stats["migrations"] == 0
+    ref, _ = _search(LocalComm(), num_samples=12, capacity=12, epochs=3,
+                     scheduler=KeepRankOne(metric="validation_loss", mode="min", max_t=3))
+    assert {k: (v[1], round(v[2], 6)) for k, v in res.items()} == {k: v[:2] for k, v in ref.items()}
+
+
 def _gloo_repair_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       MITUNE_RENDEZVOUS_DIR=os.path.join(out_dir, "rdzv"))
