@@ -226,7 +226,12 @@ class TorchDistComm(Comm):
         backend = self.backend
         try:
             if dist.is_initialized():
-                dist.destroy_process_group()
+                if backend == "nccl" and hasattr(dist.distributed_c10d, "_abort_process_group"):
+                    # an RCCL communicator with a dead peer cannot finish its pending work: abort it instead of
+                    # draining it (an orderly destroy would wait for the collective that just failed)
+                    dist.distributed_c10d._abort_process_group()
+                else:
+                    dist.destroy_process_group()
         except Exception:       # noqa: BLE001 - a group with a dead peer may refuse an orderly shutdown
             pass
         self._generation += 1
