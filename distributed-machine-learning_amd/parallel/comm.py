@@ -101,6 +101,50 @@ def single_node_bootstrap(world_size: int) -> None:
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 
 
+def file_rendezvous(gdir: str, old_rank: int, old_world: int, settle_s: float, timeout_s: float) -> List[int]:
+    """Agree, through files in ``gdir`` alone, on which of ``old_world`` ranks are still there; returns their old ranks in
+    ascending order (the same list on every member) or raises on a rank that is not among them.
+
+    Every caller drops ``alive.<rank>``.  When all old ranks have shown up, or nobody new has for ``settle_s`` seconds, the
+    lowest rank present publishes the list it sees (``members.json``, created by an atomic link: the first writer wins,
+    and whatever it wrote stands for everybody).  A rank that arrives after that finds itself left out and raises: to
+    the members it is as lost as the ranks that never came, and they have already taken its work."""
+    os.makedirs(gdir, exist_ok=True)
+    members_path = os.path.join(gdir, "members.json")
+    with open(os.path.join(gdir, f"alive.{old_rank}"), "w") as f:
+        f.write(str(os.getpid()))
+
+    def alive() -> List[int]:
+        return sorted(int(n.split(".", 1)[1]) for n in os.listdir(gdir) if n.startswith("alive."))
+
+    t0 = time.time()
+    seen, last_change = alive(), time.time()
+    while not os.path.exists(members_path):
+        now_alive = alive()
+        if now_alive != seen:
+            seen, last_change = now_alive, time.time()
+        settled = len(seen) == old_world or time.time() - last_change >= settle_s
+        if settled and seen and seen[0] == old_rank:
+            tmp = os.path.join(gdir, f"members.tmp.{old_rank}")
+            with open(tmp, "w") as f:
+                json.dump(seen, f)
+            try:
+                os.link(tmp, members_path)        # fails if someone else published first: theirs stands
+            except FileExistsError:
+                pass
+            break
+        if time.time() - t0 > timeout_s:
+            raise RuntimeError(f"rank {old_rank}: no member list appeared in {gdir} within {timeout_s} s")
+        time.sleep(0.02)
+    while not os.path.exists(members_path):
+        time.sleep(0.01)
+    with open(members_path) as f:
+        members = [int(r) for r in json.load(f)]
+    if old_rank not in members:
+        raise RuntimeError(f"rank {old_rank} reached the rendezvous after the survivors {members} had re-formed the group")
+    return members
+
+
 class TorchDistComm(Comm):
     """``torch.distributed`` process group (RCCL when the backend is "nccl")."""
 
@@ -236,39 +280,7 @@ class TorchDistComm(Comm):
             pass
         self._generation += 1
         gdir = os.path.join(self.rendezvous_dir, f"gen{self._generation}")
-        os.makedirs(gdir, exist_ok=True)
-        members_path = os.path.join(gdir, "members.json")
-        with open(os.path.join(gdir, f"alive.{old_rank}"), "w") as f:
-            f.write(str(os.getpid()))
-
-        def alive() -> List[int]:
-            return sorted(int(n.split(".", 1)[1]) for n in os.listdir(gdir) if n.startswith("alive."))
-
-        t0 = time.time()
-        seen, last_change = alive(), time.time()
-        while not os.path.exists(members_path):
-            now_alive = alive()
-            if now_alive != seen:
-                seen, last_change = now_alive, time.time()
-            settled = len(seen) == old_world or time.time() - last_change >= self.settle_s
-            if settled and seen and seen[0] == old_rank:
-                tmp = os.path.join(gdir, f"members.tmp.{old_rank}")
-                with open(tmp, "w") as f:
-                    json.dump(seen, f)
-                try:
-                    os.link(tmp, members_path)        # fails if someone else published first: theirs stands
-                except FileExistsError:
-                    pass
-                break
-            if time.time() - t0 > self.timeout_s:
-                raise RuntimeError(f"rank {old_rank}: no member list appeared in {gdir} within {self.timeout_s} s")
-            time.sleep(0.05)
-        while not os.path.exists(members_path):
-            time.sleep(0.01)
-        with open(members_path) as f:
-            members = [int(r) for r in json.load(f)]
-        if old_rank not in members:
-            raise RuntimeError(f"rank {old_rank} reached the rendezvous after the survivors {members} had re-formed the group")
+        members = file_rendezvous(gdir, old_rank, old_world, self.settle_s, self.timeout_s)
         new_rank, new_world = members.index(old_rank), len(members)
         kw = {}
         if backend == "nccl":

@@ -552,3 +552,31 @@ def test_dp_ranks_with_uneven_shards_take_the_same_number_of_steps():
 
     (n0, s0, k0), (n1, s1, k1) = _run_ranks(2, fn)
     assert (n0, n1) == (257, 256) and s0 == s1 == 1 and k0 == k1 == 1
+
+
+# ----------------------------------------------------------------------------------------- rendezvous of survivors
+@pytest.mark.parametrize("world,gone,late", [(3, {1}, None), (8, {0, 5}, None), (4, set(), None), (5, {2}, 4), (2, {0}, None)])
+def test_file_rendezvous_gives_every_survivor_the_same_member_list(tmp_path, world, gone, late):
+    """Ranks that are still there agree on one list (whoever is lowest publishes it, also when rank 0 is gone); a rank that
+    shows up after the list was published is told so."""
+    import time
+    from mitune.parallel.comm import file_rendezvous
+    out, errs = {}, {}
+
+    def body(r):
+        try:
+            if r == late:
+                time.sleep(1.5)
+            out[r] = file_rendezvous(str(tmp_path / "gen1"), r, world, settle_s=0.4, timeout_s=20.0)
+        except RuntimeError as e:
+            errs[r] = str(e)
+
+    ths = [threading.Thread(target=body, args=(r,)) for r in range(world) if r not in gone]
+    [t.start() for t in ths]
+    [t.join(timeout=60) for t in ths]
+    expect = [r for r in range(world) if r not in gone and r != late]
+    assert sorted(out) == expect and all(v == expect for v in out.values())
+    if late is not None:
+        assert "after the survivors" in errs[late]
+    else:
+        assert not errs
