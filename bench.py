@@ -122,9 +122,13 @@ def main():
     kw = {"max_width": 512, "max_layers": 3, "max_batch": 1024}
 
     def search(trials_per_gpu: int, rounds: int, seed: int, dtype: str = args.dtype):
+        # On several GPUs every rank keeps a few slots more than its share of the trials: trials are dealt to the rank
+        # whose trials weigh the least so far (width and batch size decide what a trial costs), and with no slack the last
+        # ones dealt would be forced onto whichever rank still has room.  The number of trials per GPU does not change.
+        slots = trials_per_gpu + (max(8, trials_per_gpu // 32) if n_gpus > 1 else 0)
         tr = PackedTrainable(train=train, val=val, max_epochs=rounds, engine="hip", dtype=dtype,
-                             capacity=trials_per_gpu, val_chunk=4096, model_kwargs=kw, name="bench_mlp")
-        ex = PackedExecutor(tr, comm=comm, device=device, capacity=trials_per_gpu, seed=seed)
+                             capacity=slots, val_chunk=4096, model_kwargs=kw, name="bench_mlp")
+        ex = PackedExecutor(tr, comm=comm, device=device, capacity=slots, seed=seed)
         sched = ASHAScheduler(metric="validation_loss", mode="min", max_t=rounds, grace_period=1, reduction_factor=4)
         return mitune.run(tr, config=search_space(), num_samples=trials_per_gpu * n_gpus, scheduler=sched,
                           executor=ex, seed=seed, verbose=args.verbose if comm.rank == 0 else 0, local_dir=None)

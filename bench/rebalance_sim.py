@@ -36,14 +36,28 @@ def step_cost_us(live: int) -> float:
     return float(np.interp(live, xs, ys))
 
 
+def true_cost(config) -> float:
+    """Seconds a round of this trial adds to its GPU: HipPackEngine.trial_cost for the headline data (f32)."""
+    w = [64, int(config["width_0"]), int(config["width_1"]), int(config["width_2"]), 1]
+    macs = sum(a * b for a, b in zip(w[:-1], w[1:]))
+    b = int(config["batch_size"])
+    steps = 800_000 // b
+    return macs * (6.0 * steps * b + 2.0 * 200_000) / 6.0e13 + steps * 5.0e-6
+
+
 class ReplayEngine(PackEngine):
     name = "replay"
 
-    def __init__(self, capacity: int, log: list):
+    def __init__(self, capacity: int, log: list, weigh: bool = True, loads: list = None):
         self.capacity, self.slots, self.log = capacity, {}, log
+        self.weigh, self.loads, self.costs = weigh, loads if loads is not None else [], {}
+
+    def trial_cost(self, config):
+        return true_cost(config) if self.weigh else 1.0
 
     def load(self, slot, trial_index, config, state=None):
         self.slots[slot] = [int(trial_index), int((state or {}).get("epoch", 0))]
+        self.costs[slot] = true_cost(config)
 
     def evict(self, slot):
         self.slots.pop(slot, None)
@@ -53,6 +67,7 @@ class ReplayEngine(PackEngine):
 
     def train_epoch(self):
         self.log.append(len(self.slots))
+        self.loads.append(sum(self.costs[k] for k in self.slots))
         for s in self.slots.values():
             s[1] += 1
 
@@ -69,16 +84,18 @@ class ReplayEngine(PackEngine):
         return {"model": {}, "epoch": self.slots[slot][1], "step": 0, "trial_index": self.slots[slot][0]}
 
 
-def run(ranks: int, per_gpu: int, rounds: int, gap: int):
+def run(ranks: int, per_gpu: int, rounds: int, gap: int, weigh: bool = True, slack: int = 0):
     comms = ThreadComm.make(ranks)
     X = torch.zeros(8, 4)
     logs = [[] for _ in range(ranks)]
+    loads = [[] for _ in range(ranks)]
     stats = [None] * ranks
 
     def body(r):
-        tr = PackedTrainable(train=(X, X[:, 0]), val=(X, X[:, 0]), max_epochs=rounds, capacity=per_gpu, rebalance_gap=gap)
-        ex = PackedExecutor(tr, comm=comms[r], device=torch.device("cpu"), capacity=per_gpu, seed=0,
-                            engine=ReplayEngine(per_gpu, logs[r]))
+        cap = per_gpu + slack
+        tr = PackedTrainable(train=(X, X[:, 0]), val=(X, X[:, 0]), max_epochs=rounds, capacity=cap, rebalance_gap=gap)
+        ex = PackedExecutor(tr, comm=comms[r], device=torch.device("cpu"), capacity=cap, seed=0,
+                            engine=ReplayEngine(cap, logs[r], weigh, loads[r]))
         sched = ASHAScheduler(metric="validation_loss", mode="min", max_t=rounds, grace_period=1, reduction_factor=4)
         an = mitune.run(tr, config=headline.search_space(), num_samples=per_gpu * ranks, scheduler=sched, executor=ex,
                         seed=0, verbose=0, local_dir=None)
@@ -88,6 +105,7 @@ def run(ranks: int, per_gpu: int, rounds: int, gap: int):
     [t.start() for t in ths]
     [t.join() for t in ths]
     live = np.array(logs)                                                     # [rank, round]
+    run.loads = np.array(loads)                                               # modelled seconds per rank and round
     return live, stats[0]
 
 
@@ -107,6 +125,17 @@ def main():
         print(f"{args.ranks} ranks, rebalance_gap {gap}: fullest rank per round {worst.tolist()}")
         print(f"          mean per round {[round(float(m), 1) for m in mean]}  migrations {st['migrations']}  "
               f"modelled train time {t:.2f} s  -> weak-scaling efficiency of the training part {t_one / t:.3f}")
+    # The same search priced by what each trial weighs (width, batch size) instead of by head count: a round lasts as long
+    # as the rank whose trials weigh the most.
+    for label, weigh, slack in (("trials dealt and moved by head count", False, 0), ("trials dealt and moved by weight", True, 0),
+                                ("by weight, 8 spare slots per rank", True, 8)):
+        live, st = run(args.ranks, args.trials_per_gpu, args.rounds, 2, weigh, slack)
+        loads = run.loads
+        worst, mean = loads.max(0), loads.mean(0)
+        print(f"{args.ranks} ranks, {label}: heaviest / mean rank per round "
+              f"{[round(float(a / b), 3) for a, b in zip(worst, mean)]}")
+        print(f"          migrations {st['migrations']}  modelled round times: sum of heaviest {worst.sum():.2f} s, sum of mean "
+              f"{mean.sum():.2f} s  -> weak-scaling efficiency of the training part {mean.sum() / worst.sum():.3f}")
 
 
 if __name__ == "__main__":

@@ -44,6 +44,12 @@ class PackEngine:
     def load(self, slot: int, trial_index: int, config: Dict, state: Optional[Dict] = None) -> None:
         raise NotImplementedError
 
+    def trial_cost(self, config: Dict) -> float:
+        """What one round of a trial with this configuration weighs on its GPU, in any unit that adds up over the trials
+        of a rank (the executor spreads trials over the ranks by it: a round lasts as long as its most loaded GPU).  A
+        function of the configuration alone, so every rank computes the same number.  1.0 = every trial weighs the same."""
+        return 1.0
+
     def evict(self, slot: int) -> None:
         raise NotImplementedError
 

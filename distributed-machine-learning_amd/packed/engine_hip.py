@@ -402,6 +402,22 @@ class HipPackEngine(PackEngine):
         if self.slots.pop(slot, None) is not None:
             self._dirty = True
 
+    # measured on one MI355X: the mixed packs of a search sustain about 60 TFLOP/s (f32) / 200 (bf16) of useful arithmetic,
+    # and a step costs about 5 us per resident trial on top (launch boundaries, tails)
+    COST_FLOPS = {"f32": 6.0e13, "bf16": 2.0e14}
+    COST_STEP_S = 5.0e-6
+
+    def trial_cost(self, config) -> float:
+        """Seconds one round (a training epoch and a validation pass) of this trial adds to its GPU: arithmetic at the
+        rate mixed packs sustain plus a per-step share of the launch chain."""
+        spec = MLPTrialSpec.from_config(config, self.F)
+        dims = [self.F] + list(spec.hidden_sizes) + [1]
+        macs = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+        b = min(spec.batch_size, self.n_train)
+        steps = self.n_train // b
+        flop = macs * (6.0 * steps * b + 2.0 * self.n_val)
+        return flop / self.COST_FLOPS[self.t.dtype] + steps * self.COST_STEP_S
+
     def export(self, slot):
         s = self.slots[slot]
         return {"model": self._read_params(slot, s.layout, self.P),

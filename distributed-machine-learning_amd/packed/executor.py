@@ -91,6 +91,11 @@ class PackedExecutor(Executor):
         self.experiment_id = experiment_id
         self._free: List[List[int]] = [list(range(self.capacity)) for _ in range(self.world)]
         self._place: Dict[str, Tuple[int, int]] = {}          # trial_id -> (rank, slot)
+        # what every live trial weighs (engine.trial_cost of its configuration: replicated, like the placement) and the
+        # sum per rank: trials are dealt and moved so that the most loaded rank -- which sets the round time -- is as light
+        # as possible.  An engine that weighs every trial 1.0 gets the plain count balance.
+        self._cost: Dict[str, float] = {}
+        self._load: List[float] = [0.0] * self.world
         self._live: Dict[str, Trial] = {}
         self._queued: List[Event] = []
         self._awaiting: Dict[str, Optional[str]] = {}          # trial_id -> decision (None = not yet)
@@ -131,8 +136,13 @@ class PackedExecutor(Executor):
         return len(self._live) + len(self._queued)
 
     def start_trial(self, trial: Trial) -> None:
-        owner = max(range(self.world), key=lambda r: (len(self._free[r]), -r))
+        cost = float(self.engine.trial_cost(trial.config))
+        # the least loaded rank that has a free slot (equal weights: the rank with the most free slots; ties: lowest rank)
+        owner = min((r for r in range(self.world) if self._free[r]),
+                    key=lambda r: (round(self._load[r], 12), -len(self._free[r]), r))
         slot = self._free[owner].pop(0)
+        self._cost[trial.trial_id] = cost
+        self._load[owner] += cost
         self._place[trial.trial_id] = (owner, slot)
         self._live[trial.trial_id] = trial
         self._t_total.setdefault(trial.trial_id, float(trial.last_result.get("time_total_s", 0.0)))
@@ -293,6 +303,7 @@ class PackedExecutor(Executor):
         new_of = {old: new for new, old in enumerate(survivors)}
         self.rank, self.world = self.comm.rank, self.comm.world_size
         self._free = [self._free[old] for old in survivors]
+        self._load = [self._load[old] for old in survivors]
         lost_trials: List[Trial] = []
         for tid, (r, slot) in sorted(self._place.items()):
             tr = self._live[tid]
@@ -302,6 +313,7 @@ class PackedExecutor(Executor):
             else:
                 del self._place[tid]
                 del self._live[tid]
+                self._cost.pop(tid, None)
                 lost_trials.append(tr)
         lost_trials.sort(key=lambda t: t.index)
         trials = self.runner.trials if self.runner is not None else list(self._live.values()) + lost_trials
@@ -378,12 +390,19 @@ class PackedExecutor(Executor):
             keep = self.runner.keep_checkpoints_num if self.runner is not None else None
             ckpt.save_checkpoint(tr.logdir, tr.training_iteration, state, keep)
 
+    def _unload(self, tid: str, rank: int) -> None:
+        """Take a trial's weight off its rank (call after its slot went back to the free list)."""
+        self._load[rank] -= self._cost.pop(tid, 0.0)
+        if len(self._free[rank]) == self.capacity:
+            self._load[rank] = 0.0          # no rounding residue on an empty rank
+
     def _drop(self, tr: Trial) -> None:
         owner, slot = self._place.pop(tr.trial_id)
         if owner == self.rank:
             self.engine.evict(slot)
         self._free[owner].append(slot)
         self._free[owner].sort()
+        self._unload(tr.trial_id, owner)
         self._live.pop(tr.trial_id)
 
     def _retire(self, tr: Trial) -> None:
@@ -396,6 +415,7 @@ class PackedExecutor(Executor):
             self.engine.evict(slot)
         self._free[owner].append(slot)
         self._free[owner].sort()
+        self._unload(tr.trial_id, owner)
         self._live.pop(tr.trial_id)
         self._retired_now += 1
         self._queued.append(Event("done", tr, result={"decision": STOP}))
@@ -433,8 +453,7 @@ class PackedExecutor(Executor):
 
     # ------------------------------------------------------------------ load balance between GPUs
     def _rebalance(self) -> None:
-        """Move trials from the fullest rank to the emptiest until their live-trial counts differ by less than
-        ``rebalance_gap``.  Every rank holds the same placement tables, so all of them plan the same moves in the same
+        """Move trials from the most loaded rank to the least loaded until no move is worth it.  Every rank holds the same placement tables, so all of them plan the same moves in the same
         order with no message exchanged; a move itself is one broadcast from the trial's old owner."""
         # A move has a price (building the trial again on the other GPU; for the slab engines next to nothing) and
         # buys one trial's time per round off the fullest rank.  It has to pay within the two rounds a trial that just
@@ -444,13 +463,32 @@ class PackedExecutor(Executor):
             return
         t0, moved = time.time(), False
         gap = max(2, int(self.t.rebalance_gap))      # a difference of one cannot be improved, only passed back and forth
-        while True:
-            load = [self.capacity - len(self._free[r]) for r in range(self.world)]
-            hi = max(range(self.world), key=lambda r: (load[r], -r))
-            lo = min(range(self.world), key=lambda r: (load[r], r))
-            if load[hi] - load[lo] < gap or not self._free[lo]:
+        # Weights, not head counts: the round lasts as long as the rank whose trials weigh the most.  A trial moves from
+        # the heaviest rank to the lightest one that has a free slot; the trial taken is the one that brings the pair
+        # closest to level (with equal weights: any, and the newest is taken).  It stops when the best move would gain less
+        # than ``gap`` per cent of a round (equal weights: when the two ranks are fewer than ``gap`` trials apart).
+        # Bounded: every move lowers the heavier of the two without lifting the lighter above it.
+        for _ in range(4 * self.capacity):
+            live = len(self._place)
+            if live == 0 or self.world < 2:
                 break
-            tid = max((t for t, (r, _) in self._place.items() if r == hi), key=lambda t: self._live[t].index)
+            unit = sum(self._load) / live
+            hi = max(range(self.world), key=lambda r: (round(self._load[r], 12), -r))
+            open_ = [r for r in range(self.world) if self._free[r] and r != hi]
+            if not open_:
+                break
+            lo = min(open_, key=lambda r: (round(self._load[r], 12), r))
+            diff = self._load[hi] - self._load[lo]
+            cands = [(t, self._cost[t]) for t, (r, _) in self._place.items() if r == hi and self._cost[t] < diff * (1.0 - 1e-9)]
+            if not cands:
+                break
+            tid, c = min(cands, key=lambda tc: (round(abs(tc[1] - diff / 2.0), 12), -self._live[tc[0]].index))
+            costs = self._cost.values()
+            if max(costs) - min(costs) <= 1e-12 * unit:
+                if diff < gap * unit * (1.0 - 1e-9):      # equal weights: head counts, ``gap`` apart
+                    break
+            elif min(c, diff - c) < 0.01 * gap * sum(self._load) / self.world:
+                break       # the best move would take less than gap per cent of a round off the heavier rank
             if not self._move(self._live[tid], lo):
                 continue        # a rank vanished during the move and the group was re-formed: plan again for the survivors
             moved = True
@@ -490,6 +528,11 @@ class PackedExecutor(Executor):
         self._free[src].sort()
         self._place[tr.trial_id] = (dst, dslot)
         tr.placement = {"rank": dst, "slot": dslot}
+        c = self._cost.get(tr.trial_id, 0.0)
+        self._load[src] -= c
+        self._load[dst] += c
+        if len(self._free[src]) == self.capacity:
+            self._load[src] = 0.0
         self.stats["migrations"] += 1
         return True
 
