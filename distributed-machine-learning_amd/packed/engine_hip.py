@@ -402,10 +402,12 @@ class HipPackEngine(PackEngine):
         if self.slots.pop(slot, None) is not None:
             self._dirty = True
 
-    # measured on one MI355X: the mixed packs of a search sustain about 60 TFLOP/s (f32) / 200 (bf16) of useful arithmetic,
-    # and a step costs about 5 us per resident trial on top (launch boundaries, tails)
+    # measured on one MI355X: the mixed packs of a search sustain about 60 TFLOP/s (f32) / 200 (bf16) of useful arithmetic;
+    # on top, a step costs a few microseconds per resident trial (launch boundaries, tails): about 5 us in a pack of 16
+    # survivors, much less in a full pack, where the launches are shared by hundreds of trials.  The weights only have
+    # to rank trials against each other: arithmetic decides in the early, full rounds, the step count adds to it late.
     COST_FLOPS = {"f32": 6.0e13, "bf16": 2.0e14}
-    COST_STEP_S = 5.0e-6
+    COST_STEP_S = 2.0e-6
 
     def trial_cost(self, config) -> float:
         """Seconds one round (a training epoch and a validation pass) of this trial adds to its GPU: arithmetic at the
