@@ -42,7 +42,7 @@ def true_cost(config) -> float:
     macs = sum(a * b for a, b in zip(w[:-1], w[1:]))
     b = int(config["batch_size"])
     steps = 800_000 // b
-    return macs * (6.0 * steps * b + 2.0 * 200_000) / 6.0e13 + steps * 5.0e-6
+    return macs * (6.0 * steps * b + 2.0 * 200_000) / 6.0e13 + steps * 2.0e-6
 
 
 class ReplayEngine(PackEngine):
