@@ -479,8 +479,12 @@ def test_four_ranks_stay_balanced_through_an_asha_search():
     spec = importlib.util.spec_from_file_location("rebalance_sim", os.path.join(root, "bench", "rebalance_sim.py"))
     sim = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(sim)
-    live, stats = sim.run(4, 32, 8, gap=2)
+    live, stats = sim.run(4, 32, 8, gap=2, weigh=False)       # every trial weighs the same: head counts are levelled
     assert live.shape == (4, 8) and int((live.max(0) - live.min(0)).max()) <= 1 and stats["migrations"] > 0
+    by_count = sim.run.loads.max(0) / sim.run.loads.mean(0)   # what the heaviest rank carries, by what trials really weigh
+    sim.run(4, 32, 8, gap=2, weigh=True)                      # the engine says what a trial weighs: weights are levelled
+    by_weight = sim.run.loads.max(0) / sim.run.loads.mean(0)
+    assert by_weight[0] < by_count[0] and by_weight.sum() < by_count.sum()
     assert live.sum(0).tolist() == [128, 32, 32, 32, 8, 8, 8, 8]          # rungs at 1 and 4, reduction factor 4
     still, stats0 = sim.run(4, 32, 8, gap=0)
     assert stats0["migrations"] == 0 and int((still.max(0) - still.min(0)).max()) > 1
