@@ -593,11 +593,196 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_exact_kernel(const flo
                       seed != nullptr, s0, s1, thresh, blockIdx.x);
 }
 
-// MITUNE_ATTN_EXACT=0 sends f32 operands of short sequences through the matrix form too (operands rounded to bf16).
-static bool at_exact_on() {
-  static const bool on = [] { const char* e = getenv("MITUNE_ATTN_EXACT"); return !(e && e[0] == '0'); }();
-  return on;
+// ---------------------------------------------------------------------------------------------------------------
+// The same exact-f32 arithmetic for sequences of 33..128 tokens: K and V stay in LDS for the whole (batch, head), the
+// queries are walked in blocks of ATL_QB rows (their Q / dO rows and S-wide score rows are the only per-block images),
+// and in the backward pass every thread keeps the dK and dV elements it owns -- (key, column) pairs dealt round-robin --
+// in registers across the blocks.  Row pitches follow the head width (d + 1 floats) and the sequence (S + 1), so the
+// images of a narrow head take a fraction of the LDS; the launcher passes the byte count as dynamic LDS.
+#define ATL_QB 32
+#define ATL_MAX_S 128
+#define ATL_OWN 32          // (key, column) pairs a thread owns at most: 128 keys x 64 columns / 256 threads
+
+static size_t atl_fwd_lds(int S, int dk, int dv) {
+  return (size_t)(S * (dk + 1) + S * (dv + 1) + ATL_QB * (dk + 1) + ATL_QB * (S + 1)) * 4;
 }
+static size_t atl_bwd_lds(int S, int dk, int dv) {
+  return (size_t)(S * (dk + 1) + S * (dv + 1) + ATL_QB * (dk + 1) + ATL_QB * (dv + 1) + 3 * ATL_QB * (S + 1) + ATL_QB) * 4;
+}
+
+__device__ __forceinline__ void atl_stage(float* dst, int pitch, const float* __restrict__ src, int rows, int d, long ld,
+                                          int tid) {
+  for (int q = tid; q < rows * d; q += AT_THREADS) {
+    const int r = q / d, c = q - r * d;
+    dst[r * pitch + c] = src[(size_t)r * ld + c];
+  }
+}
+
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_exact_tiled_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const uint8_t* __restrict__ keep,
+    float* __restrict__ O, float* __restrict__ stat, int S, int dk, int dv, float scale, float keep_scale, int kind, int H,
+    long ldq, long ldv, long ldo, const int64_t* __restrict__ seed, uint32_t thresh) {
+  extern __shared__ __attribute__((aligned(16))) float atl_lds[];
+  const int pk = dk + 1, pv = dv + 1, ps = S + 1;
+  float *k = atl_lds, *v = k + S * pk, *q = v + S * pv, *sc = q + ATL_QB * pk;
+  const int tid = threadIdx.x, bh = blockIdx.x;
+  const bool seeded = seed != nullptr;
+  uint32_t s0 = 0u, s1 = 0u;
+  if (seeded) { const uint64_t sv = (uint64_t)seed[0]; s0 = (uint32_t)sv; s1 = (uint32_t)(sv >> 32); }
+  const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
+  atl_stage(k, pk, K + qoff, S, dk, ldq, tid);
+  atl_stage(v, pv, V + voff, S, dv, ldv, tid);
+  for (int q0 = 0; q0 < S; q0 += ATL_QB) {
+    const int nq = (S - q0 < ATL_QB) ? S - q0 : ATL_QB;
+    __syncthreads();                      // K / V staged; the previous block's images are free
+    atl_stage(q, pk, Q + qoff + (size_t)q0 * ldq, nq, dk, ldq, tid);
+    __syncthreads();
+    for (int p = tid; p < nq * S; p += AT_THREADS) {
+      const int i = p / S, j = p - i * S;
+      float acc = 0.f;
+      for (int d = 0; d < dk; ++d) acc = fmaf(q[i * pk + d], k[j * pk + d], acc);
+      sc[i * ps + j] = acc * scale;
+    }
+    __syncthreads();
+    if (tid < nq) {
+      float* row = sc + tid * ps;
+      const int qi = q0 + tid;
+      float norm;
+      if (kind == 0) {
+        float m = row[0];
+        for (int j = 1; j < S; ++j) m = fmaxf(m, row[j]);
+        float l = 0.f;
+        for (int j = 0; j < S; ++j) { const float e = expf(row[j] - m); row[j] = e; l += e; }
+        norm = 1.f / l;
+        stat[(size_t)bh * S + qi] = m + logf(l);
+      } else {
+        float z = 0.f;
+        for (int j = 0; j < S; ++j) { const float a = fmaxf(row[j], 0.f); row[j] = a; z += a; }
+        z += AT_RELU_EPS;
+        norm = 1.f / z;
+        stat[(size_t)bh * S + qi] = z;
+      }
+      const size_t at = ((size_t)bh * S + qi) * S;
+      for (int j = 0; j < S; ++j) row[j] = row[j] * norm * atx_keep(keep, seeded, s0, s1, thresh, at + j, keep_scale);
+    }
+    __syncthreads();
+    for (int p = tid; p < nq * dv; p += AT_THREADS) {
+      const int i = p / dv, n = p - i * dv;
+      float acc = 0.f;
+      for (int j = 0; j < S; ++j) acc = fmaf(sc[i * ps + j], v[j * pv + n], acc);
+      O[ooff + (size_t)(q0 + i) * ldo + n] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_exact_tiled_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
+    const uint8_t* __restrict__ keep, const float* __restrict__ stat, float* __restrict__ dQ, float* __restrict__ dK,
+    float* __restrict__ dV, int S, int dk, int dv, float scale, float keep_scale, int kind, int H, long ldq, long ldv,
+    long ldo, const int64_t* __restrict__ seed, uint32_t thresh) {
+  extern __shared__ __attribute__((aligned(16))) float atl_lds[];
+  const int pk = dk + 1, pv = dv + 1, ps = S + 1;
+  float *k = atl_lds, *v = k + S * pk, *q = v + S * pv, *go = q + ATL_QB * pk;
+  float *pr = go + ATL_QB * pv, *ds = pr + ATL_QB * ps, *pm = ds + ATL_QB * ps, *delta = pm + ATL_QB * ps;
+  const int tid = threadIdx.x, bh = blockIdx.x;
+  const bool seeded = seed != nullptr;
+  uint32_t s0 = 0u, s1 = 0u;
+  if (seeded) { const uint64_t sv = (uint64_t)seed[0]; s0 = (uint32_t)sv; s1 = (uint32_t)(sv >> 32); }
+  const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
+  atl_stage(k, pk, K + qoff, S, dk, ldq, tid);
+  atl_stage(v, pv, V + voff, S, dv, ldv, tid);
+  float acck[ATL_OWN], accv[ATL_OWN];      // dK / dV of the pairs p = tid + 256 * t, summed over the query blocks in order
+#pragma unroll
+  for (int t = 0; t < ATL_OWN; ++t) { acck[t] = 0.f; accv[t] = 0.f; }
+  for (int q0 = 0; q0 < S; q0 += ATL_QB) {
+    const int nq = (S - q0 < ATL_QB) ? S - q0 : ATL_QB;
+    __syncthreads();
+    atl_stage(q, pk, Q + qoff + (size_t)q0 * ldq, nq, dk, ldq, tid);
+    atl_stage(go, pv, dO + ooff + (size_t)q0 * ldo, nq, dv, ldo, tid);
+    __syncthreads();
+    for (int p = tid; p < nq * S; p += AT_THREADS) {
+      const int i = p / S, j = p - i * S, qi = q0 + i;
+      float s = 0.f, dp = 0.f;
+      for (int d = 0; d < dk; ++d) s = fmaf(q[i * pk + d], k[j * pk + d], s);
+      for (int n = 0; n < dv; ++n) dp = fmaf(go[i * pv + n], v[j * pv + n], dp);
+      s *= scale;
+      const float st = stat[(size_t)bh * S + qi];
+      const float pval = (kind == 0) ? expf(s - st) : fmaxf(s, 0.f) / st;
+      const float mk = atx_keep(keep, seeded, s0, s1, thresh, ((size_t)bh * S + qi) * S + j, keep_scale);
+      pr[i * ps + j] = pval;
+      ds[i * ps + j] = dp * mk;
+      pm[i * ps + j] = pval * mk;
+    }
+    __syncthreads();
+    if (tid < nq) {
+      float a = 0.f;
+      for (int j = 0; j < S; ++j) a = fmaf(ds[tid * ps + j], pr[tid * ps + j], a);
+      delta[tid] = a;
+    }
+    __syncthreads();
+    for (int p = tid; p < nq * S; p += AT_THREADS) {
+      const int i = p / S, j = p - i * S;
+      const float pval = pr[i * ps + j], g = ds[i * ps + j] - delta[i];
+      float r;
+      if (kind == 0) r = pval * g * scale;
+      else r = (pval > 0.f) ? g * (1.f / stat[(size_t)bh * S + q0 + i]) * scale : 0.f;
+      ds[i * ps + j] = r;
+    }
+    __syncthreads();
+    for (int p = tid; p < nq * dk; p += AT_THREADS) {       // dQ rows of this block
+      const int i = p / dk, d = p - i * dk;
+      float a = 0.f;
+      for (int j = 0; j < S; ++j) a = fmaf(ds[i * ps + j], k[j * pk + d], a);
+      dQ[qoff + (size_t)(q0 + i) * ldq + d] = a;
+    }
+#pragma unroll
+    for (int t = 0; t < ATL_OWN; ++t) {                     // this block's share of dK = dS^T . Q and dV = (dropped P)^T . dO
+      const int p = tid + AT_THREADS * t;
+      if (p < S * dk) {
+        const int j = p / dk, d = p - j * dk;
+        float a = acck[t];
+        for (int i = 0; i < nq; ++i) a = fmaf(ds[i * ps + j], q[i * pk + d], a);
+        acck[t] = a;
+      }
+      if (p < S * dv) {
+        const int j = p / dv, n = p - j * dv;
+        float a = accv[t];
+        for (int i = 0; i < nq; ++i) a = fmaf(pm[i * ps + j], go[i * pv + n], a);
+        accv[t] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < ATL_OWN; ++t) {
+    const int p = tid + AT_THREADS * t;
+    if (p < S * dk) { const int j = p / dk, d = p - j * dk; dK[qoff + (size_t)j * ldq + d] = acck[t]; }
+    if (p < S * dv) { const int j = p / dv, n = p - j * dv; dV[voff + (size_t)j * ldv + n] = accv[t]; }
+  }
+}
+
+// MITUNE_ATTN_EXACT: 0 = f32 operands always go through the matrix form (rounded to bf16); 1 (default) = sequences of up
+// to 32 tokens run the exact-f32 form; 2 = so do sequences of up to 128 tokens (heads of up to 64 elements), tiled.
+static int at_level = -1;
+static int at_exact_level() {
+  if (at_level < 0) { const char* e = getenv("MITUNE_ATTN_EXACT"); at_level = e ? atoi(e) : 1; }
+  return at_level;
+}
+extern "C" int mt_attn_exact_level(int set) {      // set >= 0 replaces the level; returns the one in force before
+  const int was = at_exact_level();
+  if (set >= 0) at_level = set;
+  return was;
+}
+static bool atl_fits(int S, int dk, int dv) {
+  return at_exact_level() >= 2 && S > ATX_MAX_S && S <= ATL_MAX_S && dk <= ATX_MAX_D && dv <= ATX_MAX_D;
+}
+static int atl_prepare(const void* fn, size_t bytes) {      // kernels above 64 KiB of dynamic LDS have to be told so once
+  if (bytes > 160u * 1024u) return -2;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -9;
+  return 0;
+}
+
+// MITUNE_ATTN_EXACT=0 sends f32 operands of short sequences through the matrix form too (operands rounded to bf16).
+static bool at_exact_on() { return at_exact_level() >= 1; }
 static bool at_exact_fits(int S, int dk, int dv) { return S <= ATX_MAX_S && dk <= ATX_MAX_D && dv <= ATX_MAX_D; }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -723,6 +908,15 @@ extern "C" int mt_attn_fwd_strided_launch(const void* Q, const void* K, const vo
                        thresh);
     return (int)hipGetLastError();
   }
+  if (f32 && atl_fits(S, dk, dv)) {
+    const size_t bytes = atl_fwd_lds(S, dk, dv);
+    const int rc2 = atl_prepare((const void*)mt_attn_fwd_exact_tiled_kernel, bytes);
+    if (rc2) return rc2;
+    hipLaunchKernelGGL(mt_attn_fwd_exact_tiled_kernel, grid, block, bytes, stream, (const float*)Q, (const float*)K,
+                       (const float*)V, (const uint8_t*)keep, (float*)O, stat, S, dk, dv, scale, keep_scale, kind, H, ldq,
+                       ldv, ldo, seed, thresh);
+    return (int)hipGetLastError();
+  }
   const bool narrow = dk <= 32 && dv <= 32;
 #define AT_FWD2(N, P, F)                                                                                        \
   hipLaunchKernelGGL((mt_attn_fwd_kernel<N, P, F>), grid, block, 0, stream, Q, K, V, (const uint8_t*)keep, O, stat, S, dk, \
@@ -757,6 +951,15 @@ extern "C" int mt_attn_bwd_strided_launch(const void* Q, const void* K, const vo
     hipLaunchKernelGGL(mt_attn_bwd_exact_kernel, grid, block, 0, stream, (const float*)Q, (const float*)K, (const float*)V,
                        (const float*)dO, (const uint8_t*)keep, stat, dQ, dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq,
                        ldv, ldo, seed, thresh);
+    return (int)hipGetLastError();
+  }
+  if (f32 && atl_fits(S, dk, dv)) {
+    const size_t bytes = atl_bwd_lds(S, dk, dv);
+    const int rc2 = atl_prepare((const void*)mt_attn_bwd_exact_tiled_kernel, bytes);
+    if (rc2) return rc2;
+    hipLaunchKernelGGL(mt_attn_bwd_exact_tiled_kernel, grid, block, bytes, stream, (const float*)Q, (const float*)K,
+                       (const float*)V, (const float*)dO, (const uint8_t*)keep, stat, dQ, dK, dV, S, dk, dv, scale, keep_scale,
+                       kind, H, ldq, ldv, ldo, seed, thresh);
     return (int)hipGetLastError();
   }
   const bool narrow = dk <= 32 && dv <= 32;

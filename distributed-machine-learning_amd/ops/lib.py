@@ -222,6 +222,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_attn_bwd_strided_launch.argtypes = [c_void_p] * 9 + [C.c_int] * 4 + [c_float, c_float, C.c_int, C.c_int,
                                                                    C.c_long, C.c_long, C.c_long, C.c_int, c_void_p, c_float, c_void_p]
     lib.mt_attn_fwd_strided_launch.restype = lib.mt_attn_bwd_strided_launch.restype = C.c_int
+    lib.mt_attn_exact_level.argtypes = [C.c_int]
+    lib.mt_attn_exact_level.restype = C.c_int
     lib.mt_ln_fwd_launch.argtypes = [c_void_p] * 8 + [C.c_int, C.c_int, c_float, c_float, c_void_p, c_float, c_void_p]
     lib.mt_ln_bwd_launch.argtypes = [c_void_p] * 8 + [C.c_int, C.c_int, c_float, c_void_p, c_float, c_void_p]
     lib.mt_ln_bwd_blocks.argtypes = [C.c_int]

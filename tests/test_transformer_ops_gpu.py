@@ -152,6 +152,37 @@ def test_short_sequence_f32_attention_is_exact_f32(B, S, h, dk, dv, drop, kind):
         torch.testing.assert_close(a.double(), r, rtol=2e-5, atol=2e-5 * max(1.0, float(r.abs().max())), msg=lambda m, n=name: f"{n}: {m}")
 
 
+@pytest.mark.parametrize("kind", ["softmax", "relu"])
+@pytest.mark.parametrize("B,S,h,dk,dv,drop", [(3, 96, 4, 32, 32, 0.1), (2, 128, 2, 64, 64, 0.0), (2, 33, 3, 5, 20, 0.2),
+                                              (4, 50, 8, 16, 8, 0.0), (2, 97, 1, 64, 24, 0.3)])
+def test_tiled_exact_f32_attention_for_sequences_of_up_to_128_tokens(B, S, h, dk, dv, drop, kind):
+    """Level 2 of the exact-f32 attention (query blocks of 32 against K and V resident in LDS): float64 reference on the
+    unrounded operands, f32 summation error only."""
+    from mitune.ops import lib as L
+    from mitune.ops.attention import attention_reference
+    from mitune.ops.attention_hip import FusedSelfAttention
+    so = L.load()
+    was = so.mt_attn_exact_level(2)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(23)
+        qk = torch.randn(B, S, 2 * h * dk, device="cuda", generator=g).requires_grad_()
+        v = torch.randn(B, S, h * dv, device="cuda", generator=g).requires_grad_()
+        keep = (torch.rand(B, h, S, S, device="cuda", generator=g) >= drop).to(torch.uint8) if drop > 0 else None
+        do = torch.randn(B, S, h * dv, device="cuda", generator=g)
+        out = FusedSelfAttention.apply(qk, v, h, kind, keep, drop)
+        out.backward(do)
+        torch.cuda.synchronize()
+    finally:
+        so.mt_attn_exact_level(was)
+    qr, vr = qk.detach().double().requires_grad_(), v.detach().double().requires_grad_()
+    q, k = qr.chunk(2, dim=-1)
+    sp = lambda t, d: t.reshape(B, S, h, d).transpose(1, 2)          # noqa: E731
+    ref = attention_reference(sp(q, dk), sp(k, dk), sp(vr, dv), kind, keep, drop).transpose(1, 2).reshape(B, S, h * dv)
+    ref.backward(do.double())
+    for a, r, name in ((out.detach(), ref.detach(), "out"), (qk.grad, qr.grad, "dqk"), (v.grad, vr.grad, "dv")):
+        torch.testing.assert_close(a.double(), r, rtol=3e-5, atol=3e-5 * max(1.0, float(r.abs().max())), msg=lambda m, n=name: f"{n}: {m}")
+
+
 @pytest.mark.parametrize("B,S,h,dk,dv,dtype", [(3, 50, 4, 16, 16, torch.float32), (2, 65, 8, 24, 24, torch.bfloat16),
                                                 (2, 20, 2, 8, 16, torch.float32), (1, 128, 4, 32, 64, torch.bfloat16),
                                                 (2, 96, 16, 3, 12, torch.float32), (2, 96, 32, 5, 10, torch.bfloat16),
