@@ -74,6 +74,64 @@ __device__ __forceinline__ void stage_image(uint8_t* lds, const void* __restrict
   }
 }
 
+// Issue-then-commit staging.  stage_image above waits for each chunk before it asks for the next one, so a workgroup
+// that stages four images of two chunks per thread pays eight global-memory latencies in a row before its first MFMA;
+// these problems are small enough that this wait is most of the workgroup's life.  Here every 16-byte chunk of every
+// image a thread owns is requested first (stage_issue, into registers), and only then converted and written to LDS
+// (stage_commit): one latency per workgroup.  Images whose rows cannot be read as aligned vectors keep the
+// element-by-element path, taken inside stage_commit.
+template <int PCHQ, bool F32, int SP>
+struct StageRegs {
+  static constexpr int NIT = (SP * PCHQ + AT_THREADS - 1) / AT_THREADS;
+  u32x4 lo[NIT];
+  u32x4 hi[F32 ? NIT : 1];        // f32 operands: elements 4..7 of the chunk
+  bool vec;
+};
+
+template <int PCHQ, bool F32, int SP>
+__device__ __forceinline__ void stage_issue(StageRegs<PCHQ, F32, SP>& b, const void* __restrict__ src_, int rows, int cols,
+                                            long ld, int tid) {
+  b.vec = ((cols & 7) == 0) && ((ld & 7) == 0) && ((reinterpret_cast<uintptr_t>(src_) & 15) == 0);
+  if (!b.vec) return;
+#pragma unroll
+  for (int it = 0; it < StageRegs<PCHQ, F32, SP>::NIT; ++it) {
+    const int q = tid + it * AT_THREADS, r = q / PCHQ, c = q % PCHQ;
+    b.lo[it] = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (F32) b.hi[it] = u32x4{0u, 0u, 0u, 0u};
+    if (q < SP * PCHQ && r < rows && c * 8 < cols) {
+      if constexpr (F32) {
+        const float* src = reinterpret_cast<const float*>(src_) + (size_t)r * ld + c * 8;
+        b.lo[it] = *reinterpret_cast<const u32x4*>(src);
+        b.hi[it] = *reinterpret_cast<const u32x4*>(src + 4);
+      } else {
+        b.lo[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(src_) + (size_t)r * ld + c * 8);
+      }
+    }
+  }
+}
+
+template <int PCHQ, bool F32, int SP>
+__device__ __forceinline__ void stage_commit(const StageRegs<PCHQ, F32, SP>& b, uint8_t* lds, const void* __restrict__ src_,
+                                             int rows, int cols, long ld, int tid) {
+  if (!b.vec) { stage_image<PCHQ, F32>(lds, src_, rows, cols, ld, SP, tid); return; }
+#pragma unroll
+  for (int it = 0; it < StageRegs<PCHQ, F32, SP>::NIT; ++it) {
+    const int q = tid + it * AT_THREADS, r = q / PCHQ, c = q % PCHQ;
+    if (q < SP * PCHQ) {
+      u32x4 v = b.lo[it];
+      if constexpr (F32) {
+        const f32x4 x = __builtin_bit_cast(f32x4, b.lo[it]), y = __builtin_bit_cast(f32x4, b.hi[it]);
+        v = u32x4{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+      }
+      *reinterpret_cast<u32x4*>(lds + img_off(r, c, PCHQ)) = v;
+    }
+  }
+}
+
+// How many images are in flight at once: all of them while that is at most 24 registers quads per thread, else two.
+template <int PCHQ, bool F32, int SP>
+constexpr bool stage_all_at_once() { return StageRegs<PCHQ, F32, SP>::NIT * (F32 ? 2 : 1) * 4 <= 24; }
+
 // Where problem bh = (b, head) of a [B, S, H * d] operand with row stride ld starts: element offset.
 __device__ __forceinline__ size_t at_base(int bh, int H, int S, long ld, int d) {
   const int b = bh / H, hh = bh - b * H;
@@ -132,6 +190,87 @@ __device__ __forceinline__ void scores_T(f32x4 (&acc)[NKB], const uint8_t* ldsK,
   }
 }
 
+// The keep flags (one byte each, 1 = keep) of keys key0 .. key0 + 3 for one query: read from the stored mask, or drawn
+// from the seed words at the element's index in the [BH, S, S] mask.
+__device__ __forceinline__ uint32_t keep_word(const uint8_t* __restrict__ keep, uint32_t seed_lo, uint32_t seed_hi,
+                                              uint32_t thresh, size_t at, int key0, int S) {
+  uint32_t kw = 0u;
+  if (keep != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (key0 + j < S) kw |= (uint32_t)keep[at + j] << (8 * j);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (key0 + j < S) kw |= (mt_rng_hash(seed_lo, seed_hi, (uint32_t)(at + j)) >= thresh ? 1u : 0u) << (8 * j);
+  }
+  return kw;
+}
+
+// Scores of one block of 16 queries -> probabilities (dropout applied), in place; writes the row statistic.  KIND and
+// MASKED are compile-time so the 4 * NKB elements a lane owns are straight-line code: with run-time flags every element
+// carried its own branches, and the vector ALU, not the matrix unit, set this kernel's time.
+template <int NKB, int KIND, bool MASKED>
+__device__ __forceinline__ void fwd_probs(f32x4 (&acc)[NKB], float* __restrict__ stat, const uint8_t* __restrict__ keep,
+                                          uint32_t seed_lo, uint32_t seed_hi, uint32_t thresh, int S, int bh, int qb,
+                                          int lane, float scale, float keep_scale) {
+  const int g = lane >> 4, fr = lane & 15;
+  const int query = qb * 16 + fr;
+  float norm;
+  if constexpr (KIND == 0) {
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kb * 16 + g * 4 + j;
+        acc[kb][j] = (key < S) ? acc[kb][j] * scale : -3.0e38f;
+        m = fmaxf(m, acc[kb][j]);
+      }
+    m = group_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p = (kb * 16 + g * 4 + j < S) ? __expf(acc[kb][j] - m) : 0.f;
+        acc[kb][j] = p;
+        l += p;
+      }
+    l = group_sum(l);
+    norm = 1.f / l;
+    if (g == 0 && query < S) stat[(size_t)bh * S + query] = m + __logf(l);
+  } else {
+    float z = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = fmaxf(acc[kb][j] * scale, 0.f);     // padded keys have zero K rows -> a = 0
+        acc[kb][j] = a;
+        z += a;
+      }
+    z = group_sum(z) + AT_RELU_EPS;
+    norm = 1.f / z;
+    if (g == 0 && query < S) stat[(size_t)bh * S + query] = z;
+  }
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    if constexpr (MASKED) {
+      uint32_t kw = 0x01010101u;
+      if (query < S) {
+        const int key0 = kb * 16 + g * 4;
+        kw = keep_word(keep, seed_lo, seed_hi, thresh, ((size_t)bh * S + query) * S + key0, key0, S);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[kb][j] *= norm * (((kw >> (8 * j)) & 0xFFu) ? keep_scale : 0.f);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[kb][j] *= norm * 1.f;
+    }
+  }
+}
+
 // NKB = padded sequence length / 16 (2, 4, 6 or 8); PCHQ = 16-byte chunks per image row; F32: Q, K, V, O are f32
 // (converted while staging) instead of bf16.  Operands are [B, S, H * d] with row strides ldq (Q and K), ldv, ldo, so
 // the halves of a fused QK projection and a [B, S, d_model] value / output tensor are used in place; H = 1 with
@@ -151,76 +290,31 @@ __device__ __forceinline__ void attn_fwd_body(uint8_t* lds, const void* __restri
   const int g = lane >> 4, fr = lane & 15;
   constexpr int ES = F32 ? 4 : 2;       // bytes per operand element
   const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
-  stage_image<PCHQ, F32>(ldsQ, reinterpret_cast<const uint8_t*>(Q_) + qoff * ES, S, dk, ldq, SP, tid);
-  stage_image<PCHQ, F32>(ldsK, reinterpret_cast<const uint8_t*>(K_) + qoff * ES, S, dk, ldq, SP, tid);
-  stage_image<PCHQ, F32>(ldsV, reinterpret_cast<const uint8_t*>(V_) + voff * ES, S, dv, ldv, SP, tid);
+  {
+    const uint8_t* gq = reinterpret_cast<const uint8_t*>(Q_) + qoff * ES;
+    const uint8_t* gk = reinterpret_cast<const uint8_t*>(K_) + qoff * ES;
+    const uint8_t* gv = reinterpret_cast<const uint8_t*>(V_) + voff * ES;
+    StageRegs<PCHQ, F32, SP> rq, rk, rv;
+    stage_issue(rq, gq, S, dk, ldq, tid);
+    stage_issue(rk, gk, S, dk, ldq, tid);
+    if constexpr (stage_all_at_once<PCHQ, F32, SP>()) stage_issue(rv, gv, S, dv, ldv, tid);
+    stage_commit(rq, ldsQ, gq, S, dk, ldq, tid);
+    stage_commit(rk, ldsK, gk, S, dk, ldq, tid);
+    if constexpr (!stage_all_at_once<PCHQ, F32, SP>()) stage_issue(rv, gv, S, dv, ldv, tid);
+    stage_commit(rv, ldsV, gv, S, dv, ldv, tid);
+  }
   __syncthreads();
   const int dsteps = (dk + 31) / 32, nvb = (dv + 15) / 16;
 
-  for (int qb = wave; qb < NKB; qb += 4) {
+  for (int qb = wave; qb < NKB && qb * 16 < S; qb += 4) {     // blocks of padding queries produce nothing
     f32x4 acc[NKB];
     scores_T<NKB, PCHQ>(acc, ldsK, ldsQ, qb, dsteps, lane);
-    const int query = qb * 16 + fr;
-    float norm;
     if (kind == 0) {
-      float m = -3.0e38f;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int key = kb * 16 + g * 4 + j;
-          acc[kb][j] = (key < S) ? acc[kb][j] * scale : -3.0e38f;
-          m = fmaxf(m, acc[kb][j]);
-        }
-      m = group_max(m);
-      float l = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float p = (kb * 16 + g * 4 + j < S) ? __expf(acc[kb][j] - m) : 0.f;
-          acc[kb][j] = p;
-          l += p;
-        }
-      l = group_sum(l);
-      norm = 1.f / l;
-      if (g == 0 && query < S) stat[(size_t)bh * S + query] = m + __logf(l);
+      if (masked) fwd_probs<NKB, 0, true>(acc, stat, keep, seed_lo, seed_hi, thresh, S, bh, qb, lane, scale, keep_scale);
+      else fwd_probs<NKB, 0, false>(acc, stat, keep, seed_lo, seed_hi, thresh, S, bh, qb, lane, scale, keep_scale);
     } else {
-      float z = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float a = fmaxf(acc[kb][j] * scale, 0.f);     // padded keys have zero K rows -> a = 0
-          acc[kb][j] = a;
-          z += a;
-        }
-      z = group_sum(z) + AT_RELU_EPS;
-      norm = 1.f / z;
-      if (g == 0 && query < S) stat[(size_t)bh * S + query] = z;
-    }
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      uint32_t kw = 0x01010101u;
-      if (masked && query < S) {
-        const int key0 = kb * 16 + g * 4;
-        const size_t at = ((size_t)bh * S + query) * S + key0;        // element index in the [BH, S, S] mask
-        kw = 0u;
-        if (keep != nullptr) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (key0 + j < S) kw |= (uint32_t)keep[at + j] << (8 * j);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (key0 + j < S) kw |= (mt_rng_hash(seed_lo, seed_hi, (uint32_t)(at + j)) >= thresh ? 1u : 0u) << (8 * j);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float mk = ((kw >> (8 * j)) & 0xFFu) ? keep_scale : 0.f;
-        acc[kb][j] *= norm * (masked ? mk : 1.f);
-      }
+      if (masked) fwd_probs<NKB, 1, true>(acc, stat, keep, seed_lo, seed_hi, thresh, S, bh, qb, lane, scale, keep_scale);
+      else fwd_probs<NKB, 1, false>(acc, stat, keep, seed_lo, seed_hi, thresh, S, bh, qb, lane, scale, keep_scale);
     }
     // O = P . V with P straight from the accumulators
     for (int nb = 0; nb < nvb; ++nb) {
@@ -260,6 +354,64 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const void* __r
                                 seed != nullptr, seed_lo, seed_hi, thresh, blockIdx.x);
 }
 
+// Backward, one block of 16 queries: scores p and dP^T dp (both [key][query] accumulators) -> probabilities and dS^T in
+// dp; P^T (dropout applied) and dS^T go to LDS as bf16 for the two products that contract over queries.  KIND and
+// MASKED are compile-time for the same reason as in fwd_probs.
+template <int NKB, int PCH, int KIND, bool MASKED>
+__device__ __forceinline__ void bwd_block(f32x4 (&p)[NKB], f32x4 (&dp)[NKB], uint8_t* ldsPT, uint8_t* ldsST,
+                                          const float* __restrict__ stat, const uint8_t* __restrict__ keep,
+                                          uint32_t seed_lo, uint32_t seed_hi, uint32_t thresh, int S, int bh, int qb,
+                                          int lane, float scale, float keep_scale) {
+  const int g = lane >> 4, fr = lane & 15;
+  const int query = qb * 16 + fr;
+  const float st = (query < S) ? stat[(size_t)bh * S + query] : 1.f;
+  const float inv_z = (KIND == 1) ? 1.f / st : 0.f;
+  // where key row 4g + j keeps this query's element; key block kb is kb * 16 rows further (16 rows leave the swizzle as is)
+  int at_row[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) at_row[j] = img_off(g * 4 + j, query >> 3, PCH) + (query & 7) * 2;
+  constexpr int KB_STEP = 16 * PCH * 16;
+  float delta = 0.f;
+  uint32_t relu_pos = 0u;       // bit (kb*4 + j): pre-activation > 0 (kind 1)
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    uint32_t kw = 0x01010101u;
+    if constexpr (MASKED) {
+      if (query < S) {
+        const int key0 = kb * 16 + g * 4;
+        kw = keep_word(keep, seed_lo, seed_hi, thresh, ((size_t)bh * S + query) * S + key0, key0, S);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = kb * 16 + g * 4 + j;
+      const float s = p[kb][j] * scale;
+      float pv;
+      if constexpr (KIND == 0) pv = (key < S && query < S) ? __expf(s - st) : 0.f;
+      else { pv = fmaxf(s, 0.f) * inv_z; if (s > 0.f) relu_pos |= 1u << (kb * 4 + j); }
+      const float mk = MASKED ? (((kw >> (8 * j)) & 0xFFu) ? keep_scale : 0.f) : 1.f;
+      const float dpe = dp[kb][j] * mk;      // gradient w.r.t. the un-dropped probability
+      delta += dpe * pv;
+      p[kb][j] = pv;
+      dp[kb][j] = dpe;
+      // P^T with dropout applied feeds dV
+      *reinterpret_cast<uint16_t*>(ldsPT + at_row[j] + kb * KB_STEP) = (uint16_t)f32_to_bf16_bits(pv * mk);
+    }
+  }
+  delta = group_sum(delta);
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float ds;
+      if constexpr (KIND == 0) ds = p[kb][j] * (dp[kb][j] - delta) * scale;
+      else ds = ((relu_pos >> (kb * 4 + j)) & 1u) ? (dp[kb][j] - delta) * inv_z * scale : 0.f;
+      if (query >= S) ds = 0.f;
+      dp[kb][j] = ds;
+      *reinterpret_cast<uint16_t*>(ldsST + at_row[j] + kb * KB_STEP) = (uint16_t)f32_to_bf16_bits(ds);
+    }
+}
+
 template <int NKB, int PCHQ, bool F32>     // dQ, dK, dV are f32 and laid out like Q, K, V (same row strides)
 __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restrict__ Q_, const void* __restrict__ K_,
                                               const void* __restrict__ V_, const void* __restrict__ dO_,
@@ -279,71 +431,46 @@ __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restri
   const int g = lane >> 4, fr = lane & 15;
   constexpr int ES = F32 ? 4 : 2;
   const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
-  stage_image<PCHQ, F32>(ldsQ, reinterpret_cast<const uint8_t*>(Q_) + qoff * ES, S, dk, ldq, SP, tid);
-  stage_image<PCHQ, F32>(ldsK, reinterpret_cast<const uint8_t*>(K_) + qoff * ES, S, dk, ldq, SP, tid);
-  stage_image<PCHQ, F32>(ldsV, reinterpret_cast<const uint8_t*>(V_) + voff * ES, S, dv, ldv, SP, tid);
-  stage_image<PCHQ, F32>(ldsdO, reinterpret_cast<const uint8_t*>(dO_) + ooff * ES, S, dv, ldo, SP, tid);
+  {
+    const uint8_t* gq = reinterpret_cast<const uint8_t*>(Q_) + qoff * ES;
+    const uint8_t* gk = reinterpret_cast<const uint8_t*>(K_) + qoff * ES;
+    const uint8_t* gv = reinterpret_cast<const uint8_t*>(V_) + voff * ES;
+    const uint8_t* go = reinterpret_cast<const uint8_t*>(dO_) + ooff * ES;
+    StageRegs<PCHQ, F32, SP> rq, rk, rv, ro;
+    constexpr bool ALL = stage_all_at_once<PCHQ, F32, SP>();
+    stage_issue(rq, gq, S, dk, ldq, tid);
+    stage_issue(rk, gk, S, dk, ldq, tid);
+    if constexpr (ALL) { stage_issue(rv, gv, S, dv, ldv, tid); stage_issue(ro, go, S, dv, ldo, tid); }
+    stage_commit(rq, ldsQ, gq, S, dk, ldq, tid);
+    stage_commit(rk, ldsK, gk, S, dk, ldq, tid);
+    if constexpr (!ALL) { stage_issue(rv, gv, S, dv, ldv, tid); stage_issue(ro, go, S, dv, ldo, tid); }
+    stage_commit(rv, ldsV, gv, S, dv, ldv, tid);
+    stage_commit(ro, ldsdO, go, S, dv, ldo, tid);
+  }
   __syncthreads();
   const int dsteps = (dk + 31) / 32, vsteps = (dv + 31) / 32, nkd = (dk + 15) / 16, nvb = (dv + 15) / 16;
 
   // ---------------------------------------------------------------- query-parallel phase
   for (int qb = wave; qb < NKB; qb += 4) {
+    if (qb * 16 >= S) {      // a block of padding queries: its 32 bytes of every P^T and dS^T row are zero, nothing else
+      for (int idx = lane; idx < SP * 2; idx += 64) {
+        const int off = img_off(idx >> 1, qb * 2 + (idx & 1), PCH);
+        *reinterpret_cast<u32x4*>(ldsPT + off) = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(ldsST + off) = u32x4{0u, 0u, 0u, 0u};
+      }
+      continue;
+    }
     f32x4 p[NKB], dp[NKB];
     scores_T<NKB, PCHQ>(p, ldsK, ldsQ, qb, dsteps, lane);
     scores_T<NKB, PCHQ>(dp, ldsV, ldsdO, qb, vsteps, lane);     // dP^T[key][query] = V . dO^T, same layout
     const int query = qb * 16 + fr;
-    const float st = (query < S) ? stat[(size_t)bh * S + query] : 1.f;
-    const float inv_z = (kind == 1) ? 1.f / st : 0.f;
-    float delta = 0.f;
-    uint32_t relu_pos = 0u;       // bit (kb*4 + j): pre-activation > 0 (kind 1)
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      uint32_t kw = 0x01010101u;
-      if (masked && query < S) {
-        const int key0 = kb * 16 + g * 4;
-        const size_t at = ((size_t)bh * S + query) * S + key0;        // element index in the [BH, S, S] mask
-        kw = 0u;
-        if (keep != nullptr) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (key0 + j < S) kw |= (uint32_t)keep[at + j] << (8 * j);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (key0 + j < S) kw |= (mt_rng_hash(seed_lo, seed_hi, (uint32_t)(at + j)) >= thresh ? 1u : 0u) << (8 * j);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = kb * 16 + g * 4 + j;
-        const float s = p[kb][j] * scale;
-        float pv;
-        if (kind == 0) pv = (key < S && query < S) ? __expf(s - st) : 0.f;
-        else { pv = fmaxf(s, 0.f) * inv_z; if (s > 0.f) relu_pos |= 1u << (kb * 4 + j); }
-        const float mk = masked ? (((kw >> (8 * j)) & 0xFFu) ? keep_scale : 0.f) : 1.f;
-        const float dpe = dp[kb][j] * mk;      // gradient w.r.t. the un-dropped probability
-        delta += dpe * pv;
-        p[kb][j] = pv;
-        dp[kb][j] = dpe;
-        // P^T with dropout applied feeds dV
-        *reinterpret_cast<uint16_t*>(ldsPT + img_off(key, query >> 3, PCH) + (query & 7) * 2) =
-            (uint16_t)f32_to_bf16_bits(pv * mk);
-      }
+    if (kind == 0) {
+      if (masked) bwd_block<NKB, PCH, 0, true>(p, dp, ldsPT, ldsST, stat, keep, seed_lo, seed_hi, thresh, S, bh, qb, lane, scale, keep_scale);
+      else bwd_block<NKB, PCH, 0, false>(p, dp, ldsPT, ldsST, stat, keep, seed_lo, seed_hi, thresh, S, bh, qb, lane, scale, keep_scale);
+    } else {
+      if (masked) bwd_block<NKB, PCH, 1, true>(p, dp, ldsPT, ldsST, stat, keep, seed_lo, seed_hi, thresh, S, bh, qb, lane, scale, keep_scale);
+      else bwd_block<NKB, PCH, 1, false>(p, dp, ldsPT, ldsST, stat, keep, seed_lo, seed_hi, thresh, S, bh, qb, lane, scale, keep_scale);
     }
-    delta = group_sum(delta);
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = kb * 16 + g * 4 + j;
-        float ds;
-        if (kind == 0) ds = p[kb][j] * (dp[kb][j] - delta) * scale;
-        else ds = ((relu_pos >> (kb * 4 + j)) & 1u) ? (dp[kb][j] - delta) * inv_z * scale : 0.f;
-        if (query >= S) ds = 0.f;
-        dp[kb][j] = ds;
-        *reinterpret_cast<uint16_t*>(ldsST + img_off(key, query >> 3, PCH) + (query & 7) * 2) =
-            (uint16_t)f32_to_bf16_bits(ds);
-      }
     // dQ^T[d][query] = sum_key K[key][d] * dS[query][key]   (dS registers are the B operand)
     for (int db = 0; db < nkd; ++db) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -366,7 +493,7 @@ __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restri
   __syncthreads();
 
   // ---------------------------------------------------------------- key-parallel phase
-  for (int kb = wave; kb < NKB; kb += 4) {
+  for (int kb = wave; kb < NKB && kb * 16 < S; kb += 4) {
     for (int nb = 0; nb < nvb; ++nb) {       // dV[key][n] = sum_query P^T[key][query] dO[query][n]
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
