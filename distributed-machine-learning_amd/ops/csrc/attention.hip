@@ -723,18 +723,16 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_exact_kernel(const flo
 // ---------------------------------------------------------------------------------------------------------------
 // The same exact-f32 arithmetic for sequences of 33..128 tokens: K and V stay in LDS for the whole (batch, head), the
 // queries are walked in blocks of ATL_QB rows (their Q / dO rows and S-wide score rows are the only per-block images),
-// and in the backward pass every thread keeps the dK and dV elements it owns -- (key, column) pairs dealt round-robin --
-// in registers across the blocks.  Row pitches follow the head width (d + 1 floats) and the sequence (S + 1), so the
+// and in the backward pass every thread keeps the dK and dV elements it owns in registers across the blocks.  Row pitches follow the head width (d + 1 floats) and the sequence (S + 1), so the
 // images of a narrow head take a fraction of the LDS; the launcher passes the byte count as dynamic LDS.
 #define ATL_QB 32
 #define ATL_MAX_S 128
-#define ATL_OWN 32          // (key, column) pairs a thread owns at most: 128 keys x 64 columns / 256 threads
 
 static size_t atl_fwd_lds(int S, int dk, int dv) {
   return (size_t)(S * (dk + 1) + S * (dv + 1) + ATL_QB * (dk + 1) + ATL_QB * (S + 1)) * 4;
 }
 static size_t atl_bwd_lds(int S, int dk, int dv) {
-  return (size_t)(S * (dk + 1) + S * (dv + 1) + ATL_QB * (dk + 1) + ATL_QB * (dv + 1) + 3 * ATL_QB * (S + 1) + ATL_QB) * 4;
+  return (size_t)(S * (dk + 1) + S * (dv + 1) + ATL_QB * (dk + 1) + ATL_QB * (dv + 1) + 3 * ATL_QB * (S + 1)) * 4;
 }
 
 __device__ __forceinline__ void atl_stage(float* dst, int pitch, const float* __restrict__ src, int rows, int d, long ld,
@@ -745,153 +743,290 @@ __device__ __forceinline__ void atl_stage(float* dst, int pitch, const float* __
   }
 }
 
-__global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_exact_tiled_kernel(
-    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const uint8_t* __restrict__ keep,
-    float* __restrict__ O, float* __restrict__ stat, int S, int dk, int dv, float scale, float keep_scale, int kind, int H,
-    long ldq, long ldv, long ldo, const int64_t* __restrict__ seed, uint32_t thresh) {
-  extern __shared__ __attribute__((aligned(16))) float atl_lds[];
+// Register blocking: a thread forms a 4 x 4 block of dot products at a time (queries 4 * ib + r, keys jl + 32 * c with
+// jl = tid & 31, ib = tid >> 5), so one step of the contraction is 8 LDS reads for 16 multiply-adds instead of 32 for 16
+// -- LDS issue, not the ALUs, bounds these kernels.  Lanes walk consecutive keys (odd row pitch: every bank once) and
+// share their query rows (a broadcast).  Each dot product is still one fused-multiply-add chain in ascending index
+// order.  NC = key groups of 32 in use (ceil(S / 32)).
+template <int NC>
+__device__ __forceinline__ void atl_dots(float (&acc)[4][NC], const float* __restrict__ a, const int (&ai)[4],
+                                         const float* __restrict__ b, const int (&bj)[NC], int depth) {
+  for (int d = 0; d < depth; ++d) {
+    float av[4], bv[NC];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) av[r] = a[ai[r] + d];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) bv[c] = b[bj[c] + d];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[r][c] = fmaf(av[r], bv[c], acc[r][c]);
+  }
+}
+
+// out[i][n] = sum_j w[i][j] * m[j][n] for this thread's queries 4 * ib + r and columns jl + 32 * c (c < 2): per j four
+// broadcast reads of w and one or two reads of m for four or eight multiply-adds.
+__device__ __forceinline__ void atl_rows_times(float (&acc)[4][2], const float* __restrict__ w, const int (&wi)[4],
+                                               const float* __restrict__ m, int pitch, const int (&col)[2], bool two,
+                                               int S) {
+  for (int j = 0; j < S; ++j) {
+    float wv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wv[r] = w[wi[r] + j];
+    const float m0 = m[j * pitch + col[0]];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r][0] = fmaf(wv[r], m0, acc[r][0]);
+    if (two) {
+      const float m1 = m[j * pitch + col[1]];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r][1] = fmaf(wv[r], m1, acc[r][1]);
+    }
+  }
+}
+
+template <int NC>
+__device__ __forceinline__ void atl_fwd_body(
+    float* atl_lds, const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const uint8_t* __restrict__ keep, float* __restrict__ O, float* __restrict__ stat, int S, int dk, int dv, float scale,
+    float keep_scale, int kind, int H, long ldq, long ldv, long ldo, bool seeded, uint32_t s0, uint32_t s1, uint32_t thresh,
+    int bh) {
   const int pk = dk + 1, pv = dv + 1, ps = S + 1;
   float *k = atl_lds, *v = k + S * pk, *q = v + S * pv, *sc = q + ATL_QB * pk;
-  const int tid = threadIdx.x, bh = blockIdx.x;
-  const bool seeded = seed != nullptr;
-  uint32_t s0 = 0u, s1 = 0u;
-  if (seeded) { const uint64_t sv = (uint64_t)seed[0]; s0 = (uint32_t)sv; s1 = (uint32_t)(sv >> 32); }
+  const int tid = threadIdx.x;
+  const int jl = tid & 31, ib = tid >> 5;
   const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
   atl_stage(k, pk, K + qoff, S, dk, ldq, tid);
   atl_stage(v, pv, V + voff, S, dv, ldv, tid);
+  int kj[NC], vcol[2];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) kj[c] = ((jl + 32 * c < S) ? jl + 32 * c : S - 1) * pk;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) vcol[c] = (jl + 32 * c < dv) ? jl + 32 * c : dv - 1;
   for (int q0 = 0; q0 < S; q0 += ATL_QB) {
     const int nq = (S - q0 < ATL_QB) ? S - q0 : ATL_QB;
     __syncthreads();                      // K / V staged; the previous block's images are free
     atl_stage(q, pk, Q + qoff + (size_t)q0 * ldq, nq, dk, ldq, tid);
     __syncthreads();
-    for (int p = tid; p < nq * S; p += AT_THREADS) {
-      const int i = p / S, j = p - i * S;
-      float acc = 0.f;
-      for (int d = 0; d < dk; ++d) acc = fmaf(q[i * pk + d], k[j * pk + d], acc);
-      sc[i * ps + j] = acc * scale;
+    int qi[4], si[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (ib * 4 + r < nq) ? ib * 4 + r : nq - 1;
+      qi[r] = i * pk;
+      si[r] = i * ps;
+    }
+    if (ib * 4 < nq) {
+      float acc[4][NC] = {};
+      atl_dots<NC>(acc, q, qi, k, kj, dk);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          if (ib * 4 + r < nq && jl + 32 * c < S) sc[(ib * 4 + r) * ps + jl + 32 * c] = acc[r][c] * scale;
     }
     __syncthreads();
-    if (tid < nq) {
-      float* row = sc + tid * ps;
-      const int qi = q0 + tid;
+    {   // row pass: eight lanes per query row, each every eighth key; maxima and sums meet in a fixed xor tree
+      const int row = tid >> 3, sub = tid & 7;
+      const bool live = row < nq;
+      float* rp = sc + (live ? row : 0) * ps;
+      const int qi_g = q0 + row;
       float norm;
       if (kind == 0) {
-        float m = row[0];
-        for (int j = 1; j < S; ++j) m = fmaxf(m, row[j]);
+        float m = -3.0e38f;
+        for (int j = sub; j < S; j += 8) m = fmaxf(m, rp[j]);
+        m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
         float l = 0.f;
-        for (int j = 0; j < S; ++j) { const float e = expf(row[j] - m); row[j] = e; l += e; }
+        for (int j = sub; j < S; j += 8) { const float e = expf(rp[j] - m); if (live) rp[j] = e; l += e; }
+        l += __shfl_xor(l, 1, 64); l += __shfl_xor(l, 2, 64); l += __shfl_xor(l, 4, 64);
         norm = 1.f / l;
-        stat[(size_t)bh * S + qi] = m + logf(l);
+        if (live && sub == 0) stat[(size_t)bh * S + qi_g] = m + logf(l);
       } else {
         float z = 0.f;
-        for (int j = 0; j < S; ++j) { const float a = fmaxf(row[j], 0.f); row[j] = a; z += a; }
+        for (int j = sub; j < S; j += 8) { const float a = fmaxf(rp[j], 0.f); if (live) rp[j] = a; z += a; }
+        z += __shfl_xor(z, 1, 64); z += __shfl_xor(z, 2, 64); z += __shfl_xor(z, 4, 64);
         z += AT_RELU_EPS;
         norm = 1.f / z;
-        stat[(size_t)bh * S + qi] = z;
+        if (live && sub == 0) stat[(size_t)bh * S + qi_g] = z;
       }
-      const size_t at = ((size_t)bh * S + qi) * S;
-      for (int j = 0; j < S; ++j) row[j] = row[j] * norm * atx_keep(keep, seeded, s0, s1, thresh, at + j, keep_scale);
+      if (live) {
+        const size_t at = ((size_t)bh * S + qi_g) * S;
+        for (int j = sub; j < S; j += 8) rp[j] = rp[j] * norm * atx_keep(keep, seeded, s0, s1, thresh, at + j, keep_scale);
+      }
     }
     __syncthreads();
-    for (int p = tid; p < nq * dv; p += AT_THREADS) {
-      const int i = p / dv, n = p - i * dv;
-      float acc = 0.f;
-      for (int j = 0; j < S; ++j) acc = fmaf(sc[i * ps + j], v[j * pv + n], acc);
-      O[ooff + (size_t)(q0 + i) * ldo + n] = acc;
+    if (ib * 4 < nq && jl < dv) {
+      float acc[4][2] = {};
+      atl_rows_times(acc, sc, si, v, pv, vcol, jl + 32 < dv, S);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          if (ib * 4 + r < nq && jl + 32 * c < dv) O[ooff + (size_t)(q0 + ib * 4 + r) * ldo + jl + 32 * c] = acc[r][c];
     }
   }
 }
 
-__global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_exact_tiled_kernel(
-    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
-    const uint8_t* __restrict__ keep, const float* __restrict__ stat, float* __restrict__ dQ, float* __restrict__ dK,
-    float* __restrict__ dV, int S, int dk, int dv, float scale, float keep_scale, int kind, int H, long ldq, long ldv,
-    long ldo, const int64_t* __restrict__ seed, uint32_t thresh) {
+template <int NC>
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_exact_tiled_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const uint8_t* __restrict__ keep,
+    float* __restrict__ O, float* __restrict__ stat, int S, int dk, int dv, float scale, float keep_scale, int kind, int H,
+    long ldq, long ldv, long ldo, const int64_t* __restrict__ seed, uint32_t thresh) {
   extern __shared__ __attribute__((aligned(16))) float atl_lds[];
+  uint32_t s0 = 0u, s1 = 0u;
+  if (seed != nullptr) { const uint64_t sv = (uint64_t)seed[0]; s0 = (uint32_t)sv; s1 = (uint32_t)(sv >> 32); }
+  atl_fwd_body<NC>(atl_lds, Q, K, V, keep, O, stat, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo, seed != nullptr, s0,
+                   s1, thresh, blockIdx.x);
+}
+
+template <int NC>
+__device__ __forceinline__ void atl_bwd_body(
+    float* atl_lds, const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ dO, const uint8_t* __restrict__ keep, const float* __restrict__ stat, float* __restrict__ dQ,
+    float* __restrict__ dK, float* __restrict__ dV, int S, int dk, int dv, float scale, float keep_scale, int kind, int H,
+    long ldq, long ldv, long ldo, bool seeded, uint32_t s0, uint32_t s1, uint32_t thresh, int bh) {
   const int pk = dk + 1, pv = dv + 1, ps = S + 1;
   float *k = atl_lds, *v = k + S * pk, *q = v + S * pv, *go = q + ATL_QB * pk;
-  float *pr = go + ATL_QB * pv, *ds = pr + ATL_QB * ps, *pm = ds + ATL_QB * ps, *delta = pm + ATL_QB * ps;
-  const int tid = threadIdx.x, bh = blockIdx.x;
-  const bool seeded = seed != nullptr;
-  uint32_t s0 = 0u, s1 = 0u;
-  if (seeded) { const uint64_t sv = (uint64_t)seed[0]; s0 = (uint32_t)sv; s1 = (uint32_t)(sv >> 32); }
+  float *pr = go + ATL_QB * pv, *ds = pr + ATL_QB * ps, *pm = ds + ATL_QB * ps;
+  const int tid = threadIdx.x;
+  const int jl = tid & 31, ib = tid >> 5;
   const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
   atl_stage(k, pk, K + qoff, S, dk, ldq, tid);
   atl_stage(v, pv, V + voff, S, dv, ldv, tid);
-  float acck[ATL_OWN], accv[ATL_OWN];      // dK / dV of the pairs p = tid + 256 * t, summed over the query blocks in order
+  // dK / dV: a thread owns keys jl + 32 * c (c < NC) x columns ib + 8 * e (e < 8) -- up to 128 keys x 64 columns over 256
+  // threads -- and sums them over the query blocks in order, in registers
+  float acck[NC][8], accv[NC][8];
 #pragma unroll
-  for (int t = 0; t < ATL_OWN; ++t) { acck[t] = 0.f; accv[t] = 0.f; }
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { acck[c][e] = 0.f; accv[c][e] = 0.f; }
+  int kj[NC], vj[NC], sj[NC], kcol[2];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int j = (jl + 32 * c < S) ? jl + 32 * c : S - 1;
+    kj[c] = j * pk;
+    vj[c] = j * pv;
+    sj[c] = j;
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) kcol[c] = (jl + 32 * c < dk) ? jl + 32 * c : dk - 1;
   for (int q0 = 0; q0 < S; q0 += ATL_QB) {
     const int nq = (S - q0 < ATL_QB) ? S - q0 : ATL_QB;
     __syncthreads();
     atl_stage(q, pk, Q + qoff + (size_t)q0 * ldq, nq, dk, ldq, tid);
     atl_stage(go, pv, dO + ooff + (size_t)q0 * ldo, nq, dv, ldo, tid);
     __syncthreads();
-    for (int p = tid; p < nq * S; p += AT_THREADS) {
-      const int i = p / S, j = p - i * S, qi = q0 + i;
-      float s = 0.f, dp = 0.f;
-      for (int d = 0; d < dk; ++d) s = fmaf(q[i * pk + d], k[j * pk + d], s);
-      for (int n = 0; n < dv; ++n) dp = fmaf(go[i * pv + n], v[j * pv + n], dp);
-      s *= scale;
-      const float st = stat[(size_t)bh * S + qi];
-      const float pval = (kind == 0) ? expf(s - st) : fmaxf(s, 0.f) / st;
-      const float mk = atx_keep(keep, seeded, s0, s1, thresh, ((size_t)bh * S + qi) * S + j, keep_scale);
-      pr[i * ps + j] = pval;
-      ds[i * ps + j] = dp * mk;
-      pm[i * ps + j] = pval * mk;
-    }
-    __syncthreads();
-    if (tid < nq) {
-      float a = 0.f;
-      for (int j = 0; j < S; ++j) a = fmaf(ds[tid * ps + j], pr[tid * ps + j], a);
-      delta[tid] = a;
-    }
-    __syncthreads();
-    for (int p = tid; p < nq * S; p += AT_THREADS) {
-      const int i = p / S, j = p - i * S;
-      const float pval = pr[i * ps + j], g = ds[i * ps + j] - delta[i];
-      float r;
-      if (kind == 0) r = pval * g * scale;
-      else r = (pval > 0.f) ? g * (1.f / stat[(size_t)bh * S + q0 + i]) * scale : 0.f;
-      ds[i * ps + j] = r;
-    }
-    __syncthreads();
-    for (int p = tid; p < nq * dk; p += AT_THREADS) {       // dQ rows of this block
-      const int i = p / dk, d = p - i * dk;
-      float a = 0.f;
-      for (int j = 0; j < S; ++j) a = fmaf(ds[i * ps + j], k[j * pk + d], a);
-      dQ[qoff + (size_t)(q0 + i) * ldq + d] = a;
-    }
+    int qi[4], gi[4], si[4];
 #pragma unroll
-    for (int t = 0; t < ATL_OWN; ++t) {                     // this block's share of dK = dS^T . Q and dV = (dropped P)^T . dO
-      const int p = tid + AT_THREADS * t;
-      if (p < S * dk) {
-        const int j = p / dk, d = p - j * dk;
-        float a = acck[t];
-        for (int i = 0; i < nq; ++i) a = fmaf(ds[i * ps + j], q[i * pk + d], a);
-        acck[t] = a;
+    for (int r = 0; r < 4; ++r) {
+      const int i = (ib * 4 + r < nq) ? ib * 4 + r : nq - 1;
+      qi[r] = i * pk;
+      gi[r] = i * pv;
+      si[r] = i * ps;
+    }
+    if (ib * 4 < nq) {
+      float as[4][NC] = {}, ad[4][NC] = {};
+      atl_dots<NC>(as, q, qi, k, kj, dk);
+      atl_dots<NC>(ad, go, gi, v, vj, dv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ib * 4 + r, qg = q0 + i;
+        if (i < nq) {
+          const float st = stat[(size_t)bh * S + qg];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int j = jl + 32 * c;
+            if (j < S) {
+              const float sv = as[r][c] * scale;
+              const float pval = (kind == 0) ? expf(sv - st) : fmaxf(sv, 0.f) / st;
+              const float mk = atx_keep(keep, seeded, s0, s1, thresh, ((size_t)bh * S + qg) * S + j, keep_scale);
+              pr[i * ps + j] = pval;
+              ds[i * ps + j] = ad[r][c] * mk;
+              pm[i * ps + j] = pval * mk;
+            }
+          }
+        }
       }
-      if (p < S * dv) {
-        const int j = p / dv, n = p - j * dv;
-        float a = accv[t];
-        for (int i = 0; i < nq; ++i) a = fmaf(pm[i * ps + j], go[i * pv + n], a);
-        accv[t] = a;
+    }
+    __syncthreads();
+    {   // row pass, eight lanes per query row: delta = sum_j dP * P (partial sums meet in a fixed xor tree), then dS in
+        // place -- the lanes that read a row are the ones that overwrite it, so no barrier in between
+      const int row = tid >> 3, sub = tid & 7;
+      const bool live = row < nq;
+      const int ro = (live ? row : 0) * ps;
+      float a = 0.f;
+      for (int j = sub; j < S; j += 8) a = fmaf(ds[ro + j], pr[ro + j], a);
+      a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+      if (live) {
+        const float inv = (kind == 0) ? 0.f : 1.f / stat[(size_t)bh * S + q0 + row];
+        for (int j = sub; j < S; j += 8) {
+          const float pval = pr[ro + j], g = ds[ro + j] - a;
+          ds[ro + j] = (kind == 0) ? pval * g * scale : ((pval > 0.f) ? g * inv * scale : 0.f);
+        }
+      }
+    }
+    __syncthreads();
+    if (ib * 4 < nq && jl < dk) {                            // dQ rows of this block
+      float acc[4][2] = {};
+      atl_rows_times(acc, ds, si, k, pk, kcol, jl + 32 < dk, S);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          if (ib * 4 + r < nq && jl + 32 * c < dk) dQ[qoff + (size_t)(q0 + ib * 4 + r) * ldq + jl + 32 * c] = acc[r][c];
+    }
+    // this block's share of dK = dS^T . Q and dV = (dropped P)^T . dO: per query 4 + 4 reads along the keys and up to
+    // 8 + 8 broadcast reads along the columns for up to 64 multiply-adds
+    for (int i = 0; i < nq; ++i) {
+      float dsv[NC], pmv[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { dsv[c] = ds[i * ps + sj[c]]; pmv[c] = pm[i * ps + sj[c]]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (e * 8 < dk) {
+          const float qv = q[i * pk + ((ib + 8 * e < dk) ? ib + 8 * e : dk - 1)];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acck[c][e] = fmaf(dsv[c], qv, acck[c][e]);
+        }
+        if (e * 8 < dv) {
+          const float gv = go[i * pv + ((ib + 8 * e < dv) ? ib + 8 * e : dv - 1)];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) accv[c][e] = fmaf(pmv[c], gv, accv[c][e]);
+        }
       }
     }
   }
 #pragma unroll
-  for (int t = 0; t < ATL_OWN; ++t) {
-    const int p = tid + AT_THREADS * t;
-    if (p < S * dk) { const int j = p / dk, d = p - j * dk; dK[qoff + (size_t)j * ldq + d] = acck[t]; }
-    if (p < S * dv) { const int j = p / dv, n = p - j * dv; dV[voff + (size_t)j * ldv + n] = accv[t]; }
+  for (int c = 0; c < NC; ++c) {
+    const int j = jl + 32 * c;
+    if (j < S) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = ib + 8 * e;
+        if (col < dk) dK[qoff + (size_t)j * ldq + col] = acck[c][e];
+        if (col < dv) dV[voff + (size_t)j * ldv + col] = accv[c][e];
+      }
+    }
   }
 }
 
-// MITUNE_ATTN_EXACT: 0 = f32 operands always go through the matrix form (rounded to bf16); 1 (default) = sequences of up
-// to 32 tokens run the exact-f32 form; 2 = so do sequences of up to 128 tokens (heads of up to 64 elements), tiled.
+template <int NC>
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_exact_tiled_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
+    const uint8_t* __restrict__ keep, const float* __restrict__ stat, float* __restrict__ dQ, float* __restrict__ dK,
+    float* __restrict__ dV, int S, int dk, int dv, float scale, float keep_scale, int kind, int H, long ldq, long ldv,
+    long ldo, const int64_t* __restrict__ seed, uint32_t thresh) {
+  extern __shared__ __attribute__((aligned(16))) float atl_lds[];
+  uint32_t s0 = 0u, s1 = 0u;
+  if (seed != nullptr) { const uint64_t sv = (uint64_t)seed[0]; s0 = (uint32_t)sv; s1 = (uint32_t)(sv >> 32); }
+  atl_bwd_body<NC>(atl_lds, Q, K, V, dO, keep, stat, dQ, dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo,
+                   seed != nullptr, s0, s1, thresh, blockIdx.x);
+}
+
+// MITUNE_ATTN_EXACT: 0 = f32 operands always go through the matrix form (rounded to bf16); 1 = sequences of up to 32
+// tokens run the exact-f32 form; 2 (default) = so do sequences of up to 128 tokens, tiled (heads of up to 64 elements in
+// both; wider heads keep the matrix form).  f32 models therefore multiply in f32 unless told otherwise.
 static int at_level = -1;
 static int at_exact_level() {
-  if (at_level < 0) { const char* e = getenv("MITUNE_ATTN_EXACT"); at_level = e ? atoi(e) : 1; }
+  if (at_level < 0) { const char* e = getenv("MITUNE_ATTN_EXACT"); at_level = e ? atoi(e) : 2; }
   return at_level;
 }
 extern "C" int mt_attn_exact_level(int set) {      // set >= 0 replaces the level; returns the one in force before
@@ -899,6 +1034,8 @@ extern "C" int mt_attn_exact_level(int set) {      // set >= 0 replaces the leve
   if (set >= 0) at_level = set;
   return was;
 }
+// key groups of 32 a sequence of 33..128 tokens spans: the tiled kernels are compiled for 2, 3 and 4
+#define ATL_NC(LAUNCH, S) do { if ((S) <= 64) LAUNCH(2); else if ((S) <= 96) LAUNCH(3); else LAUNCH(4); } while (0)
 static bool atl_fits(int S, int dk, int dv) {
   return at_exact_level() >= 2 && S > ATX_MAX_S && S <= ATL_MAX_S && dk <= ATX_MAX_D && dv <= ATX_MAX_D;
 }
@@ -1004,6 +1141,45 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_exact_kernel(c
                       a.thresh, blockIdx.x);
 }
 
+// Sequences of 33..128 tokens, exact f32: the tiled bodies, dynamic LDS sized by the launcher for the widest head.
+template <int NC>
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_grouped_tiled_kernel(const MtAttnSlot* __restrict__ slots,
+                                                                               const int32_t* __restrict__ ids, int S,
+                                                                               int step_imm, int b_override, int train,
+                                                                               const int* __restrict__ step_base) {
+  extern __shared__ __attribute__((aligned(16))) float atl_lds[];
+  const int step = mt_step(step_imm, step_base);
+  const MtAttnSlot a = slots[ids[blockIdx.y]];
+  if (step >= a.active_steps) return;
+  const int B = b_override > 0 ? b_override : a.B;
+  if ((int)blockIdx.x >= B * a.H) return;
+  const int d = a.H * a.dk;
+  const bool seeded = train && a.thresh != 0u && a.seed != nullptr;
+  uint32_t s0 = 0u, s1 = 0u;
+  if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
+  atl_fwd_body<NC>(atl_lds, a.qkv, a.qkv + d, a.qkv + 2 * d, nullptr, a.o, a.stat, S, a.dk, a.dk, a.scale,
+                   seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1, a.thresh, blockIdx.x);
+}
+
+template <int NC>
+__global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_tiled_kernel(const MtAttnSlot* __restrict__ slots,
+                                                                               const int32_t* __restrict__ ids, int S,
+                                                                               int step_imm,
+                                                                               const int* __restrict__ step_base) {
+  extern __shared__ __attribute__((aligned(16))) float atl_lds[];
+  const int step = mt_step(step_imm, step_base);
+  const MtAttnSlot a = slots[ids[blockIdx.y]];
+  if (step >= a.active_steps) return;
+  if ((int)blockIdx.x >= a.B * a.H) return;
+  const int d = a.H * a.dk;
+  const bool seeded = a.thresh != 0u && a.seed != nullptr;
+  uint32_t s0 = 0u, s1 = 0u;
+  if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
+  atl_bwd_body<NC>(atl_lds, a.qkv, a.qkv + d, a.qkv + 2 * d, a.d_o, nullptr, a.stat, a.dqkv, a.dqkv + d, a.dqkv + 2 * d, S,
+                   a.dk, a.dk, a.scale, seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1, a.thresh,
+                   blockIdx.x);
+}
+
 extern "C" int mt_attn_slot_sizeof() { return (int)sizeof(MtAttnSlot); }
 
 static int nkb_for(int S) { return ((S + 31) / 32) * 2; }   // pad the sequence to a multiple of 32
@@ -1037,11 +1213,16 @@ extern "C" int mt_attn_fwd_strided_launch(const void* Q, const void* K, const vo
   }
   if (f32 && atl_fits(S, dk, dv)) {
     const size_t bytes = atl_fwd_lds(S, dk, dv);
-    const int rc2 = atl_prepare((const void*)mt_attn_fwd_exact_tiled_kernel, bytes);
-    if (rc2) return rc2;
-    hipLaunchKernelGGL(mt_attn_fwd_exact_tiled_kernel, grid, block, bytes, stream, (const float*)Q, (const float*)K,
-                       (const float*)V, (const uint8_t*)keep, (float*)O, stat, S, dk, dv, scale, keep_scale, kind, H, ldq,
-                       ldv, ldo, seed, thresh);
+#define ATL_F(NC)                                                                                                     \
+  do {                                                                                                                \
+    const int rc2 = atl_prepare((const void*)mt_attn_fwd_exact_tiled_kernel<NC>, bytes);                              \
+    if (rc2) return rc2;                                                                                              \
+    hipLaunchKernelGGL(mt_attn_fwd_exact_tiled_kernel<NC>, grid, block, bytes, stream, (const float*)Q, (const float*)K, \
+                       (const float*)V, (const uint8_t*)keep, (float*)O, stat, S, dk, dv, scale, keep_scale, kind, H, ldq, \
+                       ldv, ldo, seed, thresh);                                                                       \
+  } while (0)
+    ATL_NC(ATL_F, S);
+#undef ATL_F
     return (int)hipGetLastError();
   }
   const bool narrow = dk <= 32 && dv <= 32;
@@ -1082,11 +1263,16 @@ extern "C" int mt_attn_bwd_strided_launch(const void* Q, const void* K, const vo
   }
   if (f32 && atl_fits(S, dk, dv)) {
     const size_t bytes = atl_bwd_lds(S, dk, dv);
-    const int rc2 = atl_prepare((const void*)mt_attn_bwd_exact_tiled_kernel, bytes);
-    if (rc2) return rc2;
-    hipLaunchKernelGGL(mt_attn_bwd_exact_tiled_kernel, grid, block, bytes, stream, (const float*)Q, (const float*)K,
-                       (const float*)V, (const float*)dO, (const uint8_t*)keep, stat, dQ, dK, dV, S, dk, dv, scale, keep_scale,
-                       kind, H, ldq, ldv, ldo, seed, thresh);
+#define ATL_B(NC)                                                                                                     \
+  do {                                                                                                                \
+    const int rc2 = atl_prepare((const void*)mt_attn_bwd_exact_tiled_kernel<NC>, bytes);                              \
+    if (rc2) return rc2;                                                                                              \
+    hipLaunchKernelGGL(mt_attn_bwd_exact_tiled_kernel<NC>, grid, block, bytes, stream, (const float*)Q, (const float*)K, \
+                       (const float*)V, (const float*)dO, (const uint8_t*)keep, stat, dQ, dK, dV, S, dk, dv, scale,    \
+                       keep_scale, kind, H, ldq, ldv, ldo, seed, thresh);                                             \
+  } while (0)
+    ATL_NC(ATL_B, S);
+#undef ATL_B
     return (int)hipGetLastError();
   }
   const bool narrow = dk <= 32 && dv <= 32;
@@ -1135,6 +1321,20 @@ extern "C" int mt_attn_fwd_grouped_launch(const MtAttnSlot* slots, const int32_t
                        mt_step_base_tls);
     return (int)hipGetLastError();
   }
+  if (at_exact_level() >= 2) {                // heads of up to 32 (or, wide, 64) elements
+    const int dmax = wide ? 64 : 32;
+    const size_t bytes = atl_fwd_lds(S, dmax, dmax);
+#define ATL_GF(NC)                                                                                                    \
+  do {                                                                                                                \
+    const int rc2 = atl_prepare((const void*)mt_attn_fwd_grouped_tiled_kernel<NC>, bytes);                            \
+    if (rc2) return rc2;                                                                                              \
+    hipLaunchKernelGGL(mt_attn_fwd_grouped_tiled_kernel<NC>, grid, block, bytes, stream, slots, ids, S, step, b_override, \
+                       train, mt_step_base_tls);                                                                      \
+  } while (0)
+    ATL_NC(ATL_GF, S);
+#undef ATL_GF
+    return (int)hipGetLastError();
+  }
 #define AT_GF(N, P) hipLaunchKernelGGL((mt_attn_fwd_grouped_kernel<N, P>), grid, block, 0, stream, slots, ids, S, step, \
                                        b_override, train, mt_step_base_tls)
 #define AT_GFW(N) do { if (wide) AT_GF(N, 8); else AT_GF(N, 4); } while (0)
@@ -1157,6 +1357,20 @@ extern "C" int mt_attn_bwd_grouped_launch(const MtAttnSlot* slots, const int32_t
   dim3 grid(max_bh, n_active), block(AT_THREADS);
   if (at_exact_on() && S <= ATX_MAX_S) {
     hipLaunchKernelGGL(mt_attn_bwd_grouped_exact_kernel, grid, block, 0, stream, slots, ids, S, step, mt_step_base_tls);
+    return (int)hipGetLastError();
+  }
+  if (at_exact_level() >= 2) {
+    const int dmax = wide ? 64 : 32;
+    const size_t bytes = atl_bwd_lds(S, dmax, dmax);
+#define ATL_GB(NC)                                                                                                    \
+  do {                                                                                                                \
+    const int rc2 = atl_prepare((const void*)mt_attn_bwd_grouped_tiled_kernel<NC>, bytes);                            \
+    if (rc2) return rc2;                                                                                              \
+    hipLaunchKernelGGL(mt_attn_bwd_grouped_tiled_kernel<NC>, grid, block, bytes, stream, slots, ids, S, step,         \
+                       mt_step_base_tls);                                                                             \
+  } while (0)
+    ATL_NC(ATL_GB, S);
+#undef ATL_GB
     return (int)hipGetLastError();
   }
 #define AT_GB(N, P) hipLaunchKernelGGL((mt_attn_bwd_grouped_kernel<N, P>), grid, block, 0, stream, slots, ids, S, step, \

@@ -15,8 +15,9 @@ buffers that are reused layer after layer.  Nothing is allocated after construct
 Contract shared with the other engines (checked in tests against ``TorchPackEngine``): initial weights of a trial come
 from the trial's own seeded stream, batches from the keyed permutation of (seed, trial, epoch), an epoch is
 ``N // batch`` steps, validation metrics are sample-weighted sums over the whole validation set.  Arithmetic is f32
-throughout (exact-f32 MFMA for the dense layers); the fused attention kernel rounds its Q/K/V operands to bf16 and
-accumulates in f32, as it does for one-trial-at-a-time training.
+throughout: exact-f32 MFMA for the dense layers, f32 multiply-add chains in the attention kernels for sequences of up to
+128 tokens (the same kernels one-trial-at-a-time training uses; ``MITUNE_ATTN_EXACT=0`` or ``1`` selects the bf16
+matrix form for all, or for the longer, sequences instead).
 """
 from __future__ import annotations
 

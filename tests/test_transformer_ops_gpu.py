@@ -104,25 +104,39 @@ def test_transformer_models_run_on_the_fused_kernels():
                                               (2, 33, 3, 6, 20, 0.2), (2, 96, 4, 2, 4, 0.0),
                                               # ... and wider than 64 (256-byte image rows, S <= 96)
                                               (2, 96, 2, 96, 96, 0.1), (2, 64, 2, 128, 128, 0.0), (3, 50, 2, 40, 80, 0.0)])
-def test_strided_self_attention_on_projection_outputs(B, S, h, dk, dv, drop, kind, dtype):
-    """The kernels read Q and K in place from one [B, S, 2*h*dk] tensor and V / O as [B, S, h*dv]."""
+@pytest.mark.parametrize("level", [0, 2])
+def test_strided_self_attention_on_projection_outputs(B, S, h, dk, dv, drop, kind, dtype, level):
+    """The kernels read Q and K in place from one [B, S, 2*h*dk] tensor and V / O as [B, S, h*dv].  Level 0 sends f32
+    operands through the matrix form too (what heads wider than 64 elements always get), level 2 is the default."""
+    from mitune.ops import lib as L
     from mitune.ops.attention import attention_reference
     from mitune.ops.attention_hip import FusedSelfAttention
+    if level == 0 and dtype == torch.bfloat16:
+        pytest.skip("the level only concerns f32 operands")
     g = torch.Generator(device="cuda").manual_seed(3)
     qk = torch.randn(B, S, 2 * h * dk, device="cuda", generator=g).to(dtype).requires_grad_()
     v = torch.randn(B, S, h * dv, device="cuda", generator=g).to(dtype).requires_grad_()
     keep = (torch.rand(B, h, S, S, device="cuda", generator=g) >= drop).to(torch.uint8) if drop > 0 else None
     do = torch.randn(B, S, h * dv, device="cuda", generator=g).to(dtype)
-    out = FusedSelfAttention.apply(qk, v, h, kind, keep, drop)
-    out.backward(do)
+    so = L.load()
+    was = so.mt_attn_exact_level(level)
+    try:
+        out = FusedSelfAttention.apply(qk, v, h, kind, keep, drop)
+        out.backward(do)
+        torch.cuda.synchronize()
+    finally:
+        so.mt_attn_exact_level(was)
     got = (out.float().detach(), qk.grad.float().clone(), v.grad.float().clone())
-    # reference on the bf16-rounded operands the kernel multiplies, in f32
-    qr = qk.detach().bfloat16().float().requires_grad_()
-    vr = v.detach().bfloat16().float().requires_grad_()
+    # reference in f32 on the operands the kernel multiplies: rounded to bf16 in the matrix form, as they are in the
+    # exact form (f32 operands, heads of at most 64 elements, level 2)
+    exact = dtype == torch.float32 and level == 2 and dk <= 64 and dv <= 64
+    rnd = (lambda t: t) if exact else (lambda t: t.bfloat16().float())          # noqa: E731
+    qr = rnd(qk.detach()).requires_grad_()
+    vr = rnd(v.detach()).requires_grad_()
     q, k = qr.chunk(2, dim=-1)
     sp = lambda t, d: t.reshape(B, S, h, d).transpose(1, 2)          # noqa: E731
     ref = attention_reference(sp(q, dk), sp(k, dk), sp(vr, dv), kind, keep, drop).transpose(1, 2).reshape(B, S, h * dv)
-    ref.backward(do.bfloat16().float())
+    ref.backward(rnd(do))
     tol = 3e-2 if dtype == torch.bfloat16 else 2e-2
     for a, r, name in zip(got, (ref.detach(), qr.grad, vr.grad), ("out", "dqk", "dv")):
         assert torch.allclose(a, r, rtol=tol, atol=tol * max(1.0, r.abs().max().item())), name
