@@ -563,10 +563,50 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const void* __r
 #define ATX_FWD_LDS ((3 * ATX_MAX_S * ATX_PD + ATX_MAX_S * ATX_PS) * 4)
 #define ATX_BWD_LDS ((4 * ATX_MAX_S * ATX_PD + 3 * ATX_MAX_S * ATX_PS + ATX_MAX_S) * 4)
 
-__device__ __forceinline__ void atx_stage(float* dst, const float* __restrict__ src, int S, int d, long ld, int tid) {
-  for (int q = tid; q < S * d; q += AT_THREADS) {
-    const int r = q / d, c = q - r * d;
-    dst[r * ATX_PD + c] = src[(size_t)r * ld + c];
+// Two-phase staging of an f32 [rows][d] block (row stride ld) into LDS rows of `pitch` floats: ax_issue requests up to
+// NV 16-byte pieces per thread, ax_commit writes them.  Issuing all operands of a workgroup before committing any puts
+// their global-memory latencies on top of each other; a loop that loads and stores piece by piece pays them one after
+// the other, and these kernels do little else.  Blocks whose rows cannot be read as aligned vectors are copied element
+// by element in ax_commit.
+template <int NV>
+struct AxRegs { f32x4 v[NV]; bool vec; };
+
+template <int NV>
+__device__ __forceinline__ void ax_issue(AxRegs<NV>& b, const float* __restrict__ src, int rows, int d, long ld, int tid) {
+  b.vec = ((d & 3) == 0) && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
+          rows * (d >> 2) <= NV * AT_THREADS;
+  if (!b.vec) return;
+  const int dq = d >> 2, n = rows * dq;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int q = tid + u * AT_THREADS;
+    b.v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q < n) {
+      const int r = q / dq, c = q - r * dq;
+      b.v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)r * ld + c * 4);
+    }
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ void ax_commit(const AxRegs<NV>& b, float* dst, int pitch, const float* __restrict__ src, int rows,
+                                          int d, long ld, int tid) {
+  if (!b.vec) {
+    for (int q = tid; q < rows * d; q += AT_THREADS) {
+      const int r = q / d, c = q - r * d;
+      dst[r * pitch + c] = src[(size_t)r * ld + c];
+    }
+    return;
+  }
+  const int dq = d >> 2, n = rows * dq;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int q = tid + u * AT_THREADS;
+    if (q < n) {
+      const int r = q / dq, c = q - r * dq;
+      float* o = dst + r * pitch + c * 4;
+      o[0] = b.v[u][0]; o[1] = b.v[u][1]; o[2] = b.v[u][2]; o[3] = b.v[u][3];
+    }
   }
 }
 
@@ -586,9 +626,15 @@ __device__ __forceinline__ void attn_fwd_exact_body(float* lds, const float* __r
   float *q = lds, *k = q + ATX_MAX_S * ATX_PD, *v = k + ATX_MAX_S * ATX_PD, *sc = v + ATX_MAX_S * ATX_PD;
   const int tid = threadIdx.x;
   const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
-  atx_stage(q, Q + qoff, S, dk, ldq, tid);
-  atx_stage(k, K + qoff, S, dk, ldq, tid);
-  atx_stage(v, V + voff, S, dv, ldv, tid);
+  {
+    AxRegs<2> rq, rk, rv;        // 32 rows x 64 floats = 512 pieces, two per thread
+    ax_issue(rq, Q + qoff, S, dk, ldq, tid);
+    ax_issue(rk, K + qoff, S, dk, ldq, tid);
+    ax_issue(rv, V + voff, S, dv, ldv, tid);
+    ax_commit(rq, q, ATX_PD, Q + qoff, S, dk, ldq, tid);
+    ax_commit(rk, k, ATX_PD, K + qoff, S, dk, ldq, tid);
+    ax_commit(rv, v, ATX_PD, V + voff, S, dv, ldv, tid);
+  }
   __syncthreads();
   for (int p = tid; p < S * S; p += AT_THREADS) {
     const int i = p / S, j = p - i * S;
@@ -638,10 +684,17 @@ __device__ __forceinline__ void attn_bwd_exact_body(float* lds, const float* __r
   float* delta = pm + ATX_MAX_S * ATX_PS;
   const int tid = threadIdx.x;
   const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
-  atx_stage(q, Q + qoff, S, dk, ldq, tid);
-  atx_stage(k, K + qoff, S, dk, ldq, tid);
-  atx_stage(v, V + voff, S, dv, ldv, tid);
-  atx_stage(go, dO + ooff, S, dv, ldo, tid);
+  {
+    AxRegs<2> rq, rk, rv, ro;
+    ax_issue(rq, Q + qoff, S, dk, ldq, tid);
+    ax_issue(rk, K + qoff, S, dk, ldq, tid);
+    ax_issue(rv, V + voff, S, dv, ldv, tid);
+    ax_issue(ro, dO + ooff, S, dv, ldo, tid);
+    ax_commit(rq, q, ATX_PD, Q + qoff, S, dk, ldq, tid);
+    ax_commit(rk, k, ATX_PD, K + qoff, S, dk, ldq, tid);
+    ax_commit(rv, v, ATX_PD, V + voff, S, dv, ldv, tid);
+    ax_commit(ro, go, ATX_PD, dO + ooff, S, dv, ldo, tid);
+  }
   __syncthreads();
   for (int p = tid; p < S * S; p += AT_THREADS) {       // probabilities again, and the gradient reaching them
     const int i = p / S, j = p - i * S;
@@ -735,14 +788,6 @@ static size_t atl_bwd_lds(int S, int dk, int dv) {
   return (size_t)(S * (dk + 1) + S * (dv + 1) + ATL_QB * (dk + 1) + ATL_QB * (dv + 1) + 3 * ATL_QB * (S + 1)) * 4;
 }
 
-__device__ __forceinline__ void atl_stage(float* dst, int pitch, const float* __restrict__ src, int rows, int d, long ld,
-                                          int tid) {
-  for (int q = tid; q < rows * d; q += AT_THREADS) {
-    const int r = q / d, c = q - r * d;
-    dst[r * pitch + c] = src[(size_t)r * ld + c];
-  }
-}
-
 // Register blocking: a thread forms a 4 x 4 block of dot products at a time (queries 4 * ib + r, keys jl + 32 * c with
 // jl = tid & 31, ib = tid >> 5), so one step of the contraction is 8 LDS reads for 16 multiply-adds instead of 32 for 16
 // -- LDS issue, not the ALUs, bounds these kernels.  Lanes walk consecutive keys (odd row pitch: every bank once) and
@@ -795,8 +840,15 @@ __device__ __forceinline__ void atl_fwd_body(
   const int tid = threadIdx.x;
   const int jl = tid & 31, ib = tid >> 5;
   const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
-  atl_stage(k, pk, K + qoff, S, dk, ldq, tid);
-  atl_stage(v, pv, V + voff, S, dv, ldv, tid);
+  AxRegs<2> rq;                  // a block of 32 queries x 64 floats: two pieces per thread
+  {
+    AxRegs<8> rk, rv;            // 128 keys x 64 floats: eight pieces per thread
+    ax_issue(rk, K + qoff, S, dk, ldq, tid);
+    ax_issue(rv, V + voff, S, dv, ldv, tid);
+    ax_issue(rq, Q + qoff, (S < ATL_QB) ? S : ATL_QB, dk, ldq, tid);
+    ax_commit(rk, k, pk, K + qoff, S, dk, ldq, tid);
+    ax_commit(rv, v, pv, V + voff, S, dv, ldv, tid);
+  }
   int kj[NC], vcol[2];
 #pragma unroll
   for (int c = 0; c < NC; ++c) kj[c] = ((jl + 32 * c < S) ? jl + 32 * c : S - 1) * pk;
@@ -804,8 +856,9 @@ __device__ __forceinline__ void atl_fwd_body(
   for (int c = 0; c < 2; ++c) vcol[c] = (jl + 32 * c < dv) ? jl + 32 * c : dv - 1;
   for (int q0 = 0; q0 < S; q0 += ATL_QB) {
     const int nq = (S - q0 < ATL_QB) ? S - q0 : ATL_QB;
-    __syncthreads();                      // K / V staged; the previous block's images are free
-    atl_stage(q, pk, Q + qoff + (size_t)q0 * ldq, nq, dk, ldq, tid);
+    __syncthreads();                      // the previous block's images are free
+    if (q0 > 0) ax_issue(rq, Q + qoff + (size_t)q0 * ldq, nq, dk, ldq, tid);     // the first block is already on its way
+    ax_commit(rq, q, pk, Q + qoff + (size_t)q0 * ldq, nq, dk, ldq, tid);
     __syncthreads();
     int qi[4], si[4];
 #pragma unroll
@@ -889,8 +942,16 @@ __device__ __forceinline__ void atl_bwd_body(
   const int tid = threadIdx.x;
   const int jl = tid & 31, ib = tid >> 5;
   const size_t qoff = at_base(bh, H, S, ldq, dk), voff = at_base(bh, H, S, ldv, dv), ooff = at_base(bh, H, S, ldo, dv);
-  atl_stage(k, pk, K + qoff, S, dk, ldq, tid);
-  atl_stage(v, pv, V + voff, S, dv, ldv, tid);
+  AxRegs<2> rq, ro;
+  {
+    AxRegs<8> rk, rv;
+    ax_issue(rk, K + qoff, S, dk, ldq, tid);
+    ax_issue(rv, V + voff, S, dv, ldv, tid);
+    ax_issue(rq, Q + qoff, (S < ATL_QB) ? S : ATL_QB, dk, ldq, tid);
+    ax_issue(ro, dO + ooff, (S < ATL_QB) ? S : ATL_QB, dv, ldo, tid);
+    ax_commit(rk, k, pk, K + qoff, S, dk, ldq, tid);
+    ax_commit(rv, v, pv, V + voff, S, dv, ldv, tid);
+  }
   // dK / dV: a thread owns keys jl + 32 * c (c < NC) x columns ib + 8 * e (e < 8) -- up to 128 keys x 64 columns over 256
   // threads -- and sums them over the query blocks in order, in registers
   float acck[NC][8], accv[NC][8];
@@ -911,8 +972,12 @@ __device__ __forceinline__ void atl_bwd_body(
   for (int q0 = 0; q0 < S; q0 += ATL_QB) {
     const int nq = (S - q0 < ATL_QB) ? S - q0 : ATL_QB;
     __syncthreads();
-    atl_stage(q, pk, Q + qoff + (size_t)q0 * ldq, nq, dk, ldq, tid);
-    atl_stage(go, pv, dO + ooff + (size_t)q0 * ldo, nq, dv, ldo, tid);
+    if (q0 > 0) {
+      ax_issue(rq, Q + qoff + (size_t)q0 * ldq, nq, dk, ldq, tid);
+      ax_issue(ro, dO + ooff + (size_t)q0 * ldo, nq, dv, ldo, tid);
+    }
+    ax_commit(rq, q, pk, Q + qoff + (size_t)q0 * ldq, nq, dk, ldq, tid);
+    ax_commit(ro, go, pv, dO + ooff + (size_t)q0 * ldo, nq, dv, ldo, tid);
     __syncthreads();
     int qi[4], gi[4], si[4];
 #pragma unroll
