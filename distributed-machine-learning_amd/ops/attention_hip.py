@@ -97,14 +97,15 @@ class FusedQKVAttention(torch.autograd.Function):
         B, S, W = qkv.shape
         es = qkv.element_size()
         do = grad_out.to(qkv.dtype).contiguous()
-        dqkv = torch.empty(B, S, W, device=qkv.device, dtype=torch.float32)
+        # bf16 operands: the kernel rounds the gradient to bf16 itself (mode 2) -- no f32 tensor, no cast pass
+        dqkv = torch.empty(B, S, W, device=qkv.device, dtype=qkv.dtype)
         base, g = qkv.data_ptr(), dqkv.data_ptr()
         L.check(so.mt_attn_bwd_strided_launch(base, base + h * dk * es, base + 2 * h * dk * es, do.data_ptr(), None,
-                                              stat.data_ptr(), g, g + h * dk * 4, g + 2 * h * dk * 4, B * h, S, dk, dv,
-                                              scale, keep_scale, _KIND[kind], h, W, W, h * dv, f32,
+                                              stat.data_ptr(), g, g + h * dk * es, g + 2 * h * dk * es, B * h, S, dk, dv,
+                                              scale, keep_scale, _KIND[kind], h, W, W, h * dv, 1 if f32 else 2,
                                               ctx.seed.data_ptr() if ctx.seed is not None else None, ctx.p,
                                               L.raw_stream(qkv.device)), "mt_attn_bwd_strided_launch")
-        return dqkv.to(qkv.dtype), None, None, None, None, None
+        return dqkv, None, None, None, None, None
 
 
 class FusedSelfAttention(torch.autograd.Function):
@@ -150,12 +151,12 @@ class FusedSelfAttention(torch.autograd.Function):
         dk, dv = w2 // (2 * h), v.shape[-1] // h
         es = qk.element_size()
         do = grad_out.to(qk.dtype).contiguous()
-        dqk = torch.empty(B, S, w2, device=qk.device, dtype=torch.float32)
-        dv_ = torch.empty(B, S, h * dv, device=qk.device, dtype=torch.float32)
+        dqk = torch.empty(B, S, w2, device=qk.device, dtype=qk.dtype)
+        dv_ = torch.empty(B, S, h * dv, device=qk.device, dtype=qk.dtype)
         L.check(so.mt_attn_bwd_strided_launch(qk.data_ptr(), qk.data_ptr() + h * dk * es, v.data_ptr(), do.data_ptr(),
                                               keep_u8.data_ptr() if has_keep else None, stat.data_ptr(), dqk.data_ptr(),
-                                              dqk.data_ptr() + h * dk * 4, dv_.data_ptr(), B * h, S, dk, dv, scale,
-                                              keep_scale, _KIND[kind], h, 2 * h * dk, h * dv, h * dv, f32,
+                                              dqk.data_ptr() + h * dk * es, dv_.data_ptr(), B * h, S, dk, dv, scale,
+                                              keep_scale, _KIND[kind], h, 2 * h * dk, h * dv, h * dv, 1 if f32 else 2,
                                               ctx.seed.data_ptr() if ctx.seed is not None else None, ctx.p,
                                               L.raw_stream(qk.device)), "mt_attn_bwd_strided_launch")
-        return dqk.to(qk.dtype), dv_.to(v.dtype), None, None, None, None, None
+        return dqk, dv_, None, None, None, None, None

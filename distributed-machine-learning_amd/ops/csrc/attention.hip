@@ -412,14 +412,21 @@ __device__ __forceinline__ void bwd_block(f32x4 (&p)[NKB], f32x4 (&dp)[NKB], uin
     }
 }
 
-template <int NKB, int PCHQ, bool F32>     // dQ, dK, dV are f32 and laid out like Q, K, V (same row strides)
+// A gradient element: f32, or (gbf: bf16 operands whose gradients are wanted in bf16 too) rounded to bf16 on the way out,
+// which saves the caller a cast pass over the whole gradient tensor.  idx counts elements of either type.
+__device__ __forceinline__ void at_store_grad(float* __restrict__ base, size_t idx, float v, bool gbf) {
+  if (gbf) reinterpret_cast<uint16_t*>(base)[idx] = (uint16_t)f32_to_bf16_bits(v);
+  else base[idx] = v;
+}
+
+template <int NKB, int PCHQ, bool F32>     // dQ, dK, dV are laid out like Q, K, V (same row strides); f32 unless gbf
 __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restrict__ Q_, const void* __restrict__ K_,
                                               const void* __restrict__ V_, const void* __restrict__ dO_,
                                               const uint8_t* __restrict__ keep, const float* __restrict__ stat,
                                               float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, int S,
                                               int dk, int dv, float scale, float keep_scale, int kind, int H, long ldq,
                                               long ldv, long ldo, bool seeded, uint32_t seed_lo, uint32_t seed_hi,
-                                              uint32_t thresh, int bh) {
+                                              uint32_t thresh, int bh, bool gbf = false) {
   const bool masked = keep != nullptr || seeded;
   constexpr int SP = NKB * 16;
   constexpr int PCH = (SP <= 64) ? 8 : 16;        // chunks per row of the [key][query] images
@@ -485,7 +492,7 @@ __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int d = db * 16 + g * 4 + j;
-          if (d < dk) dQ[qoff + (size_t)query * ldq + d] = a[j];
+          if (d < dk) at_store_grad(dQ, qoff + (size_t)query * ldq + d, a[j], gbf);
         }
       }
     }
@@ -506,7 +513,7 @@ __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restri
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int key = kb * 16 + g * 4 + j;
-        if (key < S && n < dv) dV[voff + (size_t)key * ldv + n] = a[j];
+        if (key < S && n < dv) at_store_grad(dV, voff + (size_t)key * ldv + n, a[j], gbf);
       }
     }
     for (int db = 0; db < nkd; ++db) {       // dK[key][d] = sum_query dS^T[key][query] Q[query][d]
@@ -521,7 +528,7 @@ __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restri
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int key = kb * 16 + g * 4 + j;
-        if (key < S && d < dk) dK[qoff + (size_t)key * ldq + d] = a[j];
+        if (key < S && d < dk) at_store_grad(dK, qoff + (size_t)key * ldq + d, a[j], gbf);
       }
     }
   }
@@ -541,12 +548,13 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_kernel(const void* __r
                                                                  float* __restrict__ dK, float* __restrict__ dV, int S,
                                                                  int dk, int dv, float scale, float keep_scale,
                                                                  int kind, int H, long ldq, long ldv, long ldo,
-                                                                 const int64_t* __restrict__ seed, uint32_t thresh) {
+                                                                 const int64_t* __restrict__ seed, uint32_t thresh,
+                                                                 int gbf) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[at_bwd_lds_bytes<NKB, PCHQ>()];
   uint32_t seed_lo = 0u, seed_hi = 0u;
   if (seed != nullptr) { const uint64_t sv = (uint64_t)seed[0]; seed_lo = (uint32_t)sv; seed_hi = (uint32_t)(sv >> 32); }
   attn_bwd_body<NKB, PCHQ, F32>(lds, Q_, K_, V_, dO_, keep, stat, dQ, dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq,
-                                ldv, ldo, seed != nullptr, seed_lo, seed_hi, thresh, blockIdx.x);
+                                ldv, ldo, seed != nullptr, seed_lo, seed_hi, thresh, blockIdx.x, !F32 && gbf != 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1315,6 +1323,9 @@ extern "C" int mt_attn_bwd_strided_launch(const void* Q, const void* K, const vo
                                           int dv, float scale, float keep_scale, int kind, int H, long ldq, long ldv,
                                           long ldo, int f32, const int64_t* seed, float p, hipStream_t stream) {
   if (BH <= 0) return 0;
+  // f32: 1 = f32 operands and gradients; 0 = bf16 operands, f32 gradients; 2 = bf16 operands, bf16 gradients
+  const int gbf = (f32 == 2) ? 1 : 0;
+  if (gbf) f32 = 0;
   const int rc = at_check(BH, S, dk, dv, H, ldq, ldv, ldo, f32);
   if (rc) return rc;
   const uint32_t thresh = (seed != nullptr && p > 0.f) ? (uint32_t)((double)p * 4294967296.0) : 0u;
@@ -1343,7 +1354,7 @@ extern "C" int mt_attn_bwd_strided_launch(const void* Q, const void* K, const vo
   const bool narrow = dk <= 32 && dv <= 32;
 #define AT_BWD2(N, P, F)                                                                                        \
   hipLaunchKernelGGL((mt_attn_bwd_kernel<N, P, F>), grid, block, 0, stream, Q, K, V, dO, (const uint8_t*)keep, stat, dQ, \
-                     dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo, seed, thresh)
+                     dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo, seed, thresh, gbf)
 #define AT_BWD1(N, P) do { if (f32) AT_BWD2(N, P, true); else AT_BWD2(N, P, false); } while (0)
   const bool wide = dk > 64 || dv > 64;
 #define AT_BWD(N) do { if (narrow) AT_BWD1(N, 4); else if (!wide) AT_BWD1(N, 8); else AT_BWD1(N, 16); } while (0)

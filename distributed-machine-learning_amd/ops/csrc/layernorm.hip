@@ -137,16 +137,15 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_kernel(const float* __re
                                                                const float* __restrict__ w, float* __restrict__ dx,
                                                                float* __restrict__ dres, float* __restrict__ dwb_part,
                                                                int M, int d, float keep_scale,
-                                                               const int64_t* __restrict__ seed, uint32_t thresh) {
+                                                               const int64_t* __restrict__ seed, uint32_t thresh, int reps) {
   __shared__ float red[4][2 * 2048 / 4];     // per wave: dw then db for one float4 column group at a time
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = d >> 2;
   f32x4 dw[LN_MAXV], db[LN_MAXV];
 #pragma unroll
   for (int t = 0; t < LN_MAXV; ++t) { dw[t] = f32x4{0.f, 0.f, 0.f, 0.f}; db[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  const int row0 = (blockIdx.x * 4 + wave) * LN_ROWS_PER_WAVE;
-  for (int r = 0; r < LN_ROWS_PER_WAVE; ++r) {
-    const int row = row0 + r;
+  for (int r = 0; r < reps * LN_ROWS_PER_WAVE; ++r) {
+    const int row = ((blockIdx.x * reps + r / LN_ROWS_PER_WAVE) * 4 + wave) * LN_ROWS_PER_WAVE + r % LN_ROWS_PER_WAVE;
     if (row >= M) break;
     const size_t base = (size_t)row * d;
     const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
@@ -227,7 +226,8 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_small_kernel(const float
                                                                      const float* __restrict__ w, float* __restrict__ dx,
                                                                      float* __restrict__ dres, float* __restrict__ dwb_part,
                                                                      int M, int d, float keep_scale,
-                                                                     const int64_t* __restrict__ seed, uint32_t thresh) {
+                                                                     const int64_t* __restrict__ seed, uint32_t thresh,
+                                                                     int reps) {
   __shared__ float red[4][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = d >> 2;
@@ -235,8 +235,9 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_small_kernel(const float
   const int c4 = col_ok ? 4 * lane : 0;
   const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c4);
   f32x4 dw = f32x4{0.f, 0.f, 0.f, 0.f}, db = dw;
-  const int row0 = (blockIdx.x * 4 + wave) * LN_ROWS_PER_WAVE;
   const float inv_d = 1.f / (float)d;
+  for (int rep = 0; rep < reps; ++rep) {
+  const int row0 = ((blockIdx.x * reps + rep) * 4 + wave) * LN_ROWS_PER_WAVE;
 #pragma unroll
   for (int it = 0; it < LN_ROWS_PER_WAVE; it += LN_SMALL_ROWS) {
     if (row0 + it >= M) break;                                   // wave-uniform
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_small_kernel(const float
       }
     }
   }
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     red[wave][lane * 4 + e] = dw[e];
@@ -300,7 +302,14 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_small_kernel(const float
   }
 }
 
-extern "C" int mt_ln_bwd_blocks(int M) { return (M + 4 * LN_ROWS_PER_WAVE - 1) / (4 * LN_ROWS_PER_WAVE); }
+// A block takes `reps` consecutive groups of 32 rows and writes one partial of the weight / bias gradients: large row
+// counts are capped at about LN_BWD_MAX_BLOCKS partials, so the column sum over them that follows stays a small kernel
+// (66 560 rows x 192 columns: 694 partials instead of 2 080).  Up to that many groups nothing changes.
+#define LN_BWD_MAX_BLOCKS 1024
+static int ln_bwd_groups(int M) { return (M + 4 * LN_ROWS_PER_WAVE - 1) / (4 * LN_ROWS_PER_WAVE); }
+static int ln_bwd_reps(int M) { return (ln_bwd_groups(M) + LN_BWD_MAX_BLOCKS - 1) / LN_BWD_MAX_BLOCKS > 1
+                                           ? (ln_bwd_groups(M) + LN_BWD_MAX_BLOCKS - 1) / LN_BWD_MAX_BLOCKS : 1; }
+extern "C" int mt_ln_bwd_blocks(int M) { const int r = ln_bwd_reps(M); return (ln_bwd_groups(M) + r - 1) / r; }
 
 extern "C" int mt_ln_fwd_launch(const float* x, const float* res, const void* keep, const float* w, const float* b,
                                 float* y, float* z, float* stats, int M, int d, float eps, float keep_scale,
@@ -328,10 +337,10 @@ extern "C" int mt_ln_bwd_launch(const float* dy, const float* z, const float* st
   if (d > 2048 || (d & 3)) return -2;
   if (d <= 256)
     hipLaunchKernelGGL(mt_ln_bwd_small_kernel, dim3(mt_ln_bwd_blocks(M)), dim3(LN_THREADS), 0, stream, dy, z, stats,
-                       (const uint8_t*)keep, w, dx, dres, dwb_part, M, d, keep_scale, seed, thresh);
+                       (const uint8_t*)keep, w, dx, dres, dwb_part, M, d, keep_scale, seed, thresh, ln_bwd_reps(M));
   else
     hipLaunchKernelGGL(mt_ln_bwd_kernel, dim3(mt_ln_bwd_blocks(M)), dim3(LN_THREADS), 0, stream, dy, z, stats,
-                       (const uint8_t*)keep, w, dx, dres, dwb_part, M, d, keep_scale, seed, thresh);
+                       (const uint8_t*)keep, w, dx, dres, dwb_part, M, d, keep_scale, seed, thresh, ln_bwd_reps(M));
   return (int)hipGetLastError();
 }
 
@@ -418,7 +427,8 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_mixed_kernel(const float
                                                                      const float* __restrict__ w, void* __restrict__ dx_,
                                                                      float* __restrict__ dres, float* __restrict__ dwb_part,
                                                                      int M, int d, float keep_scale,
-                                                                     const int64_t* __restrict__ seed, uint32_t thresh) {
+                                                                     const int64_t* __restrict__ seed, uint32_t thresh,
+                                                                     int reps) {
   __shared__ float red[4][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = d >> 2;
@@ -426,8 +436,9 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_mixed_kernel(const float
   const int c4 = col_ok ? 4 * lane : 0;
   const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c4);
   f32x4 dw = f32x4{0.f, 0.f, 0.f, 0.f}, db = dw;
-  const int row0 = (blockIdx.x * 4 + wave) * LN_ROWS_PER_WAVE;
   const float inv_d = 1.f / (float)d;
+  for (int rep = 0; rep < reps; ++rep) {
+  const int row0 = ((blockIdx.x * reps + rep) * 4 + wave) * LN_ROWS_PER_WAVE;
 #pragma unroll
   for (int it = 0; it < LN_ROWS_PER_WAVE; it += LN_SMALL_ROWS) {
     if (row0 + it >= M) break;                                   // wave-uniform
@@ -481,6 +492,7 @@ __global__ __launch_bounds__(LN_THREADS) void mt_ln_bwd_mixed_kernel(const float
       }
     }
   }
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     red[wave][lane * 4 + e] = dw[e];
@@ -523,9 +535,9 @@ extern "C" int mt_ln_bwd_mixed_launch(const float* dy, const void* dy16, const f
   const dim3 grid(mt_ln_bwd_blocks(M)), block(LN_THREADS);
   if (dx_bf16)
     hipLaunchKernelGGL(mt_ln_bwd_mixed_kernel<true>, grid, block, 0, stream, dy, (const uint16_t*)dy16, z, stats, w, dx, dres,
-                       dwb_part, M, d, keep_scale, seed, thresh);
+                       dwb_part, M, d, keep_scale, seed, thresh, ln_bwd_reps(M));
   else
     hipLaunchKernelGGL(mt_ln_bwd_mixed_kernel<false>, grid, block, 0, stream, dy, (const uint16_t*)dy16, z, stats, w, dx, dres,
-                       dwb_part, M, d, keep_scale, seed, thresh);
+                       dwb_part, M, d, keep_scale, seed, thresh, ln_bwd_reps(M));
   return (int)hipGetLastError();
 }
