@@ -819,22 +819,29 @@ __device__ __forceinline__ void atl_dots(float (&acc)[4][NC], const float* __res
 
 // out[i][n] = sum_j w[i][j] * m[j][n] for this thread's queries 4 * ib + r and columns jl + 32 * c (c < 2): per j four
 // broadcast reads of w and one or two reads of m for four or eight multiply-adds.
+template <bool TWO>
+__device__ __forceinline__ void atl_rows_times_n(float (&acc)[4][2], const float* __restrict__ w, const int (&wi)[4],
+                                                 const float* __restrict__ m, int pitch, const int (&col)[2], int S) {
+#pragma unroll 4
+  for (int j = 0; j < S; ++j) {
+    float wv[4], mv[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wv[r] = w[wi[r] + j];
+    mv[0] = m[j * pitch + col[0]];
+    if constexpr (TWO) mv[1] = m[j * pitch + col[1]];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[r][0] = fmaf(wv[r], mv[0], acc[r][0]);
+      if constexpr (TWO) acc[r][1] = fmaf(wv[r], mv[1], acc[r][1]);
+    }
+  }
+}
+
 __device__ __forceinline__ void atl_rows_times(float (&acc)[4][2], const float* __restrict__ w, const int (&wi)[4],
                                                const float* __restrict__ m, int pitch, const int (&col)[2], bool two,
                                                int S) {
-  for (int j = 0; j < S; ++j) {
-    float wv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) wv[r] = w[wi[r] + j];
-    const float m0 = m[j * pitch + col[0]];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r][0] = fmaf(wv[r], m0, acc[r][0]);
-    if (two) {
-      const float m1 = m[j * pitch + col[1]];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r][1] = fmaf(wv[r], m1, acc[r][1]);
-    }
-  }
+  if (two) atl_rows_times_n<true>(acc, w, wi, m, pitch, col, S);
+  else atl_rows_times_n<false>(acc, w, wi, m, pitch, col, S);
 }
 
 template <int NC>
@@ -938,7 +945,32 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_exact_tiled_kernel(
                    s1, thresh, blockIdx.x);
 }
 
-template <int NC>
+// One query block's share of dK = dS^T . Q and dV = (dropped P)^T . dO for the (key, column) elements a thread owns:
+// per query NC + NC reads along the keys and NE + NE broadcast reads along the columns, all independent, then
+// 2 * NC * NE multiply-adds.  NE (column groups of eight in use) is compile-time so the loop body has no branches;
+// columns past the head are clamped reads whose sums are never stored.
+template <int NC, int NE>
+__device__ __forceinline__ void atl_dkdv(float (&acck)[NC][NE], float (&accv)[NC][NE], const float* __restrict__ ds,
+                                         const float* __restrict__ pm, const float* __restrict__ q,
+                                         const float* __restrict__ go, const int (&sj)[NC], const int (&qcol)[NE],
+                                         const int (&gcol)[NE], int nq, int ps, int pk, int pv) {
+  for (int i = 0; i < nq; ++i) {
+    float dsv[NC], pmv[NC], qv[NE], gv[NE];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { dsv[c] = ds[i * ps + sj[c]]; pmv[c] = pm[i * ps + sj[c]]; }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { qv[e] = q[i * pk + qcol[e]]; gv[e] = go[i * pv + gcol[e]]; }
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        acck[c][e] = fmaf(dsv[c], qv[e], acck[c][e]);
+        accv[c][e] = fmaf(pmv[c], gv[e], accv[c][e]);
+      }
+  }
+}
+
+template <int NC, int NE>     // NE: column groups of eight the widest head spans (2, 4 or 8)
 __device__ __forceinline__ void atl_bwd_body(
     float* atl_lds, const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const uint8_t* __restrict__ keep, const float* __restrict__ stat, float* __restrict__ dQ,
@@ -960,13 +992,13 @@ __device__ __forceinline__ void atl_bwd_body(
     ax_commit(rk, k, pk, K + qoff, S, dk, ldq, tid);
     ax_commit(rv, v, pv, V + voff, S, dv, ldv, tid);
   }
-  // dK / dV: a thread owns keys jl + 32 * c (c < NC) x columns ib + 8 * e (e < 8) -- up to 128 keys x 64 columns over 256
+  // dK / dV: a thread owns keys jl + 32 * c (c < NC) x columns ib + 8 * e (e < NE) -- up to 128 keys x 64 columns over 256
   // threads -- and sums them over the query blocks in order, in registers
-  float acck[NC][8], accv[NC][8];
+  float acck[NC][NE], accv[NC][NE];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { acck[c][e] = 0.f; accv[c][e] = 0.f; }
+    for (int e = 0; e < NE; ++e) { acck[c][e] = 0.f; accv[c][e] = 0.f; }
   int kj[NC], vj[NC], sj[NC], kcol[2];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -977,13 +1009,16 @@ __device__ __forceinline__ void atl_bwd_body(
   }
 #pragma unroll
   for (int c = 0; c < 2; ++c) kcol[c] = (jl + 32 * c < dk) ? jl + 32 * c : dk - 1;
+  int qcol[NE], gcol[NE];       // the columns ib + 8 * e this thread owns of dK / dV, clamped into the head
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    qcol[e] = (ib + 8 * e < dk) ? ib + 8 * e : dk - 1;
+    gcol[e] = (ib + 8 * e < dv) ? ib + 8 * e : dv - 1;
+  }
   for (int q0 = 0; q0 < S; q0 += ATL_QB) {
     const int nq = (S - q0 < ATL_QB) ? S - q0 : ATL_QB;
     __syncthreads();
-    if (q0 > 0) {
-      ax_issue(rq, Q + qoff + (size_t)q0 * ldq, nq, dk, ldq, tid);
-      ax_issue(ro, dO + ooff + (size_t)q0 * ldo, nq, dv, ldo, tid);
-    }
+    // this block's rows were requested before the loop or during the previous block's dK / dV pass
     ax_commit(rq, q, pk, Q + qoff + (size_t)q0 * ldq, nq, dk, ldq, tid);
     ax_commit(ro, go, pv, dO + ooff + (size_t)q0 * ldo, nq, dv, ldo, tid);
     __syncthreads();
@@ -996,6 +1031,9 @@ __device__ __forceinline__ void atl_bwd_body(
       si[r] = i * ps;
     }
     if (ib * 4 < nq) {
+      float st4[4];                // the rows' saved statistic, on its way while the dot products run
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st4[r] = stat[(size_t)bh * S + q0 + ((ib * 4 + r < nq) ? ib * 4 + r : nq - 1)];
       float as[4][NC] = {}, ad[4][NC] = {};
       atl_dots<NC>(as, q, qi, k, kj, dk);
       atl_dots<NC>(ad, go, gi, v, vj, dv);
@@ -1003,7 +1041,7 @@ __device__ __forceinline__ void atl_bwd_body(
       for (int r = 0; r < 4; ++r) {
         const int i = ib * 4 + r, qg = q0 + i;
         if (i < nq) {
-          const float st = stat[(size_t)bh * S + qg];
+          const float st = st4[r];
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
             const int j = jl + 32 * c;
@@ -1046,33 +1084,20 @@ __device__ __forceinline__ void atl_bwd_body(
         for (int c = 0; c < 2; ++c)
           if (ib * 4 + r < nq && jl + 32 * c < dk) dQ[qoff + (size_t)(q0 + ib * 4 + r) * ldq + jl + 32 * c] = acc[r][c];
     }
-    // this block's share of dK = dS^T . Q and dV = (dropped P)^T . dO: per query 4 + 4 reads along the keys and up to
-    // 8 + 8 broadcast reads along the columns for up to 64 multiply-adds
-    for (int i = 0; i < nq; ++i) {
-      float dsv[NC], pmv[NC];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) { dsv[c] = ds[i * ps + sj[c]]; pmv[c] = pm[i * ps + sj[c]]; }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (e * 8 < dk) {
-          const float qv = q[i * pk + ((ib + 8 * e < dk) ? ib + 8 * e : dk - 1)];
-#pragma unroll
-          for (int c = 0; c < NC; ++c) acck[c][e] = fmaf(dsv[c], qv, acck[c][e]);
-        }
-        if (e * 8 < dv) {
-          const float gv = go[i * pv + ((ib + 8 * e < dv) ? ib + 8 * e : dv - 1)];
-#pragma unroll
-          for (int c = 0; c < NC; ++c) accv[c][e] = fmaf(pmv[c], gv, accv[c][e]);
-        }
-      }
+    // this block's share of dK = dS^T . Q and dV = (dropped P)^T . dO
+    if (q0 + ATL_QB < S) {      // the next block's rows travel while this block's dK / dV are summed
+      const int q1 = q0 + ATL_QB, n1 = (S - q1 < ATL_QB) ? S - q1 : ATL_QB;
+      ax_issue(rq, Q + qoff + (size_t)q1 * ldq, n1, dk, ldq, tid);
+      ax_issue(ro, dO + ooff + (size_t)q1 * ldo, n1, dv, ldo, tid);
     }
+    atl_dkdv<NC, NE>(acck, accv, ds, pm, q, go, sj, qcol, gcol, nq, ps, pk, pv);
   }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int j = jl + 32 * c;
     if (j < S) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < NE; ++e) {
         const int col = ib + 8 * e;
         if (col < dk) dK[qoff + (size_t)j * ldq + col] = acck[c][e];
         if (col < dv) dV[voff + (size_t)j * ldv + col] = accv[c][e];
@@ -1081,7 +1106,7 @@ __device__ __forceinline__ void atl_bwd_body(
   }
 }
 
-template <int NC>
+template <int NC, int NE>
 __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_exact_tiled_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
     const uint8_t* __restrict__ keep, const float* __restrict__ stat, float* __restrict__ dQ, float* __restrict__ dK,
@@ -1090,7 +1115,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_exact_tiled_kernel(
   extern __shared__ __attribute__((aligned(16))) float atl_lds[];
   uint32_t s0 = 0u, s1 = 0u;
   if (seed != nullptr) { const uint64_t sv = (uint64_t)seed[0]; s0 = (uint32_t)sv; s1 = (uint32_t)(sv >> 32); }
-  atl_bwd_body<NC>(atl_lds, Q, K, V, dO, keep, stat, dQ, dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo,
+  atl_bwd_body<NC, NE>(atl_lds, Q, K, V, dO, keep, stat, dQ, dK, dV, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo,
                    seed != nullptr, s0, s1, thresh, blockIdx.x);
 }
 
@@ -1109,6 +1134,13 @@ extern "C" int mt_attn_exact_level(int set) {      // set >= 0 replaces the leve
 }
 // key groups of 32 a sequence of 33..128 tokens spans: the tiled kernels are compiled for 2, 3 and 4
 #define ATL_NC(LAUNCH, S) do { if ((S) <= 64) LAUNCH(2); else if ((S) <= 96) LAUNCH(3); else LAUNCH(4); } while (0)
+// ... and the backward kernels per number of 8-column groups of the widest head as well: 2, 4 or 8
+#define ATL_NCNE(LAUNCH, S, D)                                                                          \
+  do {                                                                                                  \
+    if ((D) <= 16) { if ((S) <= 64) LAUNCH(2, 2); else if ((S) <= 96) LAUNCH(3, 2); else LAUNCH(4, 2); } \
+    else if ((D) <= 32) { if ((S) <= 64) LAUNCH(2, 4); else if ((S) <= 96) LAUNCH(3, 4); else LAUNCH(4, 4); } \
+    else { if ((S) <= 64) LAUNCH(2, 8); else if ((S) <= 96) LAUNCH(3, 8); else LAUNCH(4, 8); }          \
+  } while (0)
 static bool atl_fits(int S, int dk, int dv) {
   return at_exact_level() >= 2 && S > ATX_MAX_S && S <= ATL_MAX_S && dk <= ATX_MAX_D && dv <= ATX_MAX_D;
 }
@@ -1234,7 +1266,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_grouped_tiled_kernel(c
                    seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1, a.thresh, blockIdx.x);
 }
 
-template <int NC>
+template <int NC, int NE>
 __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_tiled_kernel(const MtAttnSlot* __restrict__ slots,
                                                                                const int32_t* __restrict__ ids, int S,
                                                                                int step_imm,
@@ -1248,7 +1280,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_tiled_kernel(c
   const bool seeded = a.thresh != 0u && a.seed != nullptr;
   uint32_t s0 = 0u, s1 = 0u;
   if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
-  atl_bwd_body<NC>(atl_lds, a.qkv, a.qkv + d, a.qkv + 2 * d, a.d_o, nullptr, a.stat, a.dqkv, a.dqkv + d, a.dqkv + 2 * d, S,
+  atl_bwd_body<NC, NE>(atl_lds, a.qkv, a.qkv + d, a.qkv + 2 * d, a.d_o, nullptr, a.stat, a.dqkv, a.dqkv + d, a.dqkv + 2 * d, S,
                    a.dk, a.dk, a.scale, seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1, a.thresh,
                    blockIdx.x);
 }
@@ -1339,15 +1371,15 @@ extern "C" int mt_attn_bwd_strided_launch(const void* Q, const void* K, const vo
   }
   if (f32 && atl_fits(S, dk, dv)) {
     const size_t bytes = atl_bwd_lds(S, dk, dv);
-#define ATL_B(NC)                                                                                                     \
+#define ATL_B(NC, NE)                                                                                                 \
   do {                                                                                                                \
-    const int rc2 = atl_prepare((const void*)mt_attn_bwd_exact_tiled_kernel<NC>, bytes);                              \
+    const int rc2 = atl_prepare((const void*)mt_attn_bwd_exact_tiled_kernel<NC, NE>, bytes);                          \
     if (rc2) return rc2;                                                                                              \
-    hipLaunchKernelGGL(mt_attn_bwd_exact_tiled_kernel<NC>, grid, block, bytes, stream, (const float*)Q, (const float*)K, \
+    hipLaunchKernelGGL((mt_attn_bwd_exact_tiled_kernel<NC, NE>), grid, block, bytes, stream, (const float*)Q, (const float*)K, \
                        (const float*)V, (const float*)dO, (const uint8_t*)keep, stat, dQ, dK, dV, S, dk, dv, scale,    \
                        keep_scale, kind, H, ldq, ldv, ldo, seed, thresh);                                             \
   } while (0)
-    ATL_NC(ATL_B, S);
+    ATL_NCNE(ATL_B, S, (dk > dv) ? dk : dv);
 #undef ATL_B
     return (int)hipGetLastError();
   }
@@ -1386,7 +1418,9 @@ extern "C" int mt_attn_bwd_launch(const void* Q, const void* K, const void* V, c
                                     dv, 0, nullptr, 0.f, stream);
 }
 
-// max_bh: the largest B * H among the active slots; wide != 0: some slot has heads wider than 32 (64-element images).
+// max_bh: the largest B * H among the active slots; wide: the widest head among them in elements (1 is read as 64, 0 as
+// 32: the flag this argument used to be).  Heads wider than 32 take the 64-element images of the matrix form.
+static int at_group_dmax(int wide) { return wide > 1 ? (wide > 64 ? 64 : wide) : (wide ? 64 : 32); }
 extern "C" int mt_attn_fwd_grouped_launch(const MtAttnSlot* slots, const int32_t* ids, int n_active, int max_bh, int S,
                                           int wide, int step, int b_override, int train, hipStream_t stream) {
   if (n_active <= 0 || max_bh <= 0) return 0;
@@ -1397,8 +1431,8 @@ extern "C" int mt_attn_fwd_grouped_launch(const MtAttnSlot* slots, const int32_t
                        mt_step_base_tls);
     return (int)hipGetLastError();
   }
-  if (at_exact_level() >= 2) {                // heads of up to 32 (or, wide, 64) elements
-    const int dmax = wide ? 64 : 32;
+  if (at_exact_level() >= 2) {
+    const int dmax = at_group_dmax(wide);
     const size_t bytes = atl_fwd_lds(S, dmax, dmax);
 #define ATL_GF(NC)                                                                                                    \
   do {                                                                                                                \
@@ -1413,7 +1447,7 @@ extern "C" int mt_attn_fwd_grouped_launch(const MtAttnSlot* slots, const int32_t
   }
 #define AT_GF(N, P) hipLaunchKernelGGL((mt_attn_fwd_grouped_kernel<N, P>), grid, block, 0, stream, slots, ids, S, step, \
                                        b_override, train, mt_step_base_tls)
-#define AT_GFW(N) do { if (wide) AT_GF(N, 8); else AT_GF(N, 4); } while (0)
+#define AT_GFW(N) do { if (at_group_dmax(wide) > 32) AT_GF(N, 8); else AT_GF(N, 4); } while (0)
   switch (nkb_for(S)) {
     case 2: AT_GFW(2); break;
     case 4: AT_GFW(4); break;
@@ -1436,22 +1470,22 @@ extern "C" int mt_attn_bwd_grouped_launch(const MtAttnSlot* slots, const int32_t
     return (int)hipGetLastError();
   }
   if (at_exact_level() >= 2) {
-    const int dmax = wide ? 64 : 32;
+    const int dmax = at_group_dmax(wide);
     const size_t bytes = atl_bwd_lds(S, dmax, dmax);
-#define ATL_GB(NC)                                                                                                    \
+#define ATL_GB(NC, NE)                                                                                                \
   do {                                                                                                                \
-    const int rc2 = atl_prepare((const void*)mt_attn_bwd_grouped_tiled_kernel<NC>, bytes);                            \
+    const int rc2 = atl_prepare((const void*)mt_attn_bwd_grouped_tiled_kernel<NC, NE>, bytes);                        \
     if (rc2) return rc2;                                                                                              \
-    hipLaunchKernelGGL(mt_attn_bwd_grouped_tiled_kernel<NC>, grid, block, bytes, stream, slots, ids, S, step,         \
+    hipLaunchKernelGGL((mt_attn_bwd_grouped_tiled_kernel<NC, NE>), grid, block, bytes, stream, slots, ids, S, step,   \
                        mt_step_base_tls);                                                                             \
   } while (0)
-    ATL_NC(ATL_GB, S);
+    ATL_NCNE(ATL_GB, S, dmax);
 #undef ATL_GB
     return (int)hipGetLastError();
   }
 #define AT_GB(N, P) hipLaunchKernelGGL((mt_attn_bwd_grouped_kernel<N, P>), grid, block, 0, stream, slots, ids, S, step, \
                                        mt_step_base_tls)
-#define AT_GBW(N) do { if (wide) AT_GB(N, 8); else AT_GB(N, 4); } while (0)
+#define AT_GBW(N) do { if (at_group_dmax(wide) > 32) AT_GB(N, 8); else AT_GB(N, 4); } while (0)
   switch (nkb_for(S)) {
     case 2: AT_GBW(2); break;
     case 4: AT_GBW(4); break;

@@ -738,7 +738,7 @@ class SeqPackEngine(PackEngine):
             plan.max_bh = max(info[slot]["B"] * s.spec.heads for slot, s in members)
         plan.max_m = plan.max_b * S
         plan.max_params = max(s.layout.total for _, s in members)
-        plan.wide = int(any(s.spec.dk > 32 for _, s in members))
+        plan.wide = max(2, max(int(s.spec.dk) for _, s in members))      # the widest head, in elements
         plan.row_len, plan.hb, plan.n_rows = self.row_len, half_bits(self.n_train), self.n_train
         plan.use_clip = int(any(s.spec.opt.gradient_clipping > 0 for _, s in members))
         plan.ksplits, plan.max_blocks = self.ksplits, self.max_blocks
