@@ -31,8 +31,13 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
   __bf16 h = (__bf16)f;
   return (uint32_t)__builtin_bit_cast(uint16_t, h);
 }
+// Two floats -> one dword of two bf16 (round to nearest even): the vector conversion is ONE v_cvt_pk_bf16_f32; converting
+// the halves separately and or-ing them costs four instructions.
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+  typedef float mt_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 mt_bf16x2 __attribute__((ext_vector_type(2)));
+  const mt_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mt_bf16x2));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
