@@ -540,3 +540,35 @@ def test_big_unaligned_f32_layer_is_padded_onto_the_tile_kernels():
     assert w.grad.shape == (512, 81)
     torch.testing.assert_close(w.grad.double(), x.double().reshape(-1, 81).sum(0).expand(512, 81), rtol=1e-4, atol=1e-2)
     torch.testing.assert_close(b.grad.double(), torch.full((512,), 256.0 * 96, device="cuda", dtype=torch.float64))
+
+
+@pytest.mark.parametrize("B,S,h,dk,dv", [(3, 65, 8, 24, 24), (2, 96, 2, 64, 32), (2, 33, 3, 6, 20)])
+def test_bf16_attention_gradients_written_by_the_kernel_equal_a_cast_of_its_f32_gradients(B, S, h, dk, dv):
+    """Mode 2 of the backward launcher (bf16 operands, bf16 gradients) rounds exactly what mode 0 returns in f32."""
+    import math
+    from mitune.ops import lib as L
+    so = L.load()
+    g = torch.Generator(device="cuda").manual_seed(31)
+    qk = torch.randn(B, S, 2 * h * dk, device="cuda", generator=g).bfloat16()
+    v = torch.randn(B, S, h * dv, device="cuda", generator=g).bfloat16()
+    do = torch.randn(B, S, h * dv, device="cuda", generator=g).bfloat16()
+    out = torch.empty(B, S, h * dv, device="cuda", dtype=torch.bfloat16)
+    stat = torch.empty(B * h, S, device="cuda", dtype=torch.float32)
+    scale = 1.0 / math.sqrt(dk)
+    stream = L.raw_stream(qk.device)
+    L.check(so.mt_attn_fwd_strided_launch(qk.data_ptr(), qk.data_ptr() + h * dk * 2, v.data_ptr(), None, out.data_ptr(),
+                                          stat.data_ptr(), B * h, S, dk, dv, scale, 1.0, 0, h, 2 * h * dk, h * dv, h * dv,
+                                          0, None, 0.0, stream), "fwd")
+    grads = {}
+    for mode, dt, es in ((0, torch.float32, 4), (2, torch.bfloat16, 2)):
+        dqk = torch.zeros(B, S, 2 * h * dk, device="cuda", dtype=dt)
+        dv_ = torch.zeros(B, S, h * dv, device="cuda", dtype=dt)
+        L.check(so.mt_attn_bwd_strided_launch(qk.data_ptr(), qk.data_ptr() + h * dk * 2, v.data_ptr(), do.data_ptr(), None,
+                                              stat.data_ptr(), dqk.data_ptr(), dqk.data_ptr() + h * dk * es, dv_.data_ptr(),
+                                              B * h, S, dk, dv, scale, 1.0, 0, h, 2 * h * dk, h * dv, h * dv, mode, None,
+                                              0.0, stream), "bwd")
+        torch.cuda.synchronize()
+        grads[mode] = (dqk, dv_)
+    assert torch.equal(grads[0][0].bfloat16(), grads[2][0])
+    assert torch.equal(grads[0][1].bfloat16(), grads[2][1])
+    assert grads[2][0].float().abs().sum() > 0
