@@ -572,3 +572,36 @@ def test_bf16_attention_gradients_written_by_the_kernel_equal_a_cast_of_its_f32_
     assert torch.equal(grads[0][0].bfloat16(), grads[2][0])
     assert torch.equal(grads[0][1].bfloat16(), grads[2][1])
     assert grads[2][0].float().abs().sum() > 0
+
+
+@pytest.mark.parametrize("d,mixed", [(64, False), (512, False), (192, True)])
+def test_layernorm_backward_over_more_rows_than_one_block_per_group(d, mixed):
+    """40 000 rows are 1 250 groups of 32: past 1 024 a block takes several groups and writes one partial of the weight
+    and bias gradients.  All three backward kernels (narrow, wide, mixed precision) against a float64 reference."""
+    from mitune.ops.layernorm import residual_layer_norm_reference
+    from mitune.ops.layernorm_hip import FusedResidualLayerNorm, MixedResidualLayerNorm
+    g = torch.Generator(device="cuda").manual_seed(d + 1)
+    M = 40000
+    x = torch.randn(M, d, device="cuda", generator=g)
+    if mixed:
+        x = x.bfloat16()
+    x.requires_grad_()
+    r = torch.randn(M, d, device="cuda", generator=g, requires_grad=True)
+    w = torch.randn(d, device="cuda", generator=g, requires_grad=True)
+    b = torch.randn(d, device="cuda", generator=g, requires_grad=True)
+    dy = torch.randn(M, d, device="cuda", generator=g)
+    if mixed:
+        y = MixedResidualLayerNorm.apply(x, r, w, b, 1e-5, 0.0, None, False)
+    else:
+        y = FusedResidualLayerNorm.apply(x, r, w, b, 1e-5, None, 0.0)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    x64, r64, w64, b64 = (t.detach().double().requires_grad_() for t in (x, r, w, b))
+    yr = residual_layer_norm_reference(x64, r64, w64, b64, 1e-5, None, 0.0)
+    yr.backward(dy.double())
+    torch.testing.assert_close(y.detach().double(), yr.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(r.grad.double(), r64.grad, rtol=1e-4, atol=1e-4)
+    xtol = 2e-2 if mixed else 1e-4          # the mixed kernel returns the gradient of a bf16 input in bf16
+    torch.testing.assert_close(x.grad.double(), x64.grad, rtol=xtol, atol=xtol)
+    for got, ref in ((w.grad, w64.grad), (b.grad, b64.grad)):       # sums of 40 000 terms of order one
+        torch.testing.assert_close(got.double(), ref, rtol=1e-4, atol=5e-3)
