@@ -1280,9 +1280,15 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_tiled_kernel(c
   const bool seeded = a.thresh != 0u && a.seed != nullptr;
   uint32_t s0 = 0u, s1 = 0u;
   if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
-  atl_bwd_body<NC, NE>(atl_lds, a.qkv, a.qkv + d, a.qkv + 2 * d, a.d_o, nullptr, a.stat, a.dqkv, a.dqkv + d, a.dqkv + 2 * d, S,
-                   a.dk, a.dk, a.scale, seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1, a.thresh,
-                   blockIdx.x);
+  // NE covers the widest head of the launch; a slot with narrower heads takes the body compiled for its own width
+#define ATL_SLOT_BWD(E)                                                                                                   \
+  atl_bwd_body<NC, E>(atl_lds, a.qkv, a.qkv + d, a.qkv + 2 * d, a.d_o, nullptr, a.stat, a.dqkv, a.dqkv + d, a.dqkv + 2 * d, S, \
+                      a.dk, a.dk, a.scale, seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1,  \
+                      a.thresh, blockIdx.x)
+  if constexpr (NE >= 8) { if (a.dk > 32) { ATL_SLOT_BWD(8); return; } }
+  if constexpr (NE >= 4) { if (a.dk > 16) { ATL_SLOT_BWD(4); return; } }
+  ATL_SLOT_BWD(2);
+#undef ATL_SLOT_BWD
 }
 
 extern "C" int mt_attn_slot_sizeof() { return (int)sizeof(MtAttnSlot); }
