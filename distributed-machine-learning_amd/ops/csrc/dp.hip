@@ -18,7 +18,6 @@
 // no link-time dependency on RCCL; with one rank no collective is issued at all.
 #include "mt_bodies.h"
 
-#define MT_MAX_LAYERS 8
 
 extern "C" {
 int mt_gemm_single_launch(int mode, const void* A, const void* B, void* C, const void* aux, int M, int N, int K, int lda,

@@ -5,7 +5,8 @@
 #pragma once
 #include "mt_common.h"
 
-#define HL_ROWS 32       // rows per workgroup of the head/loss kernel = rows per partial record
+#define HL_ROWS 16       // rows per workgroup of the head/loss kernel = rows per partial record (= the rows of one MFMA
+                         // row tile, so that the row-block training kernel writes the same records: rowblock.hip)
 
 // Loss value and its derivative w.r.t. the prediction: 0 squared error, 1 absolute error, 2 Huber (beta 1),
 // 3 absolute percentage error.

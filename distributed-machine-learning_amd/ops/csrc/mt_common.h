@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define MT_WAVE 64
+#define MT_MAX_LAYERS 8      // hidden layers of an MLP trial (plan arrays of the step drivers)
 
 // Optional device-resident step base.  Launchers forward this thread's pointer to every step-aware kernel, which
 // adds *step_base to its immediate `step` argument.  The step driver sets it while it captures a hipGraph, so that

@@ -160,6 +160,7 @@ __device__ __forceinline__ void f32_gemm_tile(const MtGemmGroup* __restrict__ gr
 
   const int nk_all = (g.KK + F32_BK - 1) / F32_BK;
   int kt_lo = 0, kt_hi = nk_all;
+  if (MODE == 2 && g.site > 0) ksplits = g.site;      // the group's own split count (launches that mix layers)
   if (MODE == 2 && ksplits > 1) {
     const int per = (nk_all + ksplits - 1) / ksplits;
     kt_lo = split * per;

@@ -93,7 +93,7 @@ __device__ __forceinline__ void mt_head_loss_body(const MtHeadSlot* __restrict__
 #pragma unroll
       for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dot += hv[r][c].get(e) * w[c][e];
+        for (int e = 0; e < 8; ++e) dot = __builtin_fmaf(hv[r][c].get(e), w[c][e], dot);     // explicit: rowblock.hip repeats this chain
       const float out = wave_sum(dot) + bias;
       float l, g;
       loss_and_grad(s.loss_type, out, s.y[i], l, g);
@@ -108,7 +108,7 @@ __device__ __forceinline__ void mt_head_loss_body(const MtHeadSlot* __restrict__
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float h = hv[r][c].get(e);
-            gw[c][e] += dout * h;
+            gw[c][e] = __builtin_fmaf(dout, h, gw[c][e]);
             o[e] = h > 0.f ? dout * w[c][e] : 0.f;
           }
           HRow8<F32>::store(dH, (size_t)i * s.ldh + k0, o);

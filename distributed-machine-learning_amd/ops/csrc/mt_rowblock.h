@@ -1,0 +1,17 @@
+// Arguments of the row-block training kernel (rowblock.hip), shared with the step driver (runtime.hip).
+#pragma once
+#include "mt_common.h"
+
+struct MtRbBlock {
+  int32_t slot, row0;        // slot < 0: padding entry
+};
+
+struct MtRbArgs {
+  const MtGemmGroup* fwd[MT_MAX_LAYERS];       // per layer: the pack's forward groups (indexed by physical slot)
+  const MtGemmGroup* dgrad[MT_MAX_LAYERS];     // per layer: its input-gradient groups
+  const MtHeadSlot* head;
+  const MtRbBlock* blocks;
+  float* scratch;                              // head records, (slot * max_chunks + chunk) * rec
+  int32_t n_hidden, max_chunks, rec, pad;
+};
+

@@ -1,0 +1,498 @@
+// Row-block training kernel for packs of exact-f32 MLP trials (gfx950).
+//
+// Batch rows are independent through the forward pass and through the chain of input gradients; only the weight
+// gradient sums over rows.  So one workgroup takes 16 (or 32) batch rows of ONE trial through
+//     input rows -> every forward layer (+bias, ReLU) -> head + loss + dLoss/dH -> every input-gradient layer (ReLU mask)
+// with the activations of its rows staying in LDS from the first layer to the last: no workgroup ever waits for
+// another, and a training step of a pack is three launches (this one, the weight gradients of all layers, the
+// optimiser) instead of 2 L + 2 chip-wide dependent ones.  What the weight-gradient launch needs is written to memory on
+// the way: H_l for l < L - 1, dZ_l for every l, and the head's partial records {gw, gb, loss} per 16 rows.
+// This is the step of /root/reference/ray-tune-hpo-regression-sample.py:110-120 for one mini-batch slice.
+//
+// Numbers: bit for bit those of the tile kernels (mt_gemm_f32_tile.h, mt_head_body.h).  Every product runs on
+// v_mfma_f32_16x16x4_f32 with the same contraction order per output element -- MFMA number (ks, e) of a 32-deep K-step
+// contracts kk = 16 ks + 4 g + e in lane group g -- bias and ReLU are applied to the finished sum, the mask of the input
+// gradient is (forward output > 0), and the head walks its rows in the order of mt_head_loss_body.  A pack may therefore
+// switch between the two forms from one epoch to the next (the engine picks by pack size) without a trial noticing.
+//
+// Work split inside the workgroup (512 threads = 8 waves): a layer's output columns are cut into tiles of 16; wave w owns
+// tiles w, w + 8, w + 16, w + 24 (layers of up to 512 columns).  The activations [rows][K] are one LDS image that every
+// wave reads (ds_read_b128: four consecutive kk of a row = the B operands of four MFMAs).  A tile's weights are read by
+// nobody else in the workgroup; each wave streams its own through a private LDS ring of 1 KiB fragments (one 16-column
+// tile x 16 kk), filled by LDS-DMA (global_load_lds, 16 bytes a lane) as many K-steps ahead as the ring holds for the
+// wave's tile count -- 3 K-steps for 4 tiles, 12 for one -- and across layer boundaries too: the next layer's first
+// fragments are requested before the current layer's epilogue.  The ring is private, so no barrier guards it: a wave
+// waits for its own DMA with a counted s_waitcnt vmcnt and reads.  (A register ring would do the same job, but the
+// compiler copies its registers wherever two code paths meet and waits for the loads in order to do so.)  Outputs are
+// written back into the same LDS image once every wave has finished reading it (two barriers per layer, the only
+// synchronisation there is).
+#include "mt_head_body.h"
+#include "mt_rowblock.h"
+
+#define RB_THREADS 512
+#define RB_WAVES 8
+#define RB_MAXW 512                              // widest layer / input row the LDS image holds
+#define RB_PITCH (RB_MAXW * 4 + 128)             // bytes per image row; = 128 mod 256, so rows alternate bank halves
+#define RB_TPW (RB_MAXW / 16 / RB_WAVES)         // column tiles per wave
+#define RB_MASK_BYTES (MT_MAX_LAYERS * (RB_MAXW / 16) * 64)
+#define RB_FRAG 1024                             // bytes of one weight fragment: 16 columns x 16 kk of f32
+
+// Pointers read from descriptor tables are generic to the compiler, and loads through them would be flat_load: counted
+// on both wait counters and never left in flight past the next LDS access.  Everything below goes through these
+// global-address-space types instead.
+typedef const __attribute__((address_space(1))) float* rb_gcf;
+typedef __attribute__((address_space(1))) float* rb_gf;
+typedef const __attribute__((address_space(1))) f32x4* rb_gc4;
+typedef __attribute__((address_space(1))) f32x4* rb_g4;
+
+// Byte offset of the 16-byte chunk holding elements k .. k+3 (k % 4 == 0) of image row `row`.
+__device__ __forceinline__ int rb_act_off(int row, int k) {
+  return row * RB_PITCH + ((k >> 5) << 7) + ((((k >> 2) & 7) ^ (row & 7)) << 4);
+}
+
+typedef const __attribute__((address_space(1))) char* rb_gcc;
+
+// A wave-uniform 64-bit value, told to the compiler as such: the weight bases below then live in scalar registers and
+// the fragment loads take the form global_load v, v_offset, s[base] -- one 32-bit vector offset per load instead of a
+// 64-bit vector address computed by the vector ALU for each.
+__device__ __forceinline__ uint64_t rb_uniform64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+struct RbPhase {
+  rb_gcc W;              // forward: [N][ldw] (kk contiguous); input gradient: [K][ldw] (output column contiguous)
+  rb_gcf bias;           // forward only
+  rb_gf out;             // memory copy of the output rows, [B][ldo] (null: not needed)
+  int ldw, ldo, N, K, ns, nn, tv, layer;
+  int depth;             // K-steps (of 16) the wave's ring holds for this layer's tile count
+  uint32_t lane_off;     // byte offset of this lane's 16-byte piece inside a fragment's source block
+};
+
+// Every layer width and the input row length are multiples of 32 (the caller checks): a K-step is always whole and a
+// layer has an even number of 16-column tiles.  CAP: fragments of the wave's ring.
+template <int CAP>
+__device__ __forceinline__ void rb_make_phase(RbPhase& ph, const MtGemmGroup& g, int nn, int layer, int wave, int lane) {
+  ph.W = (rb_gcc)rb_uniform64((uint64_t)g.B);
+  ph.bias = nn ? nullptr : (rb_gcf)rb_uniform64((uint64_t)g.aux);
+  ph.out = (rb_gf)rb_uniform64((uint64_t)g.C);
+  ph.ldw = __builtin_amdgcn_readfirstlane(g.ldb);
+  ph.ldo = __builtin_amdgcn_readfirstlane(g.ldc);
+  ph.N = __builtin_amdgcn_readfirstlane(g.J);
+  ph.K = __builtin_amdgcn_readfirstlane(g.KK);
+  ph.ns = ph.K >> 4;
+  ph.nn = nn;
+  ph.layer = layer;
+  const int ntp = ph.N >> 4;
+  int tv = (ntp - wave + RB_WAVES - 1) / RB_WAVES;
+  ph.tv = tv < 0 ? 0 : (tv > RB_TPW ? RB_TPW : tv);
+  ph.depth = ph.tv > 0 ? CAP / ph.tv : 0;
+  // Forward: the fragment of tile n0, K-step k0 is W[n0 + i][k0 + 4 g .. + 3] for lane (i = lane & 15, g = lane >> 4) --
+  // exactly the lane's own MFMA operand, so each lane later reads back the 16 bytes it fetched.  Input gradient: lane
+  // (rr = lane >> 2, c = lane & 3) fetches W[k0 + r][j0 + 4 c .. + 3] with r = 4 (rr & 3) + (rr >> 2): piece rr * 4 + c
+  // of the fragment then holds row 4 g + e at rr = 4 e + g, which spreads the four ds_read_b32 of a lane group over
+  // all banks.
+  if (nn) {
+    const int rr = lane >> 2, c = lane & 3;
+    const int r = 4 * (rr & 3) + (rr >> 2);
+    ph.lane_off = 4u * ((uint32_t)r * (uint32_t)ph.ldw + 4u * (uint32_t)c);
+  } else {
+    ph.lane_off = 4u * ((uint32_t)(lane & 15) * (uint32_t)ph.ldw + 4u * (uint32_t)(lane >> 4));
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void rb_wait_vm_imm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// Wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform, 0 .. 15).
+__device__ __forceinline__ void rb_wait_vm(int n) {
+  switch (n) {
+    case 0: rb_wait_vm_imm<0>(); break;
+    case 1: rb_wait_vm_imm<1>(); break;
+    case 2: rb_wait_vm_imm<2>(); break;
+    case 3: rb_wait_vm_imm<3>(); break;
+    case 4: rb_wait_vm_imm<4>(); break;
+    case 5: rb_wait_vm_imm<5>(); break;
+    case 6: rb_wait_vm_imm<6>(); break;
+    case 7: rb_wait_vm_imm<7>(); break;
+    case 8: rb_wait_vm_imm<8>(); break;
+    case 9: rb_wait_vm_imm<9>(); break;
+    case 10: rb_wait_vm_imm<10>(); break;
+    case 11: rb_wait_vm_imm<11>(); break;
+    default: rb_wait_vm_imm<12>(); break;
+  }
+}
+
+// Request the fragments of K-step s (16 kk) of the wave's tiles into ring stage `stage`.
+__device__ __forceinline__ void rb_issue_stage(const RbPhase& ph, uint8_t* ring, int stage, int s, int wave) {
+  uint8_t* dst = ring + stage * ph.tv * RB_FRAG;
+  for (int t = 0; t < ph.tv; ++t) {
+    const int c0 = (wave + RB_WAVES * t) * 16;
+    const size_t elem = ph.nn ? (size_t)(s * 16) * ph.ldw + c0 : (size_t)c0 * ph.ldw + s * 16;      // wave-uniform
+    rb_gcc src = ph.W + elem * 4 + (uint64_t)ph.lane_off;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(dst + t * RB_FRAG), 16, 0, 0);
+  }
+}
+
+// The first depth - 1 K-steps of a layer (all of them when the layer has fewer).
+__device__ __forceinline__ void rb_prologue(const RbPhase& ph, uint8_t* ring, int wave) {
+  if (ph.tv == 0) return;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the ring's previous contents are back
+  const int n = (ph.depth - 1 < ph.ns) ? ph.depth - 1 : ph.ns;
+  for (int s = 0; s < n; ++s) rb_issue_stage(ph, ring, s, s, wave);
+}
+
+// K-loop of one layer for a wave with TV tiles; the first K-steps are on their way already (rb_prologue).
+template <int MT, int TV, bool NN>
+__device__ __forceinline__ void rb_kloop(f32x4 (&acc)[RB_TPW][MT], const RbPhase& ph, const uint8_t* act, uint8_t* ring,
+                                         int wave, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int ns = ph.ns, D = ph.depth;
+  int st_issue = (D - 1 < ns) ? D - 1 : ns;      // ring stage of the next K-step to request (= its index while < D)
+  if (st_issue >= D) st_issue -= D;
+  int st_use = 0;
+  // image offsets of this lane's activation chunk in even / odd K-steps (a 32-kk block is 128 bytes of an image row)
+  int aoff[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int row = m * 16 + i;
+    aoff[m][0] = row * RB_PITCH + ((g ^ (row & 7)) << 4);
+    aoff[m][1] = row * RB_PITCH + (((4 + g) ^ (row & 7)) << 4);
+  }
+  const int woff = NN ? ((g << 6) + ((i >> 2) << 4) + ((i & 3) << 2)) : (lane << 4);
+  for (int s = 0; s < ns; ++s) {
+    const int ahead = s + D - 1;
+    if (ahead < ns) {
+      rb_issue_stage(ph, ring, st_issue, ahead, wave);
+      st_issue = (st_issue + 1 == D) ? 0 : st_issue + 1;
+    }
+    const int younger = (ns - 1 - s < D - 1) ? ns - 1 - s : D - 1;     // K-steps requested after K-step s
+    rb_wait_vm(younger * TV);
+    f32x4 a[MT], w[TV];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(act + ((s >> 1) << 7) + aoff[m][s & 1]);
+    const uint8_t* frag = ring + st_use * (TV * RB_FRAG) + woff;
+#pragma unroll
+    for (int t = 0; t < TV; ++t) {
+      if constexpr (!NN) {
+        w[t] = *reinterpret_cast<const f32x4*>(frag + t * RB_FRAG);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[t][e] = *reinterpret_cast<const float*>(frag + t * RB_FRAG + (e << 8));
+      }
+    }
+    st_use = (st_use + 1 == D) ? 0 : st_use + 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < TV; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][e], a[m][e], acc[t][m], 0, 0, 0);
+  }
+}
+
+template <int MT, bool NN>
+__device__ __forceinline__ void rb_run_kloop(f32x4 (&acc)[RB_TPW][MT], const RbPhase& ph, const uint8_t* act, uint8_t* ring,
+                                             int wave, int lane) {
+#pragma unroll
+  for (int t = 0; t < RB_TPW; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  switch (ph.tv) {
+    case 1: rb_kloop<MT, 1, NN>(acc, ph, act, ring, wave, lane); break;
+    case 2: rb_kloop<MT, 2, NN>(acc, ph, act, ring, wave, lane); break;
+    case 3: rb_kloop<MT, 3, NN>(acc, ph, act, ring, wave, lane); break;
+    case 4: rb_kloop<MT, 4, NN>(acc, ph, act, ring, wave, lane); break;
+    default: break;
+  }
+}
+
+__device__ __forceinline__ void rb_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+// The head over the rows of one 16-row record, by the four waves hw = 0..3 of row tile m: the arithmetic of
+// mt_head_loss_body<1, true> (same row -> wave deal, same chains), reading H from the LDS image and leaving dZ of the
+// last layer in its place.  rb_head_fetch asks for what it needs from memory early.
+struct RbHeadRegs {
+  float w[8], y[4], bias;
+};
+
+template <int MT>
+__device__ __forceinline__ void rb_head_fetch(RbHeadRegs& hr, const MtHeadSlot& hs, int row0, int wave, int lane) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) hr.w[e] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) hr.y[q] = 0.f;
+  hr.bias = 0.f;
+  if (wave >= 4 * MT) return;
+  const int m = wave >> 2, hw = wave & 3;
+  const int crow0 = row0 + 16 * m;
+  if (crow0 >= hs.B) return;
+  const int nrows = (hs.B - crow0 < 16) ? hs.B - crow0 : 16;
+  const int k0 = lane * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (k0 + e < hs.W) hr.w[e] = ((rb_gcf)hs.w)[k0 + e];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (hw + 4 * q < nrows) hr.y[q] = ((rb_gcf)hs.y)[crow0 + hw + 4 * q];
+  hr.bias = ((rb_gcf)hs.b)[0];
+}
+
+template <int MT>
+__device__ __forceinline__ void rb_head(const RbHeadRegs& hr, const MtHeadSlot& hs, uint8_t* act, float (*red)[4][RB_MAXW],
+                                        float (*red_s)[4][2], int row0, int wave, int lane) {
+  if (wave >= 4 * MT) return;
+  const int m = wave >> 2, hw = wave & 3;
+  const int crow0 = row0 + 16 * m;
+  if (crow0 >= hs.B) return;
+  const int nrows = (hs.B - crow0 < 16) ? hs.B - crow0 : 16;
+  const int k0 = lane * 8;
+  const bool live = k0 < hs.W;
+  float gw[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) gw[e] = 0.f;
+  const float inv_b = 1.f / (float)hs.B;
+  float loss_sum = 0.f, gb = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = hw + 4 * q;
+    if (r >= nrows) break;
+    const int lr = 16 * m + r;
+    uint8_t* p0 = act + rb_act_off(lr, k0);
+    uint8_t* p1 = act + rb_act_off(lr, k0 + 4);
+    f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
+    if (live) {
+      h0 = *reinterpret_cast<const f32x4*>(p0);
+      h1 = *reinterpret_cast<const f32x4*>(p1);
+    }
+    const float h[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dot = __builtin_fmaf(h[e], hr.w[e], dot);
+    const float out = wave_sum(dot) + hr.bias;
+    float l, gl;
+    loss_and_grad(hs.loss_type, out, hr.y[q], l, gl);
+    const float dout = gl * inv_b;
+    loss_sum += l;
+    gb += dout;
+    if (live) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        gw[e] = __builtin_fmaf(dout, h[e], gw[e]);
+        o[e] = h[e] > 0.f ? dout * hr.w[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(p0) = f32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<f32x4*>(p1) = f32x4{o[4], o[5], o[6], o[7]};
+      rb_gf dst = (rb_gf)hs.dH + (size_t)(crow0 + r) * hs.ldh + k0;
+      *(rb_g4)dst = f32x4{o[0], o[1], o[2], o[3]};
+      *(rb_g4)(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[m][hw][k0 + e] = gw[e];
+  if (lane == 0) {
+    red_s[m][hw][0] = loss_sum;
+    red_s[m][hw][1] = gb;
+  }
+}
+
+template <int MT>
+__device__ __forceinline__ void rb_head_record(const MtHeadSlot& hs, const MtRbArgs& a, int slot, float (*red)[4][RB_MAXW],
+                                               float (*red_s)[4][2], int row0, int wave, int lane) {
+  if (wave >= 4 * MT) return;
+  const int m = wave >> 2;
+  const int crow0 = row0 + 16 * m;
+  if (crow0 >= hs.B) return;
+  const int t4 = (wave & 3) * 64 + lane;
+  const float inv_b = 1.f / (float)hs.B;
+  rb_gf out = (rb_gf)a.scratch + ((size_t)slot * a.max_chunks + (crow0 >> 4)) * a.rec;
+  for (int k = t4; k < hs.W; k += 256) out[k] = (red[m][0][k] + red[m][1][k]) + (red[m][2][k] + red[m][3][k]);
+  if (t4 == 0) {
+    out[a.rec - 2] = (red_s[m][0][1] + red_s[m][1][1]) + (red_s[m][2][1] + red_s[m][3][1]);
+    out[a.rec - 1] = ((red_s[m][0][0] + red_s[m][1][0]) + (red_s[m][2][0] + red_s[m][3][0])) * inv_b;
+  }
+}
+
+// A lane's value that the optimiser must not treat as loop-invariant: what is derived from it (column indices, image
+// offsets) is recomputed where it is used instead of being kept in registers, or spilled, across the layer loops.
+__device__ __forceinline__ int rb_opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// Outputs of the wave's tiles -> the LDS image (in place of the layer's input), between two barriers.
+template <int MT>
+__device__ __forceinline__ void rb_store_image(const f32x4 (&acc)[RB_TPW][MT], uint8_t* act, int tv, int wave, int lane) {
+  rb_lds_barrier();          // every wave has read the layer's input for the last time
+  const int i = rb_opaque(lane & 15), g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < RB_TPW; ++t) {
+    if (t < tv) {
+      const int col = (wave + RB_WAVES * t) * 16 + 4 * g;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(act + rb_act_off(m * 16 + i, col)) = acc[t][m];
+    }
+  }
+  rb_lds_barrier();          // the output image is complete
+}
+
+// LDS of one workgroup: the activation image, the ReLU masks of every layer (one byte per tile and lane), the head's
+// reduction buffers and the eight private weight rings.  16 rows: 34 + 16 + 8 + 96 KiB; 32 rows (at most 4 layers): 68 + 8 +
+// 16 + 64 KiB.
+template <int MT> struct RbCfg {
+  static constexpr int CAP = MT == 1 ? 12 : 8;                 // fragments per wave ring
+  static constexpr int MASK_LAYERS = MT == 1 ? MT_MAX_LAYERS : 4;
+};
+
+template <int MT>
+__global__ __launch_bounds__(RB_THREADS) void mt_mlp_rowblock_kernel(MtRbArgs a, int step_imm,
+                                                                     const int* __restrict__ step_base) {
+  constexpr int RB = 16 * MT, CAP = RbCfg<MT>::CAP;
+  __shared__ __attribute__((aligned(1024))) uint8_t rings[RB_WAVES * CAP * RB_FRAG];
+  __shared__ __attribute__((aligned(16))) uint8_t act[RB * RB_PITCH];
+  __shared__ uint8_t mask[RbCfg<MT>::MASK_LAYERS * (RB_MAXW / 16) * 64];
+  __shared__ float red[MT][4][RB_MAXW];
+  __shared__ float red_s[MT][4][2];
+  static_assert(HL_ROWS == 16, "one head record per 16-row MFMA row tile");
+
+  const int step = mt_step(step_imm, step_base);
+  const MtRbBlock blk = a.blocks[blockIdx.x];
+  if (blk.slot < 0) return;
+  const int slot = blk.slot, row0 = blk.row0;
+  const MtHeadSlot hs = a.head[slot];
+  if (step >= hs.active_steps || row0 >= hs.B) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint8_t* ring = rings + wave * (CAP * RB_FRAG);
+  int L = 0;
+  while (L < a.n_hidden && L < RbCfg<MT>::MASK_LAYERS && a.fwd[L][slot].B != nullptr) ++L;
+  if (L == 0) return;
+
+  f32x4 acc[RB_TPW][MT];
+  RbPhase cur;
+  {
+    const MtGemmGroup g0 = a.fwd[0][slot];
+    rb_make_phase<CAP>(cur, g0, 0, 0, wave, lane);
+    rb_prologue(cur, ring, wave);
+    // the block's input rows -> LDS image (zero beyond the batch, as the tile kernel's staging does)
+    rb_gcf X = (rb_gcf)rb_uniform64((uint64_t)g0.A);
+    const int cpr = cur.K >> 2;                         // 16-byte chunks per image row
+    for (int idx = tid; idx < RB * cpr; idx += RB_THREADS) {
+      const int r = idx / cpr, k = (idx - r * cpr) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row0 + r < hs.B) v = *(rb_gc4)(X + (size_t)(row0 + r) * g0.lda + k);
+      *reinterpret_cast<f32x4*>(act + rb_act_off(r, k)) = v;
+    }
+  }
+  // what the head needs from memory, asked for now: a load waited for later would also wait for every weight fragment
+  // requested in between
+  RbHeadRegs hr;
+  rb_head_fetch<MT>(hr, hs, row0, wave, lane);
+  rb_lds_barrier();
+
+  // ---- forward layers: H_l = relu(H_{l-1} W_l^T + b_l)
+  for (int l = 0; l < L; ++l) {
+    RbPhase nxt = {};
+    if (l + 1 < L) rb_make_phase<CAP>(nxt, a.fwd[l + 1][slot], 0, l + 1, wave, lane);
+    else if (L > 1) rb_make_phase<CAP>(nxt, a.dgrad[L - 1][slot], 1, L - 1, wave, lane);
+    const int i = rb_opaque(lane & 15), g = lane >> 4;
+    // bias of the wave's tiles (the array is padded with zeros to a multiple of 8 columns), waited for before the next
+    // layer's fragments are requested
+    f32x4 bb[RB_TPW];
+#pragma unroll
+    for (int t = 0; t < RB_TPW; ++t) {
+      bb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int col = (wave + RB_WAVES * t) * 16 + 4 * g;
+      if (cur.bias != nullptr && t < cur.tv) bb[t] = *(rb_gc4)(cur.bias + col);
+    }
+    rb_run_kloop<MT, false>(acc, cur, act, ring, wave, lane);
+#pragma unroll
+    for (int t = 0; t < RB_TPW; ++t) asm volatile("" : "+v"(bb[t]));
+    rb_prologue(nxt, ring, wave);
+
+    const bool to_mem = cur.out != nullptr && l + 1 < L;     // H of the last layer is consumed by the head below, from LDS
+#pragma unroll
+    for (int t = 0; t < RB_TPW; ++t) {
+      if (t < cur.tv) {
+        const int tile = wave + RB_WAVES * t;
+        const int col = tile * 16 + 4 * g;
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f32x4 v = acc[t][m] + bb[t];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = fmaxf(v[j], 0.f);
+            bits |= (v[j] > 0.f ? 1u : 0u) << (m * 4 + j);
+          }
+          acc[t][m] = v;
+          const int row = row0 + m * 16 + i;
+          if (to_mem && row < hs.B) *(rb_g4)(cur.out + (size_t)row * cur.ldo + col) = v;
+        }
+        mask[(l * (RB_MAXW / 16) + tile) * 64 + lane] = (uint8_t)bits;
+      }
+    }
+    rb_store_image<MT>(acc, act, cur.tv, wave, lane);
+    cur = nxt;
+  }
+
+  // ---- head, loss, dLoss/dH of the last layer (left in the image)
+  rb_head<MT>(hr, hs, act, red, red_s, row0, wave, lane);
+  rb_lds_barrier();
+  rb_head_record<MT>(hs, a, slot, red, red_s, row0, wave, lane);
+
+  // ---- input gradients: dZ_{l-1} = (dZ_l W_l) * (H_{l-1} > 0), l = L-1 .. 1
+  for (int l = L - 1; l >= 1; --l) {
+    RbPhase nxt = {};
+    if (l > 1) rb_make_phase<CAP>(nxt, a.dgrad[l - 1][slot], 1, l - 1, wave, lane);
+    rb_run_kloop<MT, true>(acc, cur, act, ring, wave, lane);
+    rb_prologue(nxt, ring, wave);
+    const int i = rb_opaque(lane & 15), g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < RB_TPW; ++t) {
+      if (t < cur.tv) {
+        const int tile = wave + RB_WAVES * t;
+        const int col = tile * 16 + 4 * g;
+        const uint32_t bits = mask[((l - 1) * (RB_MAXW / 16) + tile) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f32x4 v = acc[t][m];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ((bits >> (m * 4 + j)) & 1u) ? v[j] : 0.f;
+          acc[t][m] = v;
+          const int row = row0 + m * 16 + i;
+          if (cur.out != nullptr && row < hs.B) *(rb_g4)(cur.out + (size_t)row * cur.ldo + col) = v;
+        }
+      }
+    }
+    if (l > 1) rb_store_image<MT>(acc, act, cur.tv, wave, lane);      // the last input gradient is read by nobody in here
+    cur = nxt;
+  }
+}
+
+extern "C" int mt_rb_args_sizeof() { return (int)sizeof(MtRbArgs); }
+extern "C" int mt_rowblock_max_width() { return RB_MAXW; }
+
+// blocks: n_blocks entries (slot, first row), one workgroup each; rows per workgroup = 16 * mt (mt = 1 or 2), and a
+// slot's entries must cover its batch in steps of that many rows.  Every layer of every listed slot must be at most
+// mt_rowblock_max_width() wide (input rows included); the caller checks (the tables live in device memory).
+extern "C" int mt_mlp_rowblock_launch(const MtRbArgs* args, int n_blocks, int mt, int step, hipStream_t stream) {
+  if (n_blocks <= 0) return 0;
+  if (args == nullptr || args->n_hidden < 1 || args->n_hidden > MT_MAX_LAYERS || args->blocks == nullptr ||
+      args->head == nullptr || args->scratch == nullptr || args->rec < 10 || args->max_chunks < 1)
+    return -2;
+  if (mt == 1)
+    hipLaunchKernelGGL(mt_mlp_rowblock_kernel<1>, dim3(n_blocks), dim3(RB_THREADS), 0, stream, *args, step, mt_step_base_tls);
+  else if (mt == 2)
+    hipLaunchKernelGGL(mt_mlp_rowblock_kernel<2>, dim3(n_blocks), dim3(RB_THREADS), 0, stream, *args, step, mt_step_base_tls);
+  else
+    return -2;
+  return (int)hipGetLastError();
+}

@@ -9,9 +9,9 @@
 //   dgrad(+ReLU mask) of layer l in ONE launch } -> [grad sq-norm partials] -> fused per-trial optimiser
 //   (+bf16 shadow refresh), i.e. 2L + 4 (+1) launches regardless of how many trials share the GPU.
 #include "mt_bodies.h"
+#include "mt_rowblock.h"
 #include <stdlib.h>
 
-#define MT_MAX_LAYERS 8
 
 extern "C" {
 int mt_gemm_launch(int mode, const MtGemmGroup* groups, const MtTile* tiles, int ntiles, int step, int flags,
@@ -48,6 +48,7 @@ int mt_optim_gather_launch(float* P, const float* G, float* M, float* V, void* P
                            const int32_t* ids, int n_active, int max_params, float* partials, int max_blocks, int use_clip,
                            int step, int gsplits, size_t gsplit_stride, const MtGatherSlot* gslots, const float* X,
                            const float* Y, uint32_t n_rows, int F, int Fpad, int hb, int max_batch, hipStream_t stream);
+int mt_mlp_rowblock_launch(const MtRbArgs* args, int n_blocks, int mt, int step, hipStream_t stream);
 }
 
 struct MtMlpPlan {
@@ -89,6 +90,15 @@ struct MtMlpPlan {
   // 5 = 64 deep (f32 packs only)
   int32_t fwd_big[MT_MAX_LAYERS];
   int32_t bwd_big[MT_MAX_LAYERS];
+  // Row-block form of the step (exact-f32 packs; rb_nblocks > 0 selects it): one launch takes every 16 * rb_mt rows of
+  // every trial through all forward layers, the head and all input gradients (rowblock.hip), a second one computes the
+  // weight gradients of ALL layers (wg_all_*: the per-layer group tables concatenated, group = layer * capacity + slot,
+  // each group carrying its own split count) and adds up the head records, the third is the optimiser.
+  const MtRbBlock* rb_blocks;
+  int32_t rb_nblocks, rb_mt;
+  const MtGemmGroup* wg_all_groups;
+  const MtTile* wg_all_tiles;
+  int32_t wg_all_ntiles, wg_all_edge;
 };
 
 thread_local const int* mt_step_base_tls = nullptr;
@@ -142,6 +152,27 @@ static int mlp_enqueue_steps(const MtMlpPlan* p, int step0, int nsteps, hipStrea
                                (p->max_batch + HL_ROWS - 1) / HL_ROWS, ((p->max_width + 7) / 8) * 8 + 8};
   const MtHeadReduceArgs no_hr = {nullptr, nullptr, nullptr, 0, 0, 0};
   if (first_gather) MT_TRY(plan_gather(p, step0, stream));
+  if (p->rb_nblocks > 0) {
+    if (!p->f32 || p->rb_blocks == nullptr || p->wg_all_groups == nullptr || p->wg_all_tiles == nullptr) return -17;
+    MtRbArgs ra = {};
+    for (int l = 0; l < L; ++l) { ra.fwd[l] = p->fwd_groups[l]; ra.dgrad[l] = p->dgrad_groups[l]; }
+    ra.head = p->head;
+    ra.blocks = p->rb_blocks;
+    ra.scratch = p->head_scratch;
+    ra.n_hidden = L;
+    ra.max_chunks = hr.max_chunks;
+    ra.rec = hr.rec;
+    for (int step = step0; step < step0 + nsteps; ++step) {
+      MT_TRY(mt_mlp_rowblock_launch(&ra, p->rb_nblocks, p->rb_mt, step, stream));
+      MT_TRY(mt_gemm_f32_bwd_head_launch(p->wg_all_groups, p->wg_all_tiles, p->wg_all_ntiles, nullptr, nullptr, 0, step,
+                                         p->ksplits, p->gsplit_stride, f32_edge(p->wg_all_edge), hr, stream));
+      MT_TRY(mt_optim_gather_launch(p->P, p->G, p->M, p->V, p->Pb, p->slot_stride, p->opt, p->active_ids, p->n_active,
+                                    p->max_params, p->partials, p->max_blocks, p->use_clip, step, p->ksplits,
+                                    p->gsplit_stride, p->gather, p->X, p->Y, p->n_rows, p->F, p->Fpad, p->hb,
+                                    p->max_batch, stream));
+    }
+    return 0;
+  }
   for (int step = step0; step < step0 + nsteps; ++step) {
     for (int l = 0; l < L; ++l) MT_TRY(plan_forward(p, l, step, 0, 0, stream));
     if (p->f32)

@@ -66,22 +66,10 @@ class MlpPlan(C.Structure):
                 ("Pb", c_void_p), ("slot_stride", c_size_t), ("opt", c_void_p), ("partials", c_void_p),
                 ("active_ids", c_void_p), ("head_scratch", c_void_p), ("max_blocks", c_int32), ("ksplits", c_int32),
                 ("gsplit_stride", c_size_t), ("ksplits0", c_int32), ("f32", c_int32),
-                ("fwd_big", c_int32 * MT_MAX_LAYERS), ("bwd_big", c_int32 * MT_MAX_LAYERS)]
-
-
-class ResidentArgs(C.Structure):
-    """Mirror of ``MtResidentArgs`` (csrc/resident.hip): what the resident epoch kernel of an exact-f32 MLP pack reads."""
-    _fields_ = [("fwd", c_void_p * MT_MAX_LAYERS), ("dgrad", c_void_p * MT_MAX_LAYERS), ("wgrad", c_void_p * MT_MAX_LAYERS),
-                ("gather", c_void_p), ("head", c_void_p), ("opt", c_void_p), ("slot_list", c_void_p),
-                ("groups", c_void_p), ("wgs", c_void_p), ("P", c_void_p), ("G", c_void_p), ("M", c_void_p),
-                ("V", c_void_p), ("X", c_void_p), ("Y", c_void_p), ("head_scratch", c_void_p), ("sync", c_void_p),
-                ("error", c_void_p), ("timeout_ticks", C.c_uint64), ("slot_stride", c_size_t), ("n_rows", c_uint32),
-                ("F", c_int32), ("Fpad", c_int32), ("hb", c_int32), ("n_hidden", c_int32), ("max_chunks", c_int32),
-                ("rec", c_int32), ("sync_mode", c_int32), ("prof", c_void_p)]
-
-
-RES_GROUP_DTYPE = np.dtype([("first", "<i4"), ("count", "<i4"), ("nwg", "<i4"), ("pad", "<i4")], align=True)
-RES_WG_DTYPE = np.dtype([("group", "<i4"), ("member", "<i4")], align=True)
+                ("fwd_big", c_int32 * MT_MAX_LAYERS), ("bwd_big", c_int32 * MT_MAX_LAYERS),
+                ("rb_blocks", c_void_p), ("rb_nblocks", c_int32), ("rb_mt", c_int32),
+                ("wg_all_groups", c_void_p), ("wg_all_tiles", c_void_p), ("wg_all_ntiles", c_int32),
+                ("wg_all_edge", c_int32)]
 
 
 class DpPlan(C.Structure):
@@ -128,6 +116,7 @@ def gemm_group(A, B, C, aux, aux_out, I, J, KK, lda, ldb, ldc, ldaux, active_ste
     """One record of ``GEMM_GROUP_DTYPE`` (field order of ``MtGemmGroup``); the trailing per-group extras default off."""
     return (A, B, C, aux, aux_out, seed, I, J, KK, lda, ldb, ldc, ldaux, active_steps, thresh, scale, gflags, site)
 TILE_DTYPE = np.dtype([("group", "<i4"), ("ti", "<i2"), ("tj", "<i2")], align=True)
+RB_BLOCK_DTYPE = np.dtype([("slot", "<i4"), ("row0", "<i4")], align=True)
 GATHER_DTYPE = np.dtype([("X0", "<u8"), ("y", "<u8"), ("key", "<u4", (4,)), ("B", "<i4"), ("active_steps", "<i4")],
                         align=True)
 HEAD_DTYPE = np.dtype([("H", "<u8"), ("dH", "<u8"), ("w", "<u8"), ("b", "<u8"), ("gw", "<u8"), ("gb", "<u8"),
@@ -299,6 +288,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
                lib.mt_dwconv_chunks, lib.mt_dwconv_launch, lib.mt_dwconv_wgrad_launch, lib.mt_head_mlp_fwd_launch,
                lib.mt_head_mlp_bwd_launch):
         fn.restype = C.c_int
+    lib.mt_rowblock_max_width.restype = C.c_int
     lib.mt_mlp_train_steps.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]
     lib.mt_mlp_eval.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]
     lib.mt_mlp_graph_create.argtypes = [C.POINTER(MlpPlan), C.c_int, c_void_p, c_void_p, C.POINTER(C.c_int)]
@@ -314,12 +304,6 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     for fn in (lib.mt_gemm_launch, lib.mt_gather_launch, lib.mt_head_loss_launch, lib.mt_head_eval_launch,
                lib.mt_optim_launch, lib.mt_mlp_train_steps, lib.mt_mlp_eval):
         fn.restype = C.c_int
-    if lib.mt_resident_args_sizeof() != C.sizeof(ResidentArgs):
-        raise KernelLibraryError("MtResidentArgs layout mismatch between lib.py and the library")
-    lib.mt_mlp_resident_capacity.argtypes = [C.c_int]
-    lib.mt_mlp_resident_capacity.restype = C.c_int
-    lib.mt_mlp_resident_launch.argtypes = [C.POINTER(ResidentArgs), C.c_int, C.c_int, C.c_int, c_void_p]
-    lib.mt_mlp_resident_launch.restype = C.c_int
     _lib = lib
     return lib
 

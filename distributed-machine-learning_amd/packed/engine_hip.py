@@ -75,20 +75,16 @@ F32_CHAIN_RULE = _chain_rule(os.environ.get("MITUNE_F32_CHAIN_RULE", "128:4,32:2
 # chains of large batches finish early and the long chain of small batches carries no dead tiles ("0": the mixed deal).
 CHAINS_BY_BATCH = os.environ.get("MITUNE_CHAINS_BY_BATCH", "1") != "0"
 DTYPES = ("bf16", "f32")
-# Resident epochs (exact-f32 packs): instead of one chain of grouped launches per step, ONE launch per epoch in which
-# groups of workgroups each train their own list of trials, step after step, synchronised only inside the group
-# (ops/csrc/resident.hip).  Bit-identical to the grouped launches, and OFF by default: on 16 late-round survivors it
-# measured 436 us per step of the longest trial against 140 us for the grouped launches.  A group barrier costs 8-16 us
-# (device-scope write-back and invalidate, the wait for the slowest member) and there are 2L + 2 of them per step, and with
-# the two workgroups per CU that the kernel's registers allow, a tile's K-loop runs at memory latency (about 1.4 us per
-# 32-deep step, where five co-resident workgroups of a grouped launch overlap it).  "auto": packs of up to RES_MAX_SLOTS
-# trials whose shapes the kernel covers; "1": any such pack; "0": never.
-RESIDENT = os.environ.get("MITUNE_RESIDENT", "0")
-RES_MAX_SLOTS = int(os.environ.get("MITUNE_RES_MAX_SLOTS", "64"))
-RES_GMIN = int(os.environ.get("MITUNE_RES_GMIN", "8"))            # fewest workgroups a group is given
-RES_TILE = int(os.environ.get("MITUNE_RES_TILE", "0"))            # 64 or 32; 0: by pack size
-RES_TIMEOUT_S = float(os.environ.get("MITUNE_RES_TIMEOUT_S", "20"))
-
+# Row-block form of the exact-f32 training step (ops/csrc/rowblock.hip): one launch carries 16 batch rows of a trial
+# through every forward layer, the head and every input gradient with the activations staying in LDS, a second one
+# computes the weight gradients of all layers, the third is the optimiser -- three launches per step instead of 2 L + 2,
+# and no chip-wide dependency between layers.  It is bit-identical to the tile launches, so the engine is free to pick
+# per chain: "auto" takes it for chains of at most ROWBLOCK_MAX_BLOCKS 16-row blocks (the late rounds of a search, where a
+# step is bound by launch latencies), "1" whenever the shapes allow (every width and the feature count a multiple of 32,
+# at most 512), "0" never.
+ROWBLOCK = os.environ.get("MITUNE_ROWBLOCK", "auto")
+ROWBLOCK_MAX_BLOCKS = int(os.environ.get("MITUNE_ROWBLOCK_MAX_BLOCKS", "640"))
+ROWBLOCK_ROWS = 16
 
 def ceil8(x: int) -> int:
     return (x + 7) // 8 * 8
@@ -142,18 +138,21 @@ gemm_group = L.gemm_group
 def balanced_tiles(groups: List[Tuple[int, int, int, int]], ksplits: int = 1) -> np.ndarray:
     """XCD-aware tile list (``ksplits`` > 1: one entry per contraction split, index in the high byte of ``ti``).
 
-    ``groups`` holds (group index, tiles_i, tiles_j, weight).  Workgroup ids are dealt round-robin to
+    ``groups`` holds (group index, tiles_i, tiles_j, weight) or (..., weight, splits) for a group with its own number of
+    contraction splits.  Workgroup ids are dealt round-robin to
     the 8 XCDs, each with its own L2, so all tiles of one group (which share that group's operands)
     are given ids with equal ``id % 8``: groups go to the currently lightest of 8 buckets, heaviest
     first, and the buckets are interleaved; short buckets are padded with group = -1 entries.
     """
     buckets: List[List[Tuple[int, int, int]]] = [[] for _ in range(N_XCD)]
     load = [0] * N_XCD
-    for gi, ti_n, tj_n, w in sorted(groups, key=lambda g: (-g[3] * g[1] * g[2], g[0])):
+    for grp in sorted(groups, key=lambda g: (-g[3] * g[1] * g[2], g[0])):
+        gi, ti_n, tj_n, w = grp[:4]
+        splits = grp[4] if len(grp) > 4 else ksplits
         b = min(range(N_XCD), key=lambda k: (load[k], k))
         for ti in range(ti_n):
             for tj in range(tj_n):
-                for sp in range(ksplits):
+                for sp in range(splits):
                     buckets[b].append((gi, ti | (sp << 8), tj))
         load[b] += ti_n * tj_n * max(w, 1)
     depth = max((len(b) for b in buckets), default=0)
@@ -163,66 +162,6 @@ def balanced_tiles(groups: List[Tuple[int, int, int, int]], ksplits: int = 1) ->
         for k, (gi, ti, tj) in enumerate(buckets[b]):
             out[k * N_XCD + b] = (gi, ti, tj)
     return out
-
-
-def resident_layout(costs: List[float], useful: List[int], n_wgs: int, gmin: int = 8):
-    """Cut ``n_wgs`` resident workgroups into groups and deal the trials of a pack to them.
-
-    ``costs[i]`` is trial i's arithmetic for the epoch, ``useful[i]`` the largest number of work items any of its phases
-    has (more workgroups than that would idle at every barrier).  There are as many groups as trials, or as many as
-    ``n_wgs // gmin`` when that is fewer; trials go to groups heaviest first, each to the group with the least work so
-    far (so a group's list is trained one trial after the other), and a group gets workgroups in proportion to its
-    work, at least ``gmin`` and at most what its widest trial can use.  Returns ``(groups, order, wgs)``: ``groups`` as
-    ``(first, count, nwg)`` into ``order`` (indices into ``costs``), and ``wgs`` -- one ``(group, member)`` per workgroup
-    of the grid, -1 for padding -- laid out so that a group's members are consecutive positions of one XCD wherever it
-    fits (workgroup b runs on XCD ``b % 8``; position p = xcd * per_xcd + index <-> b = index * 8 + xcd).
-    """
-    n = len(costs)
-    if n == 0 or n_wgs < gmin:
-        raise ValueError("no trials or fewer workgroups than one group takes")
-    n_groups = max(1, min(n, n_wgs // gmin))
-    lists: List[List[int]] = [[] for _ in range(n_groups)]
-    load = [0.0] * n_groups
-    for i in sorted(range(n), key=lambda k: (-costs[k], k)):
-        g = min(range(n_groups), key=lambda k: (load[k], k))
-        lists[g].append(i)
-        load[g] += max(costs[i], 1e-9)
-    total = sum(load)
-    cap = [max(gmin, max(useful[i] for i in lst)) for lst in lists]
-    nwg = [gmin] * n_groups
-    spare = n_wgs - gmin * n_groups
-    # proportional shares above the floor, capped; what the caps give back goes round once more
-    for _ in range(3):
-        open_ = [g for g in range(n_groups) if nwg[g] < cap[g]]
-        if spare <= 0 or not open_:
-            break
-        wsum = sum(load[g] for g in open_)
-        given = 0
-        for g in open_:
-            add = min(cap[g] - nwg[g], int(spare * load[g] / wsum))
-            nwg[g] += add
-            given += add
-        if given == 0:
-            break
-        spare -= given
-    used = sum(nwg)
-    per = (used + N_XCD - 1) // N_XCD
-    grid = per * N_XCD
-    wgs = np.zeros(grid, dtype=L.RES_WG_DTYPE)
-    wgs["group"] = -1
-    groups, order = [], []
-    # positions: big groups first, each XCD filled in turn; a group that does not fit the rest of an XCD simply runs over
-    pos = 0
-    for g in sorted(range(n_groups), key=lambda k: (-nwg[k], k)):
-        gi = len(groups)
-        groups.append((len(order), len(lists[g]), nwg[g]))
-        order.extend(lists[g])
-        for m in range(nwg[g]):
-            p = pos + m
-            xcd, idx = divmod(p, per)
-            wgs[idx * N_XCD + xcd] = (gi, m)
-        pos += nwg[g]
-    return groups, order, wgs
 
 
 class HipPackEngine(PackEngine):
@@ -310,11 +249,6 @@ class HipPackEngine(PackEngine):
         self._chain_scratch = [torch.zeros_like(self.head_scratch) for _ in range(MAX_STREAMS - 1)]
         self._chains: List[_Chain] = []
         self.n_streams_override = int(os.environ.get("MITUNE_STREAMS", kw.get("streams", 0)) or 0)
-        self._res: Optional[Dict[str, Any]] = None      # resident-epoch launch state of the current pack (or None)
-        self._res_sync = torch.zeros(max(T, 8), device=dev, dtype=torch.int32)
-        self._res_error = torch.zeros(1, device=dev, dtype=torch.int32)
-        self._res_launched = False
-        self.resident_epochs = 0
         self._train_loss: Dict[int, float] = {}
         self._loss_pending = False          # the epoch's loss accumulators have not been read by the host yet
         self._round_steps: Dict[int, int] = {}
@@ -556,6 +490,9 @@ class HipPackEngine(PackEngine):
         # what the GEMMs read as the weight operand: the f32 masters themselves, or their bf16 shadow
         w_base, wb = (p_base, 4) if self.f32 else (self.Pb.data_ptr(), 2)
         x0_stride = self.rows_max * self.Fpad * self.eb
+        rb_mt = 0 if eval_mode else self._rowblock_mt(ids)
+        wg_all = np.zeros(Lmax * T, dtype=L.GEMM_GROUP_DTYPE) if rb_mt else None
+        wl_all = []
         for l in range(Lmax):
             fwd = np.zeros(T, dtype=L.GEMM_GROUP_DTYPE)
             dg = np.zeros(T, dtype=L.GEMM_GROUP_DTYPE)
@@ -588,6 +525,13 @@ class HipPackEngine(PackEngine):
                                       g_base + (base + lay.b_off[l]) * 4,
                                       h, k_real, bsz, o_ld, k_ld, k_ld, 0, steps)
                 wl.append((slot, h, k_real, (bsz + 63) // 64))
+                if rb_mt:      # the same group once more in the table of ALL layers, carrying its layer's split count
+                    ks_l = ksplits0 if l == 0 else ksplits
+                    wg_all[l * T + slot] = gemm_group(self._act_ptr(self.dZ[l], slot), a_in,
+                                                      g_base + (base + lay.w_off[l]) * 4, 0,
+                                                      g_base + (base + lay.b_off[l]) * 4,
+                                                      h, k_real, bsz, o_ld, k_ld, k_ld, 0, steps, site=ks_l)
+                    wl_all.append((l * T + slot, h, k_real, (bsz + 63) // 64, ks_l))
             def tiled(lst, edge):
                 return [(g_, (r_ + edge - 1) // edge, (c_ + edge - 1) // edge, w_) for g_, r_, c_, w_ in lst]
 
@@ -620,7 +564,64 @@ class HipPackEngine(PackEngine):
                 dt, wt = balanced_tiles(tiled(dl, edge)), balanced_tiles(tiled(wl, edge), ksplits0 if l == 0 else ksplits)
                 out[f"dgrad{l}"] = (self._upload(f"{tag}dg_g{l}", dg), self._upload(f"{tag}dg_t{l}", dt), len(dt))
                 out[f"wgrad{l}"] = (self._upload(f"{tag}wg_g{l}", wg), self._upload(f"{tag}wg_t{l}", wt), len(wt))
+        out["rb_mt"] = rb_mt
+        if rb_mt:
+            def n_tiles(edge):
+                return sum(((r_ + edge - 1) // edge) * ((c_ + edge - 1) // edge) * sp_ for _, r_, c_, _, sp_ in wl_all)
+            edge = SMALL_TILE if n_tiles(TILE) < F32_SMALL_TILES else TILE
+            if n_tiles(SMALL_TILE) < F32_TINY_TILES:
+                edge = TINY_TILE
+            wt = balanced_tiles([(g_, (r_ + edge - 1) // edge, (c_ + edge - 1) // edge, w_, sp_)
+                                 for g_, r_, c_, w_, sp_ in wl_all])
+            out["wg_all"] = (self._upload(f"{tag}wg_all_g", wg_all), self._upload(f"{tag}wg_all_t", wt), len(wt),
+                             {TILE: 0, SMALL_TILE: 2, TINY_TILE: 3}[edge])
+            out["rb_blocks"] = self._rowblock_blocks(ids, rb_mt, tag)
         return out
+
+    def _rowblock_mt(self, ids: List[int]) -> int:
+        """Row tiles per workgroup of the row-block step for this chain (1 = 16 rows), or 0 when the chain trains by tile
+        launches: a bf16 pack, a shape the kernel does not cover, or (in "auto") too many blocks for the form to pay."""
+        if not self.f32 or ROWBLOCK == "0":
+            return 0
+        wmax = int(self.lib.mt_rowblock_max_width())
+        if self.F % 32 or self.F > wmax or self.Fpad != self.F:
+            return 0
+        blocks = 0
+        for slot in ids:
+            s = self.slots[slot]
+            if any(h % 32 or h > wmax for h in s.layout.hidden) or len(s.layout.hidden) > L.MT_MAX_LAYERS:
+                return 0
+            blocks += (min(s.spec.batch_size, self.n_train) + ROWBLOCK_ROWS - 1) // ROWBLOCK_ROWS
+        if ROWBLOCK != "1" and blocks > ROWBLOCK_MAX_BLOCKS:
+            return 0
+        return 1
+
+    def _rowblock_blocks(self, ids: List[int], mt: int, tag: str) -> Tuple[int, int]:
+        """(device pointer, count) of the row-block work list: one (slot, first row) entry per workgroup.  All blocks of a
+        trial go to one XCD (workgroup b runs on XCD b % 8; they stream the same weights from that XCD's L2), trials are
+        dealt to the XCDs heaviest first, each to the XCD with the least work so far, and an XCD's list starts with its
+        heaviest blocks, so that the long chains start first and the short ones fill in behind them."""
+        rows = ROWBLOCK_ROWS * mt
+        per_xcd: List[List[Tuple[float, int, int]]] = [[] for _ in range(N_XCD)]
+        load = [0.0] * N_XCD
+        costs = []
+        for slot in ids:
+            lay = self.slots[slot].layout
+            macs = sum(h * k for h, k in zip(lay.hidden, lay.in_dims)) + sum(h * k for h, k in zip(lay.hidden[1:], lay.in_dims[1:]))
+            costs.append((float(macs), slot))
+        for macs, slot in sorted(costs, key=lambda c: (-c[0], c[1])):
+            x = min(range(N_XCD), key=lambda k: (load[k], k))
+            b = min(self.slots[slot].spec.batch_size, self.n_train)
+            nblk = (b + rows - 1) // rows
+            per_xcd[x].extend((macs, slot, r * rows) for r in range(nblk))
+            load[x] += macs * nblk
+        depth = max(len(v) for v in per_xcd)
+        arr = np.zeros(depth * N_XCD, dtype=L.RB_BLOCK_DTYPE)
+        arr["slot"] = -1
+        for x in range(N_XCD):
+            for k, (_, slot, row0) in enumerate(sorted(per_xcd[x], key=lambda e: (-e[0], e[1], e[2]))):
+                arr[k * N_XCD + x] = (slot, row0)
+        return self._upload(f"{tag}rb_blocks", arr), len(arr)
 
     def _build_plan(self, eval_mode: bool, slot_ids: Optional[List[int]] = None, tag: Optional[str] = None,
                     scratch: Optional[torch.Tensor] = None) -> L.MlpPlan:
@@ -649,6 +650,10 @@ class HipPackEngine(PackEngine):
             if not eval_mode:
                 plan.dgrad_groups[l], plan.dgrad_tiles[l], plan.dgrad_ntiles[l] = gt[f"dgrad{l}"]
                 plan.wgrad_groups[l], plan.wgrad_tiles[l], plan.wgrad_ntiles[l] = gt[f"wgrad{l}"]
+        if gt.get("rb_mt"):
+            plan.rb_mt = gt["rb_mt"]
+            plan.rb_blocks, plan.rb_nblocks = gt["rb_blocks"]
+            plan.wg_all_groups, plan.wg_all_tiles, plan.wg_all_ntiles, plan.wg_all_edge = gt["wg_all"]
         head = np.zeros(T, dtype=L.HEAD_DTYPE)
         for slot, s in members:
             lay, last = s.layout, len(s.layout.hidden) - 1
@@ -770,135 +775,18 @@ class HipPackEngine(PackEngine):
                 if not ch.graph:
                     raise L.KernelLibraryError(f"hipGraph capture of a training block failed with code {err.value}")
 
-    # ------------------------------------------------------------------ resident epochs
-    def _resident_reason(self) -> Optional[str]:
-        """None when this pack can train as one resident launch per epoch, else why not."""
-        if RESIDENT == "0" or not self.f32:
-            return "off"
-        if self.n_streams_override:
-            return "explicit stream count"
-        if RESIDENT != "1" and len(self.slots) > RES_MAX_SLOTS:
-            return "pack too large"
-        if self.Fpad // 4 > 256:
-            return "rows too wide for the gather"
-        for s in self.slots.values():
-            if s.spec.gradient_clipping > 0:
-                return "gradient clipping needs the norm of the whole gradient before the update"
-            if s.layout.hidden[-1] > 512:
-                return "last hidden layer wider than 512"
-        return None
-
-    def _slot_cost(self, s: "_HSlot", edge: int) -> Tuple[float, int]:
-        """(arithmetic of one epoch, most work items in any phase) of a trial under tile edge ``edge``."""
-        lay, b = s.layout, min(s.spec.batch_size, self.n_train)
-        steps = self.n_train // b
-        t = lambda v: (v + edge - 1) // edge      # noqa: E731
-        macs, items = lay.hidden[-1], 0
-        for l, h in enumerate(lay.hidden):
-            k = lay.in_dims[l]
-            macs += h * k
-            items = max(items, t(b) * t(h), t(h) * t(k) + (t(b) * t(k) if l > 0 else 0))
-        return 6.0 * macs * b * steps, items
-
-    def _build_resident(self) -> None:
-        ids = sorted(self.slots)
-        cap64, cap32 = (int(self.lib.mt_mlp_resident_capacity(e)) for e in (64, 32))
-        if cap64 <= 0 or cap32 <= 0:
-            raise L.KernelLibraryError("the runtime reports no occupancy for the resident epoch kernel")
-        edge = RES_TILE if RES_TILE in (32, 33, 64, 65) else (32 if len(ids) * 24 <= cap32 else 64)
-        n_wgs = int(self.lib.mt_mlp_resident_capacity(edge))
-        if n_wgs <= 0:
-            raise L.KernelLibraryError("the runtime reports no occupancy for the resident epoch kernel")
-        cap_env = int(os.environ.get("MITUNE_RES_WGS", "0"))
-        if cap_env > 0:
-            n_wgs = min(n_wgs, cap_env)
-        cu = [self._slot_cost(self.slots[k], 32 if edge in (32, 33) else 64) for k in ids]
-        groups, order, wgs = resident_layout([c for c, _ in cu], [u for _, u in cu], n_wgs, RES_GMIN)
-        self._pack_ksplits = (1, 1)            # unsplit weight gradients: every tile holds its whole contraction
-        try:
-            plan = self._build_plan(False, ids, "r_")
-        finally:
-            self._pack_ksplits = None
-        a = L.ResidentArgs()
-        for l in range(plan.n_hidden):
-            a.fwd[l], a.dgrad[l], a.wgrad[l] = plan.fwd_groups[l], plan.dgrad_groups[l], plan.wgrad_groups[l]
-        garr = np.array([(f, c, n, 0) for f, c, n in groups], dtype=L.RES_GROUP_DTYPE)
-        a.slot_list = self._upload("r_slot_list", np.array([ids[i] for i in order], dtype=np.int32))
-        a.groups = self._upload("r_groups", garr)
-        a.wgs = self._upload("r_wgs", wgs)
-        a.head = plan.head
-        a.P, a.G, a.M, a.V = plan.P, plan.G, plan.M, plan.V
-        a.X, a.Y = plan.X, plan.Y
-        a.head_scratch = plan.head_scratch
-        a.sync, a.error = self._res_sync.data_ptr(), self._res_error.data_ptr()
-        a.timeout_ticks = int(RES_TIMEOUT_S * 1e8)              # 100 MHz clock
-        a.slot_stride, a.n_rows = plan.slot_stride, plan.n_rows
-        a.F, a.Fpad, a.hb, a.n_hidden = plan.F, plan.Fpad, plan.hb, plan.n_hidden
-        rows = max(s.spec.batch_size for s in self.slots.values())
-        width = max(max(s.spec.hidden_sizes) for s in self.slots.values())
-        a.max_chunks, a.rec = (rows + 31) // 32, ceil8(width) + 8      # layout of the head kernel's partial records
-        a.sync_mode = int(os.environ.get("MITUNE_RES_SYNC", "0"))
-        if os.environ.get("MITUNE_RES_PROF"):
-            self._res_prof = torch.zeros(8, device=self.device, dtype=torch.int64)
-            a.prof = self._res_prof.data_ptr()
-        if len(groups) > self._res_sync.numel():
-            raise L.KernelLibraryError("more resident groups than arrival counters")
-        self._res = {"args": a, "plan": plan, "ids": ids, "n_wgs": len(wgs), "n_groups": len(groups), "edge": edge,
-                     "groups": groups}
-        if os.environ.get("MITUNE_CHAIN_DEBUG"):
-            import sys
-            print(f"[mitune] resident: {len(ids)} trials, {len(groups)} groups of {sorted({n for _, _, n in groups})} "
-                  f"workgroups, grid {len(wgs)}, tile {edge}", file=sys.stderr, flush=True)
-
-    def _check_resident(self) -> None:
-        """Raise if the previous resident launch gave up at a barrier (reads one word: waits for that launch)."""
-        if not self._res_launched:
-            return
-        self._res_launched = False
-        if int(self._res_error.item()) != 0:
-            self._res_error.zero_()
-            raise L.KernelLibraryError(
-                f"a resident training epoch was abandoned: a group of workgroups waited more than {RES_TIMEOUT_S} s for "
-                "its members (is another process running resident kernels on this GPU?); the trials of this pack "
-                "are in an undefined state.  MITUNE_RESIDENT=0 selects the grouped launches.")
-
     def _prepare(self) -> None:
-        """(Re)build whatever the current membership of the pack needs: the resident launch or the chains, and the
-        validation plan."""
-        self._res = None
-        if self._resident_reason() is None:
-            torch.cuda.synchronize(self.device)
-            self._drop_graphs()
-            self._chains = []
-            self._build_resident()
-        else:
-            self._build_chains()
+        """(Re)build whatever the current membership of the pack needs: the chains and the validation plan."""
+        self._build_chains()
         self._tables["eval_plan"] = self._build_plan(eval_mode=True)
         self._dirty = False
-
-    def _train_epoch_resident(self, main) -> None:
-        r = self._res
-        a, plan = r["args"], r["plan"]
-        self._epoch_tables(plan, r["ids"], "r_")
-        a.gather, a.opt = plan.gather, plan.opt
-        L.check(self.lib.mt_mlp_resident_launch(C.byref(a), r["n_wgs"], r["n_groups"], r["edge"], main.cuda_stream),
-                "mt_mlp_resident_launch")
-        self._res_launched = True
-        self.resident_epochs += 1
 
     # ------------------------------------------------------------------ training / evaluation
     def train_epoch(self):
         if not self.slots:
             return
-        self._check_resident()
-        if self._dirty or (not self._chains and self._res is None):
+        if self._dirty or not self._chains:
             self._prepare()
-        if self._res is not None:
-            self.loss_acc.zero_()
-            main = torch.cuda.current_stream(self.device)
-            self._train_epoch_resident(main)
-            self._finish_epoch(main)
-            return
         for ch in self._chains:
             ch.steps = self._epoch_tables(ch.plan, ch.ids, ch.tag)
         self.loss_acc.zero_()
@@ -1000,4 +888,3 @@ class HipPackEngine(PackEngine):
         if self._chains:
             torch.cuda.synchronize(self.device)
             self._drop_graphs()
-        self._check_resident()

@@ -69,36 +69,3 @@ def test_tile_split_index_fits_its_field():
     t = balanced_tiles([(0, 200, 1, 1)], ksplits=3)
     live = t[t["group"] >= 0]
     assert set(int(x) & 0xFF for x in live["ti"]) == set(range(200)) and set(int(x) >> 8 for x in live["ti"]) == {0, 1, 2}
-
-
-@settings(max_examples=200, deadline=None)
-@given(costs=st.lists(st.floats(0.0, 50.0), min_size=1, max_size=300), data=st.data(),
-       n_wgs=st.sampled_from([64, 512, 768, 1024]), gmin=st.sampled_from([1, 4, 8, 16, 64]))
-def test_resident_layout_gives_every_trial_one_group_and_every_workgroup_one_seat(costs, data, n_wgs, gmin):
-    """What the resident epoch kernel indexes with: each trial in exactly one group's list, each group at least ``gmin``
-    and at most its widest trial's worth of workgroups, never more workgroups than fit the chip, every (group, member)
-    seat exactly once in the grid, and a group's members on consecutive positions of the XCD-major order."""
-    from mitune.packed.engine_hip import resident_layout
-    useful = data.draw(st.lists(st.integers(1, 400), min_size=len(costs), max_size=len(costs)))
-    groups, order, wgs = resident_layout(costs, useful, n_wgs, gmin)
-    assert sorted(order) == list(range(len(costs)))
-    assert sum(c for _, c, _ in groups) == len(costs) and all(c >= 1 for _, c, _ in groups)
-    pos = 0
-    for first, count, nwg in groups:                        # the lists tile `order` without gaps
-        assert first == pos
-        pos += count
-        assert gmin <= nwg <= max(gmin, max(useful[i] for i in order[first:first + count]))
-    assert len(groups) == max(1, min(len(costs), n_wgs // gmin))
-    assert sum(n for _, _, n in groups) <= n_wgs and len(wgs) % N_XCD == 0 and len(wgs) <= n_wgs + N_XCD - 1
-    per = len(wgs) // N_XCD
-    seats = {}
-    for b in range(len(wgs)):
-        g, m = int(wgs[b]["group"]), int(wgs[b]["member"])
-        if g < 0:
-            continue
-        assert (g, m) not in seats
-        seats[(g, m)] = (b % N_XCD) * per + b // N_XCD       # position in XCD-major order
-    for gi, (_, _, nwg) in enumerate(groups):
-        p = [seats[(gi, m)] for m in range(nwg)]             # every member seated ...
-        assert p == list(range(p[0], p[0] + nwg))            # ... on consecutive positions
-    assert len(seats) == sum(n for _, _, n in groups)

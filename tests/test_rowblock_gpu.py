@@ -1,0 +1,84 @@
+"""The row-block training step of exact-f32 MLP packs (ops/csrc/rowblock.hip) against the tile launches it replaces.
+
+The two forms must agree bit for bit: the engine picks one per chain from the size of the pack, so a trial meets both in
+the course of one search, and its numbers may not depend on which (packing invariance).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    {"hidden_sizes": [64, 64], "batch_size": 128, "learning_rate": 3e-3, "optimizer": "adamw", "weight_decay": 1e-3},
+    {"hidden_sizes": [128, 96, 32], "batch_size": 256, "learning_rate": 1e-3, "optimizer": "adam", "loss_function": "huber"},
+    {"hidden_sizes": [512], "batch_size": 64, "learning_rate": 1e-2, "optimizer": "sgd", "momentum": 0.9,
+     "gradient_clipping": 1.0},
+    {"hidden_sizes": [256, 224], "batch_size": 200, "learning_rate": 2e-3, "optimizer": "rmsprop", "loss_function": "mae",
+     "warmup_steps": 5, "total_steps": 200},
+    {"hidden_sizes": [32, 512, 64, 160], "batch_size": 512, "learning_rate": 1e-3, "optimizer": "adamw",
+     "loss_function": "mape"},
+]
+
+
+def _data(n=8000, f=64, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(n, f, generator=g)
+    w = torch.randn(f, generator=g)
+    y = torch.tanh(X @ w * 0.3) * 2 + 0.3 * X[:, 0] * X[:, 1] + 0.05 * torch.randn(n, generator=g) + 3.0
+    k = int(0.8 * n)
+    return (X[:k], y[:k]), (X[k:], y[k:])
+
+
+def _run(form, monkeypatch, configs, slots, epochs=2, capacity=8, seed=5):
+    from mitune.packed import PackedTrainable, engine_hip
+    monkeypatch.setattr(engine_hip, "ROWBLOCK", form)
+    train, val = _data(seed=3)
+    tr = PackedTrainable(train=train, val=val, max_epochs=epochs, val_chunk=512, dtype="f32",
+                         model_kwargs={"max_width": 512, "max_layers": 4, "max_batch": 512})
+    eng = engine_hip.HipPackEngine(tr, device="cuda", capacity=capacity, seed=seed)
+    for slot, (idx, cfg) in zip(slots, configs):
+        eng.load(slot, idx, cfg)
+    hist = []
+    for _ in range(epochs):
+        eng.train_epoch()
+        hist.append(eng.evaluate())
+    used = [int(ch.plan.rb_nblocks) for ch in eng._chains]
+    states = {slot: eng.export(slot) for slot in slots}
+    eng.close()
+    return hist, states, used
+
+
+def _same(a, b, what):
+    for k, v in a.items():
+        if isinstance(v, dict):
+            _same(v, b[k], f"{what}.{k}")
+        elif isinstance(v, torch.Tensor):
+            assert torch.equal(v, b[k]), f"{what}.{k}"
+        else:
+            assert v == b[k], f"{what}.{k}"
+
+
+def test_row_block_step_equals_the_tile_launches_bit_for_bit(monkeypatch):
+    """Every loss and optimiser family, one to four layers, widths of 32 to 512, a batch that ends inside a block."""
+    cfgs = list(enumerate(CONFIGS, start=3))
+    slots = [4, 0, 6, 1, 3]
+    h_tile, s_tile, used_tile = _run("0", monkeypatch, cfgs, slots)
+    h_rb, s_rb, used_rb = _run("1", monkeypatch, cfgs, slots)
+    assert all(n == 0 for n in used_tile) and all(n > 0 for n in used_rb)
+    for slot in slots:
+        _same(s_tile[slot], s_rb[slot], f"slot{slot}")
+    assert h_tile == h_rb
+
+
+def test_row_block_results_do_not_depend_on_slot_or_neighbours(monkeypatch):
+    _, alone, _ = _run("1", monkeypatch, [(7, CONFIGS[1])], [0])
+    _, packed, _ = _run("1", monkeypatch, [(3, CONFIGS[0]), (7, CONFIGS[1]), (9, CONFIGS[4])], [5, 2, 6])
+    _same(alone[0]["model"], packed[2]["model"], "model")
+
+
+def test_small_packs_take_the_row_block_step_and_unsupported_shapes_the_tiles(monkeypatch):
+    _, _, used = _run("auto", monkeypatch, [(1, CONFIGS[0]), (2, CONFIGS[1])], [0, 1], epochs=1)
+    assert all(n > 0 for n in used)
+    odd = dict(CONFIGS[0], hidden_sizes=[64, 40])           # 40 columns: not a multiple of 32
+    _, _, used = _run("auto", monkeypatch, [(1, CONFIGS[0]), (2, odd)], [0, 1], epochs=1)
+    assert all(n == 0 for n in used)
