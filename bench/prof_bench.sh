@@ -6,7 +6,7 @@
 set -u
 ROOT="$(pwd)"
 TAG="$1"; shift
-mkdir -p "$ROOT/gpurun_out"
+mkdir -p "$(dirname "$ROOT/gpurun_out/$TAG")"
 cd /tmp && export TMPDIR=/tmp
 rm -rf "/tmp/prof_$TAG"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "/tmp/prof_$TAG" -- python3 "$ROOT/bench.py" "$@" \

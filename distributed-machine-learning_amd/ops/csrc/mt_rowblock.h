@@ -13,5 +13,6 @@ struct MtRbArgs {
   const MtRbBlock* blocks;
   float* scratch;                              // head records, (slot * max_chunks + chunk) * rec
   int32_t n_hidden, max_chunks, rec, pad;
+  unsigned long long* prof;                    // diagnostics: 16 clock stamps per workgroup (null: none are taken)
 };
 

@@ -29,11 +29,18 @@
 #include "mt_head_body.h"
 #include "mt_rowblock.h"
 
-#define RB_THREADS 512
-#define RB_WAVES 8
+// Geometry per row-tile count MT.  16 rows: sixteen waves of at most two tiles each -- four waves per SIMD cover each
+// other's DMA issue and LDS round trips better than two (critical workgroup of the 16-survivor pack 184 k -> 163 k
+// clocks); 32 rows: eight waves of at most four tiles (the MFMA work per fragment doubles, and so do the registers).
+template <int MT> struct RbCfg {
+  static constexpr int NW = MT == 1 ? 16 : 8;                  // waves per workgroup
+  static constexpr int THREADS = NW * 64;
+  static constexpr int TPW = 512 / 16 / NW;                    // column tiles per wave (RB_MAXW / 16 / NW)
+  static constexpr int CAP = MT == 1 ? 6 : 8;                  // fragments per wave ring
+  static constexpr int MASK_LAYERS = MT == 1 ? MT_MAX_LAYERS : 4;
+};
 #define RB_MAXW 512                              // widest layer / input row the LDS image holds
 #define RB_PITCH (RB_MAXW * 4 + 128)             // bytes per image row; = 128 mod 256, so rows alternate bank halves
-#define RB_TPW (RB_MAXW / 16 / RB_WAVES)         // column tiles per wave
 #define RB_MASK_BYTES (MT_MAX_LAYERS * (RB_MAXW / 16) * 64)
 #define RB_FRAG 1024                             // bytes of one weight fragment: 16 columns x 16 kk of f32
 
@@ -72,7 +79,7 @@ struct RbPhase {
 
 // Every layer width and the input row length are multiples of 32 (the caller checks): a K-step is always whole and a
 // layer has an even number of 16-column tiles.  CAP: fragments of the wave's ring.
-template <int CAP>
+template <int NW, int TPW, int CAP>
 __device__ __forceinline__ void rb_make_phase(RbPhase& ph, const MtGemmGroup& g, int nn, int layer, int wave, int lane) {
   ph.W = (rb_gcc)rb_uniform64((uint64_t)g.B);
   ph.bias = nn ? nullptr : (rb_gcf)rb_uniform64((uint64_t)g.aux);
@@ -85,20 +92,27 @@ __device__ __forceinline__ void rb_make_phase(RbPhase& ph, const MtGemmGroup& g,
   ph.nn = nn;
   ph.layer = layer;
   const int ntp = ph.N >> 4;
-  int tv = (ntp - wave + RB_WAVES - 1) / RB_WAVES;
-  ph.tv = tv < 0 ? 0 : (tv > RB_TPW ? RB_TPW : tv);
+  int tv = (ntp - wave + NW - 1) / NW;
+  ph.tv = tv < 0 ? 0 : (tv > TPW ? TPW : tv);
   ph.depth = ph.tv > 0 ? CAP / ph.tv : 0;
-  // Forward: the fragment of tile n0, K-step k0 is W[n0 + i][k0 + 4 g .. + 3] for lane (i = lane & 15, g = lane >> 4) --
-  // exactly the lane's own MFMA operand, so each lane later reads back the 16 bytes it fetched.  Input gradient: lane
-  // (rr = lane >> 2, c = lane & 3) fetches W[k0 + r][j0 + 4 c .. + 3] with r = 4 (rr & 3) + (rr >> 2): piece rr * 4 + c
-  // of the fragment then holds row 4 g + e at rr = 4 e + g, which spreads the four ds_read_b32 of a lane group over
-  // all banks.
-  if (nn) {
+  // Which 16 bytes of a fragment's source block a lane fetches (they land at fragment byte 16 * lane).  In both forms
+  // four consecutive lanes fetch the four 16-byte pieces of one 64-byte row segment: the memory pipeline handles a
+  // wave's request quad by quad, and a quad that touches four different rows costs four times the address cycles (this
+  // alone took the forward K-loops from 2030 to about 1300 cycles per K-step of 512 columns).
+  // Forward: rows are W[n0 + r][k0 .. k0 + 15], r = lane >> 2; the lane takes piece (lane & 3) ^ f(r >> 2) of the row, f =
+  // {0, 3, 2, 1}, so that MFMA lane (i, g), which needs piece g of row i, finds it at position 4 i + (g ^ f(i >> 2)) and
+  // the sixteen lanes that share an LDS cycle of ds_read_b128 hit sixteen different bank groups.
+  // Input gradient: rows are W[k0 + r][j0 .. j0 + 15] with r = 4 (rr & 3) + (rr >> 2), rr = lane >> 2: position rr * 4 + c
+  // then holds row 4 g + e at rr = 4 e + g, which spreads the four ds_read_b32 of a lane group over all banks.
+  {
     const int rr = lane >> 2, c = lane & 3;
-    const int r = 4 * (rr & 3) + (rr >> 2);
-    ph.lane_off = 4u * ((uint32_t)r * (uint32_t)ph.ldw + 4u * (uint32_t)c);
-  } else {
-    ph.lane_off = 4u * ((uint32_t)(lane & 15) * (uint32_t)ph.ldw + 4u * (uint32_t)(lane >> 4));
+    if (nn) {
+      const int r = 4 * (rr & 3) + (rr >> 2);
+      ph.lane_off = 4u * ((uint32_t)r * (uint32_t)ph.ldw + 4u * (uint32_t)c);
+    } else {
+      const int piece = c ^ ((4 - (rr >> 2)) & 3);
+      ph.lane_off = 4u * ((uint32_t)rr * (uint32_t)ph.ldw + 4u * (uint32_t)piece);
+    }
   }
 }
 
@@ -126,10 +140,11 @@ __device__ __forceinline__ void rb_wait_vm(int n) {
 }
 
 // Request the fragments of K-step s (16 kk) of the wave's tiles into ring stage `stage`.
+template <int NW>
 __device__ __forceinline__ void rb_issue_stage(const RbPhase& ph, uint8_t* ring, int stage, int s, int wave) {
   uint8_t* dst = ring + stage * ph.tv * RB_FRAG;
   for (int t = 0; t < ph.tv; ++t) {
-    const int c0 = (wave + RB_WAVES * t) * 16;
+    const int c0 = (wave + NW * t) * 16;
     const size_t elem = ph.nn ? (size_t)(s * 16) * ph.ldw + c0 : (size_t)c0 * ph.ldw + s * 16;      // wave-uniform
     rb_gcc src = ph.W + elem * 4 + (uint64_t)ph.lane_off;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -137,24 +152,32 @@ __device__ __forceinline__ void rb_issue_stage(const RbPhase& ph, uint8_t* ring,
   }
 }
 
-// The first depth - 1 K-steps of a layer (all of them when the layer has fewer).
+// The first `depth` K-steps of a layer (all of them when the layer has fewer): the whole ring.
+template <int NW>
 __device__ __forceinline__ void rb_prologue(const RbPhase& ph, uint8_t* ring, int wave) {
   if (ph.tv == 0) return;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the ring's previous contents are back
-  const int n = (ph.depth - 1 < ph.ns) ? ph.depth - 1 : ph.ns;
-  for (int s = 0; s < n; ++s) rb_issue_stage(ph, ring, s, s, wave);
+  const int n = (ph.depth < ph.ns) ? ph.depth : ph.ns;
+  for (int s = 0; s < n; ++s) rb_issue_stage<NW>(ph, ring, s, s, wave);
 }
 
-// K-loop of one layer for a wave with TV tiles; the first K-steps are on their way already (rb_prologue).
-template <int MT, int TV, bool NN>
-__device__ __forceinline__ void rb_kloop(f32x4 (&acc)[RB_TPW][MT], const RbPhase& ph, const uint8_t* act, uint8_t* ring,
+// K-loop of one layer for a wave with TV tiles; its first `depth` K-steps are on their way already (rb_prologue).
+// Per K-step s: wait for the fragments of K-step s, read them (and the activation chunk) into registers, run the MFMAs
+// of K-step s - 1 from the other register set, and only then -- the reads are back by now -- refill the ring stage just
+// read with K-step s + depth.  So the matrix pipe never waits for the LDS round trip, and the whole ring is in flight
+// except for the one stage in registers.  Measured on the critical workgroup of the 16-survivor pack (512 x 512 layer, 16
+// rows): this loop alone, weights not fetched, 39.9 k clocks (its MFMAs need 32.8 k); the DMA stream alone, MFMAs replaced
+// by vector multiply-adds, 38.5 k clocks = 27 bytes per clock per CU, which is what LDS-DMA delivers from L2 here; both
+// together 53.8 k.  A 16-row block needs a byte of weights for every 8 multiply-adds, so the two streams are the same
+// length and whatever fails to overlap shows.
+template <int MT, int TV, bool NN, int CAP>
+__device__ __forceinline__ void rb_kloop(f32x4 (&acc)[RbCfg<MT>::TPW][MT], const RbPhase& ph, const uint8_t* act, uint8_t* ring,
                                          int wave, int lane) {
   const int i = lane & 15, g = lane >> 4;
-  const int ns = ph.ns, D = ph.depth;
-  int st_issue = (D - 1 < ns) ? D - 1 : ns;      // ring stage of the next K-step to request (= its index while < D)
-  if (st_issue >= D) st_issue -= D;
-  int st_use = 0;
-  // image offsets of this lane's activation chunk in even / odd K-steps (a 32-kk block is 128 bytes of an image row)
+  constexpr int D = CAP / TV;
+  const int ns = ph.ns;
+  int st = 0;                                    // ring stage of K-step s (s mod D)
+  // image offset of this lane's activation chunk in even / odd K-steps (a 32-kk block is 128 bytes of an image row)
   int aoff[MT][2];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -162,19 +185,15 @@ __device__ __forceinline__ void rb_kloop(f32x4 (&acc)[RB_TPW][MT], const RbPhase
     aoff[m][0] = row * RB_PITCH + ((g ^ (row & 7)) << 4);
     aoff[m][1] = row * RB_PITCH + (((4 + g) ^ (row & 7)) << 4);
   }
-  const int woff = NN ? ((g << 6) + ((i >> 2) << 4) + ((i & 3) << 2)) : (lane << 4);
-  for (int s = 0; s < ns; ++s) {
-    const int ahead = s + D - 1;
-    if (ahead < ns) {
-      rb_issue_stage(ph, ring, st_issue, ahead, wave);
-      st_issue = (st_issue + 1 == D) ? 0 : st_issue + 1;
-    }
-    const int younger = (ns - 1 - s < D - 1) ? ns - 1 - s : D - 1;     // K-steps requested after K-step s
-    rb_wait_vm(younger * TV);
-    f32x4 a[MT], w[TV];
+  const int woff = NN ? ((g << 6) + ((i >> 2) << 4) + ((i & 3) << 2)) : ((4 * i + (g ^ ((4 - (i >> 2)) & 3))) << 4);
+
+  auto fetch = [&](int s, f32x4 (&a)[MT], f32x4 (&w)[TV]) __attribute__((always_inline)) {
+    // K-steps requested after K-step s and still possibly in flight: s + 1 .. s + D - 1, as far as the layer goes
+    if (ns - 1 - s >= D - 1) rb_wait_vm_imm<(D - 1) * TV>();
+    else rb_wait_vm((ns - 1 - s) * TV);
 #pragma unroll
     for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(act + ((s >> 1) << 7) + aoff[m][s & 1]);
-    const uint8_t* frag = ring + st_use * (TV * RB_FRAG) + woff;
+    const uint8_t* frag = ring + st * (TV * RB_FRAG) + woff;
 #pragma unroll
     for (int t = 0; t < TV; ++t) {
       if constexpr (!NN) {
@@ -184,28 +203,56 @@ __device__ __forceinline__ void rb_kloop(f32x4 (&acc)[RB_TPW][MT], const RbPhase
         for (int e = 0; e < 4; ++e) w[t][e] = *reinterpret_cast<const float*>(frag + t * RB_FRAG + (e << 8));
       }
     }
-    st_use = (st_use + 1 == D) ? 0 : st_use + 1;
+  };
+  auto refill = [&](int s) __attribute__((always_inline)) {       // K-step s has been read: its stage takes K-step s + D
+    if (s + D < ns) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // a DMA may not overtake the reads of the stage it overwrites
+      rb_issue_stage<RbCfg<MT>::NW>(ph, ring, st, s + D, wave);
+    }
+    st = (st + 1 == D) ? 0 : st + 1;
+  };
+  auto mma = [&](const f32x4 (&a)[MT], const f32x4 (&w)[TV]) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int t = 0; t < TV; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][e], a[m][e], acc[t][m], 0, 0, 0);
+  };
+
+  f32x4 a0[MT], w0[TV], a1[MT], w1[TV];
+  fetch(0, a0, w0);
+  refill(0);
+  int s = 1;
+  for (; s + 1 < ns; s += 2) {
+    fetch(s, a1, w1);
+    mma(a0, w0);
+    refill(s);
+    fetch(s + 1, a0, w0);
+    mma(a1, w1);
+    refill(s + 1);
+  }
+  if (s < ns) {
+    fetch(s, a1, w1);
+    mma(a0, w0);
+    mma(a1, w1);
+  } else {
+    mma(a0, w0);
   }
 }
 
-template <int MT, bool NN>
-__device__ __forceinline__ void rb_run_kloop(f32x4 (&acc)[RB_TPW][MT], const RbPhase& ph, const uint8_t* act, uint8_t* ring,
+template <int MT, bool NN, int CAP>
+__device__ __forceinline__ void rb_run_kloop(f32x4 (&acc)[RbCfg<MT>::TPW][MT], const RbPhase& ph, const uint8_t* act, uint8_t* ring,
                                              int wave, int lane) {
 #pragma unroll
-  for (int t = 0; t < RB_TPW; ++t)
+  for (int t = 0; t < RbCfg<MT>::TPW; ++t)
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
   switch (ph.tv) {
-    case 1: rb_kloop<MT, 1, NN>(acc, ph, act, ring, wave, lane); break;
-    case 2: rb_kloop<MT, 2, NN>(acc, ph, act, ring, wave, lane); break;
-    case 3: rb_kloop<MT, 3, NN>(acc, ph, act, ring, wave, lane); break;
-    case 4: rb_kloop<MT, 4, NN>(acc, ph, act, ring, wave, lane); break;
+    case 1: rb_kloop<MT, 1, NN, CAP>(acc, ph, act, ring, wave, lane); break;
+    case 2: rb_kloop<MT, 2, NN, CAP>(acc, ph, act, ring, wave, lane); break;
+    case 3: if constexpr (RbCfg<MT>::TPW >= 3) rb_kloop<MT, 3, NN, CAP>(acc, ph, act, ring, wave, lane); break;
+    case 4: if constexpr (RbCfg<MT>::TPW >= 4) rb_kloop<MT, 4, NN, CAP>(acc, ph, act, ring, wave, lane); break;
     default: break;
   }
 }
@@ -329,13 +376,13 @@ __device__ __forceinline__ int rb_opaque(int v) {
 
 // Outputs of the wave's tiles -> the LDS image (in place of the layer's input), between two barriers.
 template <int MT>
-__device__ __forceinline__ void rb_store_image(const f32x4 (&acc)[RB_TPW][MT], uint8_t* act, int tv, int wave, int lane) {
+__device__ __forceinline__ void rb_store_image(const f32x4 (&acc)[RbCfg<MT>::TPW][MT], uint8_t* act, int tv, int wave, int lane) {
   rb_lds_barrier();          // every wave has read the layer's input for the last time
   const int i = rb_opaque(lane & 15), g = lane >> 4;
 #pragma unroll
-  for (int t = 0; t < RB_TPW; ++t) {
+  for (int t = 0; t < RbCfg<MT>::TPW; ++t) {
     if (t < tv) {
-      const int col = (wave + RB_WAVES * t) * 16 + 4 * g;
+      const int col = (wave + RbCfg<MT>::NW * t) * 16 + 4 * g;
 #pragma unroll
       for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(act + rb_act_off(m * 16 + i, col)) = acc[t][m];
     }
@@ -344,18 +391,13 @@ __device__ __forceinline__ void rb_store_image(const f32x4 (&acc)[RB_TPW][MT], u
 }
 
 // LDS of one workgroup: the activation image, the ReLU masks of every layer (one byte per tile and lane), the head's
-// reduction buffers and the eight private weight rings.  16 rows: 34 + 16 + 8 + 96 KiB; 32 rows (at most 4 layers): 68 + 8 +
-// 16 + 64 KiB.
-template <int MT> struct RbCfg {
-  static constexpr int CAP = MT == 1 ? 12 : 8;                 // fragments per wave ring
-  static constexpr int MASK_LAYERS = MT == 1 ? MT_MAX_LAYERS : 4;
-};
-
+// reduction buffers and the private weight rings.  16 rows: 34 + 16 + 8 + 96 KiB; 32 rows (at most 4 layers): 68 + 8 + 16 +
+// 64 KiB.
 template <int MT>
-__global__ __launch_bounds__(RB_THREADS) void mt_mlp_rowblock_kernel(MtRbArgs a, int step_imm,
+__global__ __launch_bounds__(RbCfg<MT>::THREADS) void mt_mlp_rowblock_kernel(MtRbArgs a, int step_imm,
                                                                      const int* __restrict__ step_base) {
-  constexpr int RB = 16 * MT, CAP = RbCfg<MT>::CAP;
-  __shared__ __attribute__((aligned(1024))) uint8_t rings[RB_WAVES * CAP * RB_FRAG];
+  constexpr int RB = 16 * MT, CAP = RbCfg<MT>::CAP, NW = RbCfg<MT>::NW, TPW = RbCfg<MT>::TPW;
+  __shared__ __attribute__((aligned(1024))) uint8_t rings[NW * CAP * RB_FRAG];
   __shared__ __attribute__((aligned(16))) uint8_t act[RB * RB_PITCH];
   __shared__ uint8_t mask[RbCfg<MT>::MASK_LAYERS * (RB_MAXW / 16) * 64];
   __shared__ float red[MT][4][RB_MAXW];
@@ -375,16 +417,23 @@ __global__ __launch_bounds__(RB_THREADS) void mt_mlp_rowblock_kernel(MtRbArgs a,
   while (L < a.n_hidden && L < RbCfg<MT>::MASK_LAYERS && a.fwd[L][slot].B != nullptr) ++L;
   if (L == 0) return;
 
-  f32x4 acc[RB_TPW][MT];
+  // Diagnostic stamps (a.prof != null only in profiling runs): shader clock of thread 0 at the phase boundaries.
+  int n_stamp = 0;
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if (a.prof != nullptr && tid == 0 && n_stamp < 16) a.prof[(size_t)blockIdx.x * 16 + n_stamp] = __builtin_amdgcn_s_memtime();
+    ++n_stamp;
+  };
+  stamp();
+  f32x4 acc[TPW][MT];
   RbPhase cur;
   {
     const MtGemmGroup g0 = a.fwd[0][slot];
-    rb_make_phase<CAP>(cur, g0, 0, 0, wave, lane);
-    rb_prologue(cur, ring, wave);
+    rb_make_phase<NW, TPW, CAP>(cur, g0, 0, 0, wave, lane);
+    rb_prologue<NW>(cur, ring, wave);
     // the block's input rows -> LDS image (zero beyond the batch, as the tile kernel's staging does)
     rb_gcf X = (rb_gcf)rb_uniform64((uint64_t)g0.A);
     const int cpr = cur.K >> 2;                         // 16-byte chunks per image row
-    for (int idx = tid; idx < RB * cpr; idx += RB_THREADS) {
+    for (int idx = tid; idx < RB * cpr; idx += RbCfg<MT>::THREADS) {
       const int r = idx / cpr, k = (idx - r * cpr) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row0 + r < hs.B) v = *(rb_gc4)(X + (size_t)(row0 + r) * g0.lda + k);
@@ -396,32 +445,34 @@ __global__ __launch_bounds__(RB_THREADS) void mt_mlp_rowblock_kernel(MtRbArgs a,
   RbHeadRegs hr;
   rb_head_fetch<MT>(hr, hs, row0, wave, lane);
   rb_lds_barrier();
+  stamp();
 
   // ---- forward layers: H_l = relu(H_{l-1} W_l^T + b_l)
   for (int l = 0; l < L; ++l) {
     RbPhase nxt = {};
-    if (l + 1 < L) rb_make_phase<CAP>(nxt, a.fwd[l + 1][slot], 0, l + 1, wave, lane);
-    else if (L > 1) rb_make_phase<CAP>(nxt, a.dgrad[L - 1][slot], 1, L - 1, wave, lane);
+    if (l + 1 < L) rb_make_phase<NW, TPW, CAP>(nxt, a.fwd[l + 1][slot], 0, l + 1, wave, lane);
+    else if (L > 1) rb_make_phase<NW, TPW, CAP>(nxt, a.dgrad[L - 1][slot], 1, L - 1, wave, lane);
     const int i = rb_opaque(lane & 15), g = lane >> 4;
     // bias of the wave's tiles (the array is padded with zeros to a multiple of 8 columns), waited for before the next
     // layer's fragments are requested
-    f32x4 bb[RB_TPW];
+    f32x4 bb[TPW];
 #pragma unroll
-    for (int t = 0; t < RB_TPW; ++t) {
+    for (int t = 0; t < TPW; ++t) {
       bb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int col = (wave + RB_WAVES * t) * 16 + 4 * g;
+      const int col = (wave + NW * t) * 16 + 4 * g;
       if (cur.bias != nullptr && t < cur.tv) bb[t] = *(rb_gc4)(cur.bias + col);
     }
-    rb_run_kloop<MT, false>(acc, cur, act, ring, wave, lane);
+    rb_run_kloop<MT, false, CAP>(acc, cur, act, ring, wave, lane);
+    stamp();
 #pragma unroll
-    for (int t = 0; t < RB_TPW; ++t) asm volatile("" : "+v"(bb[t]));
-    rb_prologue(nxt, ring, wave);
+    for (int t = 0; t < TPW; ++t) asm volatile("" : "+v"(bb[t]));
+    rb_prologue<NW>(nxt, ring, wave);
 
     const bool to_mem = cur.out != nullptr && l + 1 < L;     // H of the last layer is consumed by the head below, from LDS
 #pragma unroll
-    for (int t = 0; t < RB_TPW; ++t) {
+    for (int t = 0; t < TPW; ++t) {
       if (t < cur.tv) {
-        const int tile = wave + RB_WAVES * t;
+        const int tile = wave + NW * t;
         const int col = tile * 16 + 4 * g;
         uint32_t bits = 0u;
 #pragma unroll
@@ -440,6 +491,7 @@ __global__ __launch_bounds__(RB_THREADS) void mt_mlp_rowblock_kernel(MtRbArgs a,
       }
     }
     rb_store_image<MT>(acc, act, cur.tv, wave, lane);
+    stamp();
     cur = nxt;
   }
 
@@ -447,18 +499,20 @@ __global__ __launch_bounds__(RB_THREADS) void mt_mlp_rowblock_kernel(MtRbArgs a,
   rb_head<MT>(hr, hs, act, red, red_s, row0, wave, lane);
   rb_lds_barrier();
   rb_head_record<MT>(hs, a, slot, red, red_s, row0, wave, lane);
+  stamp();
 
   // ---- input gradients: dZ_{l-1} = (dZ_l W_l) * (H_{l-1} > 0), l = L-1 .. 1
   for (int l = L - 1; l >= 1; --l) {
     RbPhase nxt = {};
-    if (l > 1) rb_make_phase<CAP>(nxt, a.dgrad[l - 1][slot], 1, l - 1, wave, lane);
-    rb_run_kloop<MT, true>(acc, cur, act, ring, wave, lane);
-    rb_prologue(nxt, ring, wave);
+    if (l > 1) rb_make_phase<NW, TPW, CAP>(nxt, a.dgrad[l - 1][slot], 1, l - 1, wave, lane);
+    rb_run_kloop<MT, true, CAP>(acc, cur, act, ring, wave, lane);
+    stamp();
+    rb_prologue<NW>(nxt, ring, wave);
     const int i = rb_opaque(lane & 15), g = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < RB_TPW; ++t) {
+    for (int t = 0; t < TPW; ++t) {
       if (t < cur.tv) {
-        const int tile = wave + RB_WAVES * t;
+        const int tile = wave + NW * t;
         const int col = tile * 16 + 4 * g;
         const uint32_t bits = mask[((l - 1) * (RB_MAXW / 16) + tile) * 64 + lane];
 #pragma unroll
@@ -473,9 +527,14 @@ __global__ __launch_bounds__(RB_THREADS) void mt_mlp_rowblock_kernel(MtRbArgs a,
       }
     }
     if (l > 1) rb_store_image<MT>(acc, act, cur.tv, wave, lane);      // the last input gradient is read by nobody in here
+    stamp();
     cur = nxt;
   }
 }
+
+// Diagnostics: a buffer of 16 stamps per workgroup that every later row-block launch of this process fills (null: off).
+static unsigned long long* rb_prof_buffer = nullptr;
+extern "C" void mt_rowblock_set_prof(unsigned long long* buf) { rb_prof_buffer = buf; }
 
 extern "C" int mt_rb_args_sizeof() { return (int)sizeof(MtRbArgs); }
 extern "C" int mt_rowblock_max_width() { return RB_MAXW; }
@@ -488,10 +547,12 @@ extern "C" int mt_mlp_rowblock_launch(const MtRbArgs* args, int n_blocks, int mt
   if (args == nullptr || args->n_hidden < 1 || args->n_hidden > MT_MAX_LAYERS || args->blocks == nullptr ||
       args->head == nullptr || args->scratch == nullptr || args->rec < 10 || args->max_chunks < 1)
     return -2;
+  MtRbArgs a = *args;
+  a.prof = rb_prof_buffer;
   if (mt == 1)
-    hipLaunchKernelGGL(mt_mlp_rowblock_kernel<1>, dim3(n_blocks), dim3(RB_THREADS), 0, stream, *args, step, mt_step_base_tls);
+    hipLaunchKernelGGL(mt_mlp_rowblock_kernel<1>, dim3(n_blocks), dim3(RbCfg<1>::THREADS), 0, stream, a, step, mt_step_base_tls);
   else if (mt == 2)
-    hipLaunchKernelGGL(mt_mlp_rowblock_kernel<2>, dim3(n_blocks), dim3(RB_THREADS), 0, stream, *args, step, mt_step_base_tls);
+    hipLaunchKernelGGL(mt_mlp_rowblock_kernel<2>, dim3(n_blocks), dim3(RbCfg<2>::THREADS), 0, stream, a, step, mt_step_base_tls);
   else
     return -2;
   return (int)hipGetLastError();

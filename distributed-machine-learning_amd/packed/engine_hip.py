@@ -83,8 +83,9 @@ DTYPES = ("bf16", "f32")
 # step is bound by launch latencies), "1" whenever the shapes allow (every width and the feature count a multiple of 32,
 # at most 512), "0" never.
 ROWBLOCK = os.environ.get("MITUNE_ROWBLOCK", "auto")
-ROWBLOCK_MAX_BLOCKS = int(os.environ.get("MITUNE_ROWBLOCK_MAX_BLOCKS", "640"))
+ROWBLOCK_MAX_BLOCKS = int(os.environ.get("MITUNE_ROWBLOCK_MAX_BLOCKS", "400"))
 ROWBLOCK_ROWS = 16
+ROWBLOCK_MT = int(os.environ.get("MITUNE_ROWBLOCK_MT", "1"))      # row tiles of 16 per workgroup (2: at most 4 layers)
 
 def ceil8(x: int) -> int:
     return (x + 7) // 8 * 8
@@ -594,6 +595,8 @@ class HipPackEngine(PackEngine):
             blocks += (min(s.spec.batch_size, self.n_train) + ROWBLOCK_ROWS - 1) // ROWBLOCK_ROWS
         if ROWBLOCK != "1" and blocks > ROWBLOCK_MAX_BLOCKS:
             return 0
+        if ROWBLOCK_MT == 2 and all(len(self.slots[k].layout.hidden) <= 4 for k in ids):
+            return 2
         return 1
 
     def _rowblock_blocks(self, ids: List[int], mt: int, tag: str) -> Tuple[int, int]:
