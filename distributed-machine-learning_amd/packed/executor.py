@@ -109,6 +109,8 @@ class PackedExecutor(Executor):
         self._retired_last = 0             # slots freed by the previous round's decisions
         self._retired_now = 0
         self._n_undecided = 0
+        # a lost rank is repaired in place only where a failed collective raises in the caller (parallel/comm.py)
+        self._repairable = self.t.on_rank_loss == "repair" and bool(getattr(self.comm, "delivers_errors", True))
         self._hostname = socket.gethostname()
         self._diverged: set = set()
         self._lost_pending: List[Trial] = []      # trials of ranks lost while moving trials: reported with the next round
@@ -125,6 +127,56 @@ class PackedExecutor(Executor):
 
     def bind_runner(self, runner) -> None:
         self.runner = runner
+
+    def adapt_to_space(self, config: Optional[Dict]) -> None:
+        """Called by ``run()`` with the search space before the first trial starts.  The grouped-launch sequence engine is
+        chosen from the trainable alone, but whether it can hold a trial depends on the trial's d_model / num_heads /
+        num_layers / batch_size: every combination the space can produce is checked here, the engine's limits are set from
+        them, and a space with a combination outside the grouped kernels' envelope (or with a non-enumerable domain on
+        one of those keys) gets the one-graph-per-slot engine instead, which takes any shape."""
+        if self.engine.name != "seq" or self.t.engine != "auto" or self._place or not config:
+            return
+        import itertools
+        from . import engine_seq
+        from ..tune.space import Categorical, Domain
+        keys = ("d_model", "num_heads", "num_layers", "batch_size")
+        options: List[List[Any]] = []
+        for k in keys:
+            v = config.get(k, self.t.model_kwargs.get(k))
+            if isinstance(v, Categorical):
+                options.append(list(v.categories))
+            elif isinstance(v, Domain) or callable(v) or isinstance(v, dict):
+                options = []                     # a domain that cannot be listed: no guarantee possible
+                break
+            else:
+                options.append([v])
+        why = None if options else "the search space draws an engine shape from a domain that cannot be enumerated"
+        combos = [dict(zip(keys, c)) for c in itertools.product(*options)] if options else []
+        for c in combos:
+            c = {k: v for k, v in c.items() if v is not None}
+            why = engine_seq.supports(self.t, {**{"num_layers": 1}, **c}) if {"d_model", "num_heads"} <= set(c) else None
+            if why:
+                break
+        if why is None and combos:
+            kw = dict(self.t.model_kwargs)
+            have = lambda k: [c[k] for c in combos if c.get(k) is not None]      # noqa: E731
+            for k, limit in (("d_model", "max_d_model"), ("num_heads", "max_heads"), ("num_layers", "max_layers"),
+                             ("batch_size", "max_batch")):
+                if have(k):
+                    kw[limit] = max(int(kw.get(limit, 0) or 0), max(int(x) for x in have(k)))
+            if kw != self.t.model_kwargs:
+                self.t.model_kwargs = kw
+                self.engine.close()
+                self.engine = make_engine(self.t, self.device, self.capacity, self.seed)
+            return
+        if why is not None:
+            self.engine.close()
+            from .engine_graph import GraphPackEngine
+            self.engine = GraphPackEngine(self.t, str(self.device), self.capacity, self.seed)
+            self.capacity = self.engine.capacity
+            self._free = [list(range(self.capacity)) for _ in range(self.world)]
+            self.stats["engine"] = self.engine.name
+            self.stats["engine_fallback"] = why
 
     # ------------------------------------------------------------------ capacity / placement
     def has_capacity(self) -> bool:
@@ -218,7 +270,7 @@ class PackedExecutor(Executor):
         except Exception as e:          # noqa: BLE001 - RCCL / gloo raise backend-specific types
             what = (f"rank {self.rank} of {self.world}: metric exchange after epoch {self.stats['epochs'] + 1} "
                     f"failed ({type(e).__name__}: {e})")
-            if self.t.on_rank_loss != "repair":
+            if not self._repairable:
                 raise RankLostError(what) from e
             lost_trials = lost_trials + self._repair(what, e)
             try:        # the round's results of the trials that are still there, over the re-formed group
@@ -323,6 +375,10 @@ class PackedExecutor(Executor):
                 tr.checkpoint_rank = new_of.get(src)
                 if tr.checkpoint_rank is None:
                     tr.checkpoint = None
+                    if not tr.logdir:
+                        # the only copy went with the lost rank and nothing is on disk: the trial starts over, and says
+                        # so -- a restart from the initial weights under the old iteration count would pass for a resume
+                        tr.checkpoint_iter = 0
         self.stats["world_size"] = self.world
         self.stats["ranks_lost"] = self.stats.get("ranks_lost", 0) + len(lost)
         self.stats["trials_recovered"] = self.stats.get("trials_recovered", 0) + len(lost_trials)
@@ -501,6 +557,8 @@ class PackedExecutor(Executor):
         src, sslot = self._place[tr.trial_id]
         dslot = self._free[dst][0]            # taken for good only once the state has arrived
         eng = self.engine
+        err: Optional[Exception] = None
+        payload = None
         try:
             if hasattr(eng, "export_raw"):
                 # parameters and optimiser moments travel as the device-resident slab they already are: HBM -> xGMI -> HBM
@@ -510,11 +568,23 @@ class PackedExecutor(Executor):
             else:
                 payload = self.comm.broadcast_object(eng.export(sslot) if self.rank == src else None, src=src)
         except Exception as e:          # noqa: BLE001 - RCCL / gloo raise backend-specific types
+            err = e
+        # A broadcast can complete on some ranks before the others notice that a peer is gone.  The move is committed only
+        # when every rank says it holds the payload: one more (tiny) collective, which fails or reports 0 on every
+        # survivor alike, so that either all of them commit the move or all of them repair the group and plan again.
+        try:
+            flag = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float32, device=self.comm.device)
+            self.comm.all_reduce(flag, op="min")
+            agreed = float(flag.item()) >= 1.0
+        except Exception as e:          # noqa: BLE001
+            agreed, err = False, (err or e)
+        if not agreed:
+            cause = err or RuntimeError("another rank did not receive the trial")
             what = (f"rank {self.rank} of {self.world}: moving trial {tr.trial_id} from rank {src} to "
-                    f"rank {dst} failed ({type(e).__name__}: {e})")
-            if self.t.on_rank_loss != "repair":
-                raise RankLostError(what) from e
-            self._lost_pending.extend(self._repair(what, e))
+                    f"rank {dst} failed ({type(cause).__name__}: {cause})")
+            if not self._repairable:
+                raise RankLostError(what) from cause
+            self._lost_pending.extend(self._repair(what, cause))
             return False
         self._free[dst].pop(0)
         if self.rank == dst:

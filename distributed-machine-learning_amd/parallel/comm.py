@@ -29,6 +29,9 @@ class Comm:
     rank: int = 0
     world_size: int = 1
     device: torch.device = torch.device("cpu")
+    # True when a collective whose peer has died raises in the caller (so that the caller can re-form the group) instead
+    # of hanging or ending the process from a watchdog thread
+    delivers_errors: bool = True
 
     def all_gather(self, t: torch.Tensor) -> torch.Tensor:
         """Stack equal-shaped ``t`` from every rank along a new leading dim."""
@@ -95,9 +98,11 @@ def single_node_bootstrap(world_size: int) -> None:
     """RCCL's bootstrap (the TCP side channel that sets a communicator up) picks a network interface by itself; in a
     container whose host name does not resolve, or whose outward interface is filtered, that handshake times out.  When
     every rank of the job is on this node (the launcher's LOCAL_WORLD_SIZE equals the world size, or there is one rank)
-    the loopback interface is the right one; an explicit NCCL_SOCKET_IFNAME always wins."""
-    local = int(os.environ.get("LOCAL_WORLD_SIZE", world_size) or world_size)
-    if world_size <= 1 or local >= world_size:
+    the loopback interface is the right one; an explicit NCCL_SOCKET_IFNAME always wins.
+    A launch that exports only RANK / WORLD_SIZE (srun, mpirun, by hand) says nothing about where its ranks are: the
+    choice is then left to RCCL."""
+    local = os.environ.get("LOCAL_WORLD_SIZE")
+    if world_size <= 1 or (local is not None and local != "" and int(local) == world_size):
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 
 
@@ -175,11 +180,20 @@ class TorchDistComm(Comm):
             if backend == "nccl":
                 kw["device_id"] = device
                 single_node_bootstrap(world_size)
+                # RCCL collectives are asynchronous: left alone, a dead peer shows up in torch's watchdog thread, which
+                # ends the process after the group's timeout.  With blocking waits the wait inside the collective call
+                # polls the work, raises in THIS thread when the timeout passes or the communicator reports an error,
+                # and the watchdog leaves the process alone -- which is what lets PackedExecutor re-form the group
+                # (shrink).  The collectives here run once per scheduling round, so a blocking host wait costs nothing.
+                os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
             dist.init_process_group(backend=backend, init_method=init_method or "env://", rank=rank,
                                     world_size=world_size, timeout=datetime.timedelta(seconds=timeout_s), **kw)
             self._own = True
         self.backend = dist.get_backend()
         self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+        # parity unpinned on RCCL: every test box has one GPU, so a peer lost from a multi-rank RCCL group has never been
+        # observed here; the gloo and in-process backends are covered by tests/test_distributed_cpu.py
+        self.delivers_errors = self.backend != "nccl" or os.environ.get("TORCH_NCCL_BLOCKING_WAIT", "0") == "1"
         # One process per GPU: the ranks of a node share its CPUs.  Left alone, every rank keeps a full-size intra-op
         # thread pool whose idle workers spin; together they overrun the node's CPU allowance and each small host-side
         # tensor op then stalls for milliseconds (measured with two ranks: 1.2 ms per in-place multiply of a weight

@@ -176,6 +176,8 @@ def run(run_or_experiment: Any,
         ex = ProcessExecutor(trainable, resources_per_trial, max_concurrent_trials, tname)
     else:
         raise ValueError(f"unknown executor {executor!r}")
+    if hasattr(ex, "adapt_to_space"):
+        ex.adapt_to_space(config)          # an engine picked from the trainable alone may not hold every shape of this space
     # One process per GPU runs this same function.  Rank 0 is the primary: it names the experiment, owns the loggers
     # and experiment_state.json; every rank shares the directory (trial owners write their checkpoints into it).
     rank, world = int(getattr(ex, "rank", 0)), int(getattr(ex, "world", 1))

@@ -323,6 +323,11 @@ class TrialRunner:
                 it = int(ckpt.load_checkpoint(cp).get("training_iteration", 0))
             except Exception:       # noqa: BLE001 - a checkpoint cut off by the crash counts as none
                 it = 0
+        comm = getattr(self.executor, "comm", None)
+        if comm is not None and getattr(comm, "world_size", 1) > 1:
+            # ranks on different nodes may not see the same files: the (new) rank 0's reading of the disk stands for all,
+            # so that every rank truncates the trial's history at the same iteration
+            it = int(comm.broadcast_object(it, src=0))
         trial.checkpoint, trial.checkpoint_iter, trial.checkpoint_rank = None, it, None
         trial.restore_from, trial.restore_pending = None, True
         trial.results = [r for r in trial.results if r.get("training_iteration", 0) <= it]
