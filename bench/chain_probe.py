@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import bench as headline  # noqa: E402
+from mitune.options import OPTIONS  # noqa: E402
 from mitune.packed import PackedTrainable, engine_hip  # noqa: E402
 from mitune.tune import space as sp  # noqa: E402
 
@@ -26,7 +27,7 @@ def main():
     train, val = headline.make_data(args.rows, 64, dev)
     for slots in args.slots:
         for by_batch in (False, True):
-            engine_hip.CHAINS_BY_BATCH = by_batch
+            OPTIONS.chains_by_batch = by_batch
             tr = PackedTrainable(train=train, val=val, max_epochs=3, engine="hip", dtype=args.dtype, capacity=slots,
                                  val_chunk=4096, model_kwargs={"max_width": 512, "max_layers": 3, "max_batch": 1024})
             eng = engine_hip.HipPackEngine(tr, dev, slots, 0)

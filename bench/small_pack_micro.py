@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--stamps", action="store_true", help="print the row-block kernel's phase stamps of its last launch")
     args = ap.parse_args()
     import bench as headline
+    from mitune.options import OPTIONS
     from mitune.packed import PackedTrainable, engine_hip
     dev = torch.device("cuda", 0)
     train, val = headline.make_data(args.rows, 64, dev)
@@ -57,7 +58,7 @@ def main():
         prof = torch.zeros(4096 * 16, device=dev, dtype=torch.int64)
         L.load().mt_rowblock_set_prof(C.c_void_p(prof.data_ptr()))
     for form in args.forms.split(","):
-        engine_hip.ROWBLOCK = form
+        OPTIONS.rowblock = form
         tr = PackedTrainable(train=train, val=val, max_epochs=args.epochs, engine="hip", dtype="f32", capacity=args.slots,
                              val_chunk=4096, model_kwargs={"max_width": 512, "max_layers": 3, "max_batch": 1024})
         eng = engine_hip.HipPackEngine(tr, device=dev, capacity=args.slots, seed=0)

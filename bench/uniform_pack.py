@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     args = ap.parse_args()
     import bench as headline
+    from mitune.options import OPTIONS
     from mitune.packed import PackedTrainable, engine_hip
     dev = torch.device("cuda", 0)
     train, val = headline.make_data(args.rows, 64, dev)
@@ -35,7 +36,7 @@ def main():
     flop = 6.0 * macs * (n_tr // args.batch) * args.batch * args.slots
     out = {}
     for name, dtype, big in (("bf16_128_tiles", "bf16", 0), ("bf16_256_tiles", "bf16", 256), ("f32", "f32", 0)):
-        engine_hip.BIG_MIN_TILES = big
+        OPTIONS.big_min_tiles = big
         tr = PackedTrainable(train=train, val=val, max_epochs=args.epochs + 1, engine="hip", dtype=dtype,
                              capacity=args.slots, val_chunk=4096,
                              model_kwargs={"max_width": 512, "max_layers": 3, "max_batch": 1024})

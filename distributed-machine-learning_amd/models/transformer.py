@@ -22,9 +22,9 @@ hyper-parameter is live and every combination runs:
 * ``SimpleTransformerModel``  - the sample script's model: projection -> stock post-norm encoder
   (dff = 4 d) -> last token -> ``Linear(d, 1)`` (/root/reference/ray-tune-hpo-regression-sample.py:60-83).
 
-Attention, dropout+residual+LayerNorm, PE add + dropout, the depthwise convolution and the regression
-head go through ``mitune.ops`` which runs hand-written HIP kernels on a GPU and plain PyTorch elsewhere;
-the remaining dense projections are library GEMMs.
+Attention, dropout+residual+LayerNorm, PE add + dropout, the depthwise convolution and every dense projection
+(``ops/linear.py``: exact-f32 or bf16 MFMA tile kernels, no BLAS-library GEMM) go through ``mitune.ops``, which runs
+hand-written HIP kernels on a GPU and plain PyTorch on the CPU.
 """
 from __future__ import annotations
 
@@ -37,7 +37,6 @@ import torch.nn.functional as F
 
 from ..ops.attention import self_attention, self_attention_qkv
 from ..ops.elementwise import depthwise_conv1d, pe_add_dropout, relu_dropout
-from ..ops.head_mlp import head_mlp
 from ..ops.layernorm import residual_layer_norm
 from ..ops.linear import linear
 
@@ -214,7 +213,6 @@ class TransformerModel(nn.Module):
         self.fc3 = nn.Linear(64, 32)
         self.fc4 = nn.Linear(32, 16)
         self.fc5 = nn.Linear(16, 1)
-        self.fused_head = False          # True: the single-kernel head of ops/head_mlp.py (kept for comparison)
 
     @classmethod
     def from_config(cls, config, input_size: int) -> "TransformerModel":
@@ -242,11 +240,9 @@ class TransformerModel(nn.Module):
             x = layer(x, drop_path=self.drop_rates[i])
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5)
         h = x[:, -1, :]                                  # last token of every sequence
-        if self.fused_head:
-            return head_mlp(h, [fc.weight for fc in fcs], [fc.bias for fc in fcs])      # [B, 1]
         # Layer by layer: with the one-launch dense backward of ``ops/linear.py`` this is 90-200 us forward + backward at
-        # batch 32-256, against 160-590 us for the three-launch fused head (whose workgroups stream the whole first
-        # weight matrix through LDS for eight rows each).
+        # batch 32-256; a single-kernel head with all five weight matrices staged through LDS was built and measured at
+        # 160-590 us (its workgroups stream the whole first matrix for eight rows each) and removed.
         for i, fc in enumerate(fcs):
             h = linear(h, fc.weight, fc.bias)
             if i < len(fcs) - 1:

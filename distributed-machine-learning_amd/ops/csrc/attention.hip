@@ -1119,14 +1119,12 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_exact_tiled_kernel(
                    seed != nullptr, s0, s1, thresh, blockIdx.x);
 }
 
-// MITUNE_ATTN_EXACT: 0 = f32 operands always go through the matrix form (rounded to bf16); 1 = sequences of up to 32
-// tokens run the exact-f32 form; 2 (default) = so do sequences of up to 128 tokens, tiled (heads of up to 64 elements in
-// both; wider heads keep the matrix form).  f32 models therefore multiply in f32 unless told otherwise.
-static int at_level = -1;
-static int at_exact_level() {
-  if (at_level < 0) { const char* e = getenv("MITUNE_ATTN_EXACT"); at_level = e ? atoi(e) : 2; }
-  return at_level;
-}
+// Exactness level of f32 attention: 0 = f32 operands always go through the matrix form (rounded to bf16); 1 = sequences
+// of up to 32 tokens run the exact-f32 form; 2 (default) = so do sequences of up to 128 tokens, tiled (heads of up to 64
+// elements in both; wider heads keep the matrix form).  f32 models therefore multiply in f32 unless told otherwise
+// (mt_attn_exact_level, driven by the package's ``attn_exact`` option).
+static int at_level = 2;
+static int at_exact_level() { return at_level; }
 extern "C" int mt_attn_exact_level(int set) {      // set >= 0 replaces the level; returns the one in force before
   const int was = at_exact_level();
   if (set >= 0) at_level = set;
@@ -1150,7 +1148,7 @@ static int atl_prepare(const void* fn, size_t bytes) {      // kernels above 64 
   return 0;
 }
 
-// MITUNE_ATTN_EXACT=0 sends f32 operands of short sequences through the matrix form too (operands rounded to bf16).
+// Level 0 sends f32 operands of short sequences through the matrix form too (operands rounded to bf16).
 static bool at_exact_on() { return at_exact_level() >= 1; }
 static bool at_exact_fits(int S, int dk, int dv) { return S <= ATX_MAX_S && dk <= ATX_MAX_D && dv <= ATX_MAX_D; }
 

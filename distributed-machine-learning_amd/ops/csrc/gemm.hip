@@ -906,14 +906,8 @@ __global__ __launch_bounds__(P8_THREADS) void mt_gemm_p8_grouped_bwd_kernel(cons
 }
 
 // Large single GEMMs take the eight-wave 256-tile form once they have this many 256-tiles (0: never).
-static int p8_limit = -1;
-static int p8_min_tiles() {
-  if (p8_limit < 0) {
-    const char* e = getenv("MITUNE_P8_MIN_TILES");
-    p8_limit = e ? atoi(e) : 256;
-  }
-  return p8_limit;
-}
+static int p8_limit = 256;
+static int p8_min_tiles() { return p8_limit; }
 // schedule (-1: by mode -- one barrier per K-tile when both operands are K-major, two otherwise: the forward GEMM gains
 // 4-8 % from the single barrier, the input- and weight-gradient GEMMs lose 10-15 % to the shorter time their refills get;
 // 0 / 1 force the two-barrier / one-barrier form, +8 / +16 are timing-only ablations without MFMAs / without refills)

@@ -58,26 +58,21 @@ __global__ __launch_bounds__(F32_THREADS) void mt_gemm_f32_bwd_kernel(const MtGe
     mt_head_reduce_body(hr.slots, hr.ids, step, hr.scratch, hr.max_chunks, hr.rec, b - n_wtiles - n_dtiles);
 }
 
-// tile_edge selects tile and pipeline: 128, 64, 32 = that edge on the two-stage, two-barrier pipeline (a 64-tile workgroup
-// holds 32 KB of LDS, so five fit a CU: the throughput forms); 65 = 64-tiles, three stages, one barrier (kept for
-// comparison: 7-22 % slower than 64); 66 = 64-tiles, four stages and 33 = 32-tiles, eight stages (64 KB of LDS either
-// way) and 35 = 33 with four K-steps per barrier: deep-prefetch forms for launches of a few tiles per CU.  Measured on
-// 13-slot launches they change nothing that matters (weight gradient of 16 tiles over 1024 rows: 19.4 us with two stages,
-// 20.0 with eight, 17.4 with four K-steps per barrier), which shows that such a tile is bound by the dependent chain inside
-// a K-step (LDS fragment reads -> MFMAs on one accumulator), not by memory latency or barriers; the engine does not
-// select them.  The tile list must have been built with the same edge.
+// tile_edge selects the tile: 128, 64 or 32, all on the two-stage, two-barrier pipeline (a 64-tile workgroup holds 32 KB
+// of LDS, so five fit a CU).  Deeper pipelines were built and measured for launches of a few tiles per CU and dropped:
+// 64-tiles with three stages and one barrier were 7-22 % slower; 64-tiles with four stages, 32-tiles with eight, and the
+// latter with four K-steps per barrier changed nothing that matters on 13-slot launches (weight gradient of 16 tiles over
+// 1024 rows: 19.4 us with two stages, 20.0 with eight, 17.4 with four K-steps per barrier) -- such a tile is bound by the
+// dependent chain inside a K-step (LDS fragment reads -> MFMAs on one accumulator), not by memory latency or barriers.
+// The tile list must have been built with the same edge.
 #define MT_F32_FORMS(CALL)                    \
   switch (tile_edge) {                        \
     case 128: { CALL(2, 128); } break;        \
     case 64: { CALL(2, 64); } break;          \
-    case 65: { CALL(3, 64); } break;          \
-    case 66: { CALL(4, 64); } break;          \
-    case 33: { CALL(8, 32); } break;          \
-    case 35: { CALL(8, 32, 4); } break;       \
     default: { CALL(2, 32); } break;          \
   }
 
-static bool f32_edge_ok(int e) { return e == 128 || (e >= 64 && e <= 66) || e == 32 || e == 33 || e == 35; }
+static bool f32_edge_ok(int e) { return e == 128 || e == 64 || e == 32; }
 
 extern "C" int mt_gemm_f32_launch(int mode, const MtGemmGroup* groups, const MtTile* tiles, int ntiles, int step,
                                   int flags, int arow0, int i_override, int ksplits, size_t split_stride, int tile_edge,

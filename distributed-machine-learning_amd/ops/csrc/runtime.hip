@@ -121,11 +121,8 @@ static inline int f32_edge(int code) {
   }
 }
 
-// 256-tile launches of bf16 packs: the eight-wave pipelined form (258), or with MITUNE_BIG_FORM=256 the four-wave one
-static int big_form() {
-  static const int form = [] { const char* e = getenv("MITUNE_BIG_FORM"); return (e && atoi(e) == 256) ? 256 : 258; }();
-  return form;
-}
+// 256-tile launches of bf16 packs use the eight-wave pipelined form (258; 256 is the four-wave one, 30-50 % slower)
+static int big_form() { return 258; }
 
 static int plan_gather(const MtMlpPlan* p, int step, hipStream_t stream) {
   return (p->f32 ? mt_gather_f32_launch : mt_gather_launch)(p->gather, p->active_ids, p->n_active, p->max_batch, p->X, p->Y,

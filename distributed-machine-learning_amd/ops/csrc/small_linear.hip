@@ -304,110 +304,3 @@ extern "C" int mt_small_linear_bwd_tiled_launch(const float* X, const float* W, 
     hipLaunchKernelGGL(mt_small_linear_bwd_kernel, dim3((unsigned)blocks), dim3(SL_THREADS), 0, stream, p);
   return (int)hipGetLastError();
 }
-
-// ----------------------------------------------------------------------------------------------------
-// Forward of the same layers: Y = X W^T + b, f32, on the 16x16x4 instruction.  Both operands have the contraction index
-// contiguous (X[r][k], W[o][k]), so lane (n = l & 15, kg = l >> 4) reads ONE 16-byte piece of its row of X and one of
-// its row of W per sixteen contraction steps and feeds four instructions from them.  No library call is left in the
-// training step of a small f32 trial: nothing shares a BLAS workspace between trials replayed on different streams,
-// and an eager pass (warm-up, capture) does not pay the library's per-call host cost.
-//   ksplit 1: a wave owns a 16x16 output tile over the whole contraction (workgroup: 256 rows x 16 columns);
-//   ksplit 4: four waves share a tile and add their accumulators through LDS (64 rows x 16 columns), for wide inputs.
-struct MtSmallLinFwd {
-  const float* X;     // [R, in]
-  const float* W;     // [out, in]
-  const float* bias;  // [out] or null
-  float* Y;           // [R, out]
-  int R, in, out;
-  int nto;            // 16-column tiles along `out`
-  int ksplit;         // 1 or 4
-  int kq;             // contraction columns per wave (multiple of 16); ksplit * kq >= in
-  int relu;
-};
-
-__global__ __launch_bounds__(SL_THREADS) void mt_small_linear_fwd_kernel(const MtSmallLinFwd p) {
-  __shared__ float red[SL_WAVES][256];
-  const int t = threadIdx.x, wave = t >> 6, l = t & 63, n = l & 15, kg = l >> 4;
-  const int blk = blockIdx.x;
-  const int sub = p.ksplit == 4 ? (wave >> 2) : wave, quarter = p.ksplit == 4 ? (wave & 3) : 0;
-  const int rows_per_block = p.ksplit == 4 ? 64 : 256;
-  const int rb = (blk / p.nto) * rows_per_block, o0 = (blk % p.nto) * 16;
-  const int r0 = rb + sub * 16;
-  const int row = r0 + n, ocol = o0 + n;
-  const bool row_ok = row < p.R, col_ok = ocol < p.out;
-  const float* a_row = p.X + (size_t)(row_ok ? row : 0) * p.in;
-  const float* b_row = p.W + (size_t)(col_ok ? ocol : 0) * p.in;
-  const bool vec = (p.in & 3) == 0;
-  const int k_begin = quarter * p.kq, k_end = min(p.in, k_begin + p.kq);
-  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-  if (r0 < p.R) {
-    for (int k0 = k_begin; k0 < k_end; k0 += 128) {    // a round: 8 x (16-byte A piece + 16-byte B piece), then <= 32 MFMAs
-      float a[8][4], b[8][4];
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int kb = k0 + it * 16 + kg * 4;
-        if (vec && kb + 3 < k_end) {
-          const float4 va = row_ok ? *reinterpret_cast<const float4*>(a_row + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
-          const float4 vb = col_ok ? *reinterpret_cast<const float4*>(b_row + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
-          a[it][0] = va.x; a[it][1] = va.y; a[it][2] = va.z; a[it][3] = va.w;
-          b[it][0] = vb.x; b[it][1] = vb.y; b[it][2] = vb.z; b[it][3] = vb.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            a[it][j] = (row_ok && kb + j < k_end) ? a_row[kb + j] : 0.f;
-            b[it][j] = (col_ok && kb + j < k_end) ? b_row[kb + j] : 0.f;
-          }
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        if (k0 + it * 16 < k_end) {                    // wave-uniform
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc = mfma4(a[it][j], b[it][j], acc);
-        }
-      }
-    }
-  }
-  if (p.ksplit == 4) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) red[wave][i * 64 + l] = acc[i];
-    __syncthreads();
-    const int g = t >> 8, e = t & 255, i = e >> 6, ll = e & 63;
-    float v = (red[g * 4][e] + red[g * 4 + 1][e]) + (red[g * 4 + 2][e] + red[g * 4 + 3][e]);
-    const int r = rb + g * 16 + 4 * (ll >> 4) + i, c = o0 + (ll & 15);
-    if (r < p.R && c < p.out) {
-      if (p.bias != nullptr) v += p.bias[c];
-      if (p.relu) v = fmaxf(v, 0.f);
-      p.Y[(size_t)r * p.out + c] = v;
-    }
-  } else if (col_ok) {
-    const float bv = p.bias != nullptr ? p.bias[ocol] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = r0 + 4 * kg + i;
-      if (r < p.R) {
-        float v = acc[i] + bv;
-        if (p.relu) v = fmaxf(v, 0.f);
-        p.Y[(size_t)r * p.out + ocol] = v;
-      }
-    }
-  }
-}
-
-extern "C" int mt_small_linear_fwd_launch(const float* X, const float* W, const float* bias, float* Y, int R, int in, int out,
-                                          int relu, hipStream_t stream) {
-  if (R <= 0 || in <= 0 || out <= 0) return -1;
-  if (!X || !W || !Y) return -2;
-  if ((((uintptr_t)X | (uintptr_t)W) & 15) != 0) return -3;      // 16-byte loads of X and W rows
-  MtSmallLinFwd p;
-  p.X = X; p.W = W; p.bias = bias; p.Y = Y; p.R = R; p.in = in; p.out = out; p.relu = relu;
-  p.nto = (out + 15) / 16;
-  p.ksplit = in >= 256 ? 4 : 1;
-  p.kq = ((in + p.ksplit - 1) / p.ksplit + 15) / 16 * 16;
-  if ((long)p.ksplit * p.kq < in) return -5;
-  const int rows_per_block = p.ksplit == 4 ? 64 : 256;
-  const long blocks = (long)((R + rows_per_block - 1) / rows_per_block) * p.nto;
-  if (blocks <= 0 || blocks > 0x7fffffffL) return -6;
-  hipLaunchKernelGGL(mt_small_linear_fwd_kernel, dim3((unsigned)blocks), dim3(SL_THREADS), 0, stream, p);
-  return (int)hipGetLastError();
-}

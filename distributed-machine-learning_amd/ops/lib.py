@@ -96,12 +96,6 @@ class FlatOpt(C.Structure):
                 ("total", c_int32), ("step", c_int32), ("pad", c_int32)]
 
 
-class HeadMlp(C.Structure):
-    _fields_ = [("W", c_void_p * HM_MAXL), ("b", c_void_p * HM_MAXL), ("dW", c_void_p * HM_MAXL),
-                ("db", c_void_p * HM_MAXL), ("dims", c_int32 * (HM_MAXL + 1)), ("n_layers", c_int32),
-                ("act_stride", c_int32), ("dz_stride", c_int32)]
-
-
 # numpy views of the same layouts, for building whole descriptor tables vectorised
 GEMM_GROUP_DTYPE = np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("aux", "<u8"), ("aux_out", "<u8"),
                              ("seed", "<u8"),
@@ -219,8 +213,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     for fn in (lib.mt_attn_fwd_launch, lib.mt_attn_bwd_launch, lib.mt_ln_fwd_launch, lib.mt_ln_bwd_launch,
                lib.mt_ln_bwd_blocks):
         fn.restype = C.c_int
-    if lib.mt_flat_opt_sizeof() != C.sizeof(FlatOpt) or lib.mt_head_mlp_sizeof() != C.sizeof(HeadMlp):
-        raise KernelLibraryError("FlatOpt / HeadMlp layout mismatch between lib.py and the library")
+    if lib.mt_flat_opt_sizeof() != C.sizeof(FlatOpt):
+        raise KernelLibraryError("FlatOpt layout mismatch between lib.py and the library")
     if lib.mt_grad_seg_sizeof() != 24:
         raise KernelLibraryError("MtGradSeg is not 24 bytes")
     lib.mt_flat_optim_seg_launch.argtypes = [c_void_p] * 4 + [C.c_int, c_void_p, c_void_p, C.c_int, c_void_p]
@@ -255,8 +249,6 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_small_linear_bwd_launch.restype = C.c_int
     lib.mt_small_linear_bwd_tiled_launch.argtypes = [c_void_p] * 6 + [C.c_int] * 4 + [c_void_p]
     lib.mt_small_linear_bwd_tiled_launch.restype = C.c_int
-    lib.mt_small_linear_fwd_launch.argtypes = [c_void_p] * 4 + [C.c_int] * 4 + [c_void_p]
-    lib.mt_small_linear_fwd_launch.restype = C.c_int
     lib.mt_cursor_batch_launch.argtypes = [c_void_p, c_void_p, C.c_long, c_void_p, c_void_p, C.c_long, C.c_long, C.c_long,
                                            c_void_p, c_void_p, C.c_int, c_void_p]
     lib.mt_cursor_batch_launch.restype = C.c_int
@@ -281,12 +273,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_dwconv_chunks.argtypes = [C.c_long]
     lib.mt_dwconv_launch.argtypes = [c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]
     lib.mt_dwconv_wgrad_launch.argtypes = [c_void_p] * 3 + [C.c_long, C.c_int, C.c_int, C.c_int, c_void_p]
-    lib.mt_head_mlp_fwd_launch.argtypes = [C.POINTER(HeadMlp), c_void_p, C.c_long, c_void_p, c_void_p, C.c_int, c_void_p]
-    lib.mt_head_mlp_bwd_launch.argtypes = [C.POINTER(HeadMlp), c_void_p, C.c_long, c_void_p, c_void_p, c_void_p, c_void_p,
-                                           C.c_long, C.c_int, c_void_p]
     for fn in (lib.mt_flat_optim_blocks, lib.mt_flat_optim_launch, lib.mt_posenc_fwd_launch, lib.mt_posenc_bwd_launch,
-               lib.mt_dwconv_chunks, lib.mt_dwconv_launch, lib.mt_dwconv_wgrad_launch, lib.mt_head_mlp_fwd_launch,
-               lib.mt_head_mlp_bwd_launch):
+               lib.mt_dwconv_chunks, lib.mt_dwconv_launch, lib.mt_dwconv_wgrad_launch):
         fn.restype = C.c_int
     lib.mt_rowblock_max_width.restype = C.c_int
     lib.mt_mlp_train_steps.argtypes = [C.POINTER(MlpPlan), C.c_int, C.c_int, c_void_p]
@@ -304,6 +292,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     for fn in (lib.mt_gemm_launch, lib.mt_gather_launch, lib.mt_head_loss_launch, lib.mt_head_eval_launch,
                lib.mt_optim_launch, lib.mt_mlp_train_steps, lib.mt_mlp_eval):
         fn.restype = C.c_int
+    from ..options import OPTIONS
+    lib.mt_attn_exact_level(int(OPTIONS.attn_exact))
     _lib = lib
     return lib
 

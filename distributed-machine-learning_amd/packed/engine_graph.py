@@ -33,8 +33,7 @@ whole launch resident; two such launches from different streams split the CUs be
 workgroups that the other keeps from being scheduled.  The small-kernel regime never met them (its GEMMs are plain
 tiles).  Dense layers now run on this package's own tile kernels (``ops/linear.py``: no workgroup ever waits for
 another), with which the same pack completes on any number of streams (156 steps x 3 slots in 1.8 s, unbounded
-run-ahead).  With ``MITUNE_OWN_GEMM=0`` (library GEMMs) a pack outside the small-kernel regime is refused several
-streams.  Independently of that, the host is kept at most ``IN_FLIGHT`` replays ahead of each stream it feeds (an event
+run-ahead); no library GEMM route is left in the package.  Independently of that, the host is kept at most ``OPTIONS.in_flight`` replays ahead of each stream it feeds (an event
 ring per stream), which bounds the queue depth at no cost: in the small regime the device drains replays as fast as
 one thread enqueues them.
 
@@ -54,12 +53,13 @@ from .engine import TorchPackEngine, _Slot
 from .permutation import permute, round_keys
 from ..models.mlp import MLPTrialSpec, init_mlp_state
 from ..ops import rng
+from ..options import OPTIONS
 from ..train.graphed import FlatOptimizer, FlatParams, GraphedTrainer
 from ..train.losses import MAPE_EPS, elementwise_loss, get_criterion
 
 DEFAULT_STREAMS = 4      # = the runtime's hardware queues per process; which streams exactly: packed/streams.py
 SMALL_STEP_ROWS = 4096   # batch x tokens up to which slots are issued concurrently by default
-IN_FLIGHT = int(os.environ.get("MITUNE_IN_FLIGHT", "8"))      # graph replays the host may be ahead of any one stream while it feeds several
+# OPTIONS.in_flight: graph replays the host may be ahead of any one stream while it feeds several
 
 
 class _FlowControl:
@@ -67,8 +67,8 @@ class _FlowControl:
     ``j`` waits until all but the newest ``depth - 1`` pieces of work enqueued there have finished; ``sent(j, stream)``
     marks the piece just enqueued."""
 
-    def __init__(self, n_streams: int, depth: int = IN_FLIGHT):
-        self.depth = max(1, int(depth))
+    def __init__(self, n_streams: int, depth: Optional[int] = None):
+        self.depth = max(1, int(OPTIONS.in_flight if depth is None else depth))
         self.rings: List[List[torch.cuda.Event]] = [[] for _ in range(n_streams)]
         self.count = [0] * n_streams
 
@@ -100,12 +100,12 @@ class GraphPackEngine(TorchPackEngine):
         self._pending_epoch = None
         self._prep_stream = torch.cuda.Stream(self.device)
         self._eval_ready = None        # slot -> [3] sums produced by the replays issued with the last training epoch
-        self._eval_graphs = bool(int(trainable.model_kwargs.get("eval_graphs", os.environ.get("MITUNE_EVAL_GRAPHS", 1))))
+        self._eval_graphs = bool(int(trainable.model_kwargs.get("eval_graphs", OPTIONS.eval_graphs)))
         self.prepared_total = 0
-        n = int(trainable.model_kwargs.get("streams", os.environ.get("MITUNE_GRAPH_STREAMS", DEFAULT_STREAMS)))
+        n = int(trainable.model_kwargs.get("streams", OPTIONS.graph_streams))
         self._n_streams = max(1, min(n, 16))
         # an explicit request for streams is honoured for every pack; the default keeps big-kernel packs on one stream
-        self._streams_forced = "streams" in trainable.model_kwargs or os.environ.get("MITUNE_GRAPH_FORCE_STREAMS") == "1"
+        self._streams_forced = "streams" in trainable.model_kwargs or OPTIONS.graph_force_streams
         self._streams: List[torch.cuda.Stream] = []     # picked at the first concurrent epoch (packed/streams.py)
         self._calibrated = False
 
@@ -240,12 +240,6 @@ class GraphPackEngine(TorchPackEngine):
         small = samples_per_launch * self._tokens_per_sample() <= bound
         if not (small or self._streams_forced) or self._n_streams < 2 or len(order) < 2:
             return [torch.cuda.current_stream(self.device)]
-        if not small:
-            from ..ops import linear as _lin
-            if not _lin.OWN_GEMM:
-                raise ValueError("several streams were requested for a pack of large steps while MITUNE_OWN_GEMM=0 routes "
-                                 "its dense layers to the BLAS library: the library's stream-K GEMM kernels deadlock when "
-                                 "launched from several streams at once; drop 'streams' or keep the own GEMM kernels on")
         if not self._calibrated:
             self._calibrate_streams()
         return self._streams
@@ -307,7 +301,7 @@ class GraphPackEngine(TorchPackEngine):
                     if i > batches or (i == batches and not ride):
                         continue
                     q = j % ns
-                    flow.admit(q)                       # never more than IN_FLIGHT replays ahead of a stream
+                    flow.admit(q)                       # never more than OPTIONS.in_flight replays ahead of a stream
                     with torch.cuda.stream(streams[q]):
                         if i < batches:
                             tr.step_once(i)

@@ -20,7 +20,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-import os
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -31,6 +30,7 @@ from .permutation import half_bits, round_keys
 from .trainable import PackedTrainable
 from ..models.mlp import MLPTrialSpec, init_mlp_state
 from ..ops import lib as L
+from ..options import OPTIONS
 from ..train.losses import LOSS_CODES
 from ..train.optim import OPT_CODES
 
@@ -45,20 +45,18 @@ BIG_TILE = 256         # tile edge of the throughput-form GEMM kernels
 # 256-tile over a 64-column layer is three quarters padding).  Eight-wave kernel on 256 slots x 512^3: forward 110 us
 # against 124 on 128-tiles, input gradient 129 / 136, weight gradient 135 / 161 (the earlier four-wave 256-tile form:
 # 167 / 309 / 242, which is why this stayed off until the eight-wave form existed).  0 disables.
-BIG_MIN_TILES = int(os.environ.get("MITUNE_BIG_MIN_TILES", "256"))
-BIG_COST = float(os.environ.get("MITUNE_BIG_COST", "3.5"))
-KSPLITS_SMALL = int(os.environ.get("MITUNE_KSPLITS_SMALL", str(MAX_KSPLITS)))     # wgrad splits of packs with <= 128 tiles
+# (OPTIONS.big_min_tiles, OPTIONS.big_cost; OPTIONS.ksplits_small: weight-gradient splits of packs with <= 128 tiles)
 GRAPH_STEPS = 25       # steps per captured hipGraph block (3125 = 125 blocks; shorter epochs run the rest directly)
 # Exact-f32 packs: launches with fewer 128-tiles than this use 64x64 tiles instead.  The f32 matrix instruction is 16x
 # slower than the bf16 one, so a 64-tile still hides its staging (16 B/clk/CU) and the finer tiles cut both the padding
 # of narrow layers and the tail of a launch that does not fill the chip.
-F32_SMALL_TILES = int(os.environ.get("MITUNE_F32_SMALL_TILES", "2048"))
+# (OPTIONS.f32_small_tiles)
 SMALL_TILE = 64
 # Launches with fewer 64-tiles than this (a late-round layer of a dozen survivors: about one tile per CU) use 32x32
 # tiles: four times the workgroups for the same arithmetic.  Measured on 16 slots x [256 x 128] . [128 x 128]: forward
 # 6.5 -> 4.5 us, weight gradient 10.9 -> 6.6 us; at 512 64-tiles the two forms are level.  Headline search by threshold:
 # 0 (never) 72.7 k trials/hour, 256 73.9 k, 512 75.5 k, 768 75.1 k, 1024 74.4 k, 2048 74.9 k.
-F32_TINY_TILES = int(os.environ.get("MITUNE_F32_TINY_TILES", "512"))
+# (OPTIONS.f32_tiny_tiles)
 TINY_TILE = 32
 # Exact-f32 packs of 32 and more trials run as independent chains of launches on separate HIP streams: every launch of
 # the f32 engine ends in a tail of long-running tiles (the f32 matrix instruction is sixteen times slower than the bf16
@@ -69,11 +67,11 @@ def _chain_rule(text: str):
     return sorted(rule, reverse=True)
 
 
-F32_CHAIN_RULE = _chain_rule(os.environ.get("MITUNE_F32_CHAIN_RULE", "128:4,32:2"))
+# (OPTIONS.f32_chain_rule)
 # Chains by batch size: a trial's batch size sets how many steps its epoch has (N // batch), so a chain that mixes batch sizes
 # runs the step count of its smallest batch with ever fewer live slots in every launch.  With one chain per batch size the
 # chains of large batches finish early and the long chain of small batches carries no dead tiles ("0": the mixed deal).
-CHAINS_BY_BATCH = os.environ.get("MITUNE_CHAINS_BY_BATCH", "1") != "0"
+# (OPTIONS.chains_by_batch)
 DTYPES = ("bf16", "f32")
 # Row-block form of the exact-f32 training step (ops/csrc/rowblock.hip): one launch carries 16 batch rows of a trial
 # through every forward layer, the head and every input gradient with the activations staying in LDS, a second one
@@ -82,10 +80,8 @@ DTYPES = ("bf16", "f32")
 # per chain: "auto" takes it for chains of at most ROWBLOCK_MAX_BLOCKS 16-row blocks (the late rounds of a search, where a
 # step is bound by launch latencies), "1" whenever the shapes allow (every width and the feature count a multiple of 32,
 # at most 512), "0" never.
-ROWBLOCK = os.environ.get("MITUNE_ROWBLOCK", "auto")
-ROWBLOCK_MAX_BLOCKS = int(os.environ.get("MITUNE_ROWBLOCK_MAX_BLOCKS", "400"))
+# (OPTIONS.rowblock, OPTIONS.rowblock_max_blocks; OPTIONS.rowblock_mt: row tiles of 16 per workgroup, 2 for at most 4 layers)
 ROWBLOCK_ROWS = 16
-ROWBLOCK_MT = int(os.environ.get("MITUNE_ROWBLOCK_MT", "1"))      # row tiles of 16 per workgroup (2: at most 4 layers)
 
 def ceil8(x: int) -> int:
     return (x + 7) // 8 * 8
@@ -241,7 +237,7 @@ class HipPackEngine(PackEngine):
         # separate HIP streams.  One host thread cannot feed several chains kernel by kernel (a launch costs ~3.5 us
         # of host time), so each chain's steps are captured in blocks of GRAPH_STEPS as a hipGraph that reads its step
         # number from a device counter and is replayed block after block.  OFF by default ("streams": n or
-        # MITUNE_STREAMS=n enables it): measured wall-clock on the 256-trial search with streams on distinct hardware
+        # OPTIONS.streams = n enables it): measured wall-clock on the 256-trial search with streams on distinct hardware
         # queues, 7.02 s with one chain, 7.12 s with two or three and 7.23 s with four -- the grouped launches of even a
         # 16-trial pack are wide enough that splitting them only adds launches.  (Kernels of a few workgroups each, as in small Transformer trials, do overlap across
         # streams; packed/engine_graph.py uses that.)
@@ -249,7 +245,7 @@ class HipPackEngine(PackEngine):
         self._counters = torch.zeros(MAX_STREAMS, device=dev, dtype=torch.int32)
         self._chain_scratch = [torch.zeros_like(self.head_scratch) for _ in range(MAX_STREAMS - 1)]
         self._chains: List[_Chain] = []
-        self.n_streams_override = int(os.environ.get("MITUNE_STREAMS", kw.get("streams", 0)) or 0)
+        self.n_streams_override = int(OPTIONS.streams or kw.get("streams", 0) or 0)
         self._train_loss: Dict[int, float] = {}
         self._loss_pending = False          # the epoch's loss accumulators have not been read by the host yet
         self._round_steps: Dict[int, int] = {}
@@ -474,8 +470,8 @@ class HipPackEngine(PackEngine):
             # reads, and the optimiser is a quarter of a late-round step: end to end the 256-trial search takes 7.37 s
             # with 4 splits up to 128 tiles, 7.16 s with 2 and 7.15 s with none.  Splits are kept for very small packs.
             if tiles <= 32:
-                return min(4, KSPLITS_SMALL)
-            return min(2, KSPLITS_SMALL) if tiles <= 64 else 1
+                return min(4, OPTIONS.ksplits_small)
+            return min(2, OPTIONS.ksplits_small) if tiles <= 64 else 1
 
         rest = rule(max([v for l, v in per_layer.items() if l > 0] or [per_layer[0]]))
         return rest, max(rest, rule(per_layer[0]))
@@ -540,22 +536,22 @@ class HipPackEngine(PackEngine):
                 return sum(a * b for _, a, b, _ in tiled(lst, edge))
 
             if self.f32:      # tile-edge codes of the plan: 0 = 128, 2 = 64, 3 = 32
-                edge_f = SMALL_TILE if count(fl, TILE) < F32_SMALL_TILES else TILE
-                if count(fl, SMALL_TILE) < F32_TINY_TILES:
+                edge_f = SMALL_TILE if count(fl, TILE) < OPTIONS.f32_small_tiles else TILE
+                if count(fl, SMALL_TILE) < OPTIONS.f32_tiny_tiles:
                     edge_f = TINY_TILE
                 ks_l = ksplits0 if l == 0 else ksplits
-                edge_b = SMALL_TILE if count(dl, TILE) + count(wl, TILE) * ks_l < F32_SMALL_TILES else TILE
-                if count(dl, SMALL_TILE) + count(wl, SMALL_TILE) * ks_l < F32_TINY_TILES:
+                edge_b = SMALL_TILE if count(dl, TILE) + count(wl, TILE) * ks_l < OPTIONS.f32_small_tiles else TILE
+                if count(dl, SMALL_TILE) + count(wl, SMALL_TILE) * ks_l < OPTIONS.f32_tiny_tiles:
                     edge_b = TINY_TILE
                 code = {TILE: 0, SMALL_TILE: 2, TINY_TILE: 3}
                 out[f"big_fwd{l}"], out[f"big_bwd{l}"] = code[edge_f], code[edge_b]
             else:
                 # 256-tiles halve the bytes staged per flop; they pay once a launch still has enough of them to fill the chip
-                big_f = (BIG_MIN_TILES > 0 and count(fl, BIG_TILE) >= BIG_MIN_TILES
-                         and count(fl, BIG_TILE) * BIG_COST <= count(fl, TILE))
+                big_f = (OPTIONS.big_min_tiles > 0 and count(fl, BIG_TILE) >= OPTIONS.big_min_tiles
+                         and count(fl, BIG_TILE) * OPTIONS.big_cost <= count(fl, TILE))
                 nb_big, nb_128 = count(dl, BIG_TILE) + count(wl, BIG_TILE), count(dl, TILE) + count(wl, TILE)
-                big_b = (BIG_MIN_TILES > 0 and (not eval_mode) and ksplits0 == 1 and ksplits == 1
-                         and nb_big >= BIG_MIN_TILES and nb_big * BIG_COST <= nb_128)
+                big_b = (OPTIONS.big_min_tiles > 0 and (not eval_mode) and ksplits0 == 1 and ksplits == 1
+                         and nb_big >= OPTIONS.big_min_tiles and nb_big * OPTIONS.big_cost <= nb_128)
                 out[f"big_fwd{l}"], out[f"big_bwd{l}"] = int(big_f), int(big_b)
                 edge_f, edge_b = (BIG_TILE if big_f else TILE), (BIG_TILE if big_b else TILE)
             ft = balanced_tiles(tiled(fl, edge_f))
@@ -569,8 +565,8 @@ class HipPackEngine(PackEngine):
         if rb_mt:
             def n_tiles(edge):
                 return sum(((r_ + edge - 1) // edge) * ((c_ + edge - 1) // edge) * sp_ for _, r_, c_, _, sp_ in wl_all)
-            edge = SMALL_TILE if n_tiles(TILE) < F32_SMALL_TILES else TILE
-            if n_tiles(SMALL_TILE) < F32_TINY_TILES:
+            edge = SMALL_TILE if n_tiles(TILE) < OPTIONS.f32_small_tiles else TILE
+            if n_tiles(SMALL_TILE) < OPTIONS.f32_tiny_tiles:
                 edge = TINY_TILE
             wt = balanced_tiles([(g_, (r_ + edge - 1) // edge, (c_ + edge - 1) // edge, w_, sp_)
                                  for g_, r_, c_, w_, sp_ in wl_all])
@@ -582,7 +578,7 @@ class HipPackEngine(PackEngine):
     def _rowblock_mt(self, ids: List[int]) -> int:
         """Row tiles per workgroup of the row-block step for this chain (1 = 16 rows), or 0 when the chain trains by tile
         launches: a bf16 pack, a shape the kernel does not cover, or (in "auto") too many blocks for the form to pay."""
-        if not self.f32 or ROWBLOCK == "0":
+        if not self.f32 or OPTIONS.rowblock == "0":
             return 0
         wmax = int(self.lib.mt_rowblock_max_width())
         if self.F % 32 or self.F > wmax or self.Fpad != self.F:
@@ -593,9 +589,9 @@ class HipPackEngine(PackEngine):
             if any(h % 32 or h > wmax for h in s.layout.hidden) or len(s.layout.hidden) > L.MT_MAX_LAYERS:
                 return 0
             blocks += (min(s.spec.batch_size, self.n_train) + ROWBLOCK_ROWS - 1) // ROWBLOCK_ROWS
-        if ROWBLOCK != "1" and blocks > ROWBLOCK_MAX_BLOCKS:
+        if OPTIONS.rowblock != "1" and blocks > OPTIONS.rowblock_max_blocks:
             return 0
-        if ROWBLOCK_MT == 2 and all(len(self.slots[k].layout.hidden) <= 4 for k in ids):
+        if OPTIONS.rowblock_mt == 2 and all(len(self.slots[k].layout.hidden) <= 4 for k in ids):
             return 2
         return 1
 
@@ -707,7 +703,7 @@ class HipPackEngine(PackEngine):
             return max(1, min(MAX_STREAMS, self.n_streams_override, len(self.slots)))
         if self.f32:
             n = len(self.slots)
-            for min_slots, chains in F32_CHAIN_RULE:       # largest pack size first
+            for min_slots, chains in _chain_rule(OPTIONS.f32_chain_rule):       # largest pack size first
                 if n >= min_slots:
                     return max(1, min(MAX_STREAMS, chains, n))
         return 1
@@ -728,7 +724,7 @@ class HipPackEngine(PackEngine):
         for k in order:
             by_batch.setdefault(min(self.slots[k].spec.batch_size, self.n_train), []).append(k)
         # (packs too small for the chain rule stay one chain: 13 + 3 survivors as two chains ran 35 % slower than as one)
-        if not (CHAINS_BY_BATCH and self.f32 and not self.n_streams_override and len(by_batch) > 1 and n > 1):
+        if not (OPTIONS.chains_by_batch and self.f32 and not self.n_streams_override and len(by_batch) > 1 and n > 1):
             return [sorted(order[c::n]) for c in range(n)]
         groups = [by_batch[b] for b in sorted(by_batch)]            # ascending batch size = descending step count
         while len(groups) > MAX_STREAMS:                             # merge the two neighbours with the fewest slots
@@ -762,7 +758,7 @@ class HipPackEngine(PackEngine):
             ch.graph = None
             self._chains.append(ch)
         self._pack_ksplits = None
-        if os.environ.get("MITUNE_CHAIN_DEBUG"):
+        if OPTIONS.chain_debug:
             import sys
             print(f"[mitune] chains: {[(len(ch.ids), sorted({self.slots[k].spec.batch_size for k in ch.ids})) for ch in self._chains]}",
                   file=sys.stderr, flush=True)

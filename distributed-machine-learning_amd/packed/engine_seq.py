@@ -16,7 +16,7 @@ Contract shared with the other engines (checked in tests against ``TorchPackEngi
 from the trial's own seeded stream, batches from the keyed permutation of (seed, trial, epoch), an epoch is
 ``N // batch`` steps, validation metrics are sample-weighted sums over the whole validation set.  Arithmetic is f32
 throughout: exact-f32 MFMA for the dense layers, f32 multiply-add chains in the attention kernels for sequences of up to
-128 tokens (the same kernels one-trial-at-a-time training uses; ``MITUNE_ATTN_EXACT=0`` or ``1`` selects the bf16
+128 tokens (the same kernels one-trial-at-a-time training uses; ``OPTIONS.attn_exact`` 0 or 1 selects the bf16
 matrix form for all, or for the longer, sequences instead).
 """
 from __future__ import annotations
@@ -36,14 +36,14 @@ from .permutation import half_bits, mix32, round_keys
 from .trainable import PackedTrainable
 from ..models.mlp import MLPTrialSpec
 from ..ops import lib as L
+from ..options import OPTIONS
 from ..train.losses import LOSS_CODES
 from ..train.optim import OPT_CODES
 
 MAX_LAYERS = 8
 # host threads drawing the next trials' weights while the GPU trains (1 / 2 / 4 threads on the 2048-trial search: 6.27 /
 # 6.19 / 6.64 s -- more threads fight over the interpreter lock between the many small fills)
-PREP_THREADS = int(os.environ.get("MITUNE_SEQ_PREP_THREADS", "2"))
-KSPLITS = int(os.environ.get("MITUNE_SEQ_KSPLITS", "2"))     # weight-gradient slabs: the token contraction is split in this many
+# (OPTIONS.seq_prep_threads; OPTIONS.seq_ksplits: weight-gradient slabs, the token contraction is split in this many)
 
 
 def _chain_rule(text: str):
@@ -54,7 +54,7 @@ def _chain_rule(text: str):
 # separate HIP streams (the first rule reached applies; none: one chain).  Measured per pack step, one chain / two
 # chains / four chains: 16 slots 907 / 985 / 970 us, 64 slots 2236 / 2100 / 2202 us, 128 slots 3965 / 3702 / 4131 us --
 # two chains fill each other's launch tails once a pack is big enough to keep both busy.
-SEQ_CHAIN_RULE = _chain_rule(os.environ.get("MITUNE_SEQ_CHAIN_RULE", "32:2"))
+# (OPTIONS.seq_chain_rule)
 
 
 def ceil4(x: int) -> int:
@@ -273,7 +273,7 @@ class SeqPackEngine(PackEngine):
         self.max_batch = int(kw.get("max_batch", kw.get("batch_size", 32)))
         if self.max_layers > MAX_LAYERS or self.max_d > 256 or self.max_batch > 1024:
             raise ValueError("max_layers <= 8, max_d_model <= 256, max_batch <= 1024")
-        self.ksplits = max(1, int(kw.get("ksplits", KSPLITS)))
+        self.ksplits = max(1, int(kw.get("ksplits", OPTIONS.seq_ksplits)))
         Xtr, Xva = trainable.train[0], trainable.val[0]
         self.n_train, self.S, self.F = int(Xtr.shape[0]), int(Xtr.shape[1]), int(Xtr.shape[2])
         self.n_val = int(Xva.shape[0])
@@ -428,7 +428,7 @@ class SeqPackEngine(PackEngine):
         # by a few worker threads (the tensor library releases the interpreter lock while it fills)
         if self._pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=PREP_THREADS, thread_name_prefix="mitune-seq-init")
+            self._pool = ThreadPoolExecutor(max_workers=max(1, OPTIONS.seq_prep_threads), thread_name_prefix="mitune-seq-init")
         fut = self._pool.submit(self._initial_image, lay, trial_index, self._pinned(), torch.Generator())
         self._prepared[int(trial_index)] = (dict(config), fut)
         self.prepared_total += 1
@@ -781,7 +781,7 @@ class SeqPackEngine(PackEngine):
 
     def _n_chains(self) -> int:
         n = len(self.slots)
-        for min_slots, chains in SEQ_CHAIN_RULE:
+        for min_slots, chains in _chain_rule(OPTIONS.seq_chain_rule):
             if n >= min_slots:
                 return max(1, min(chains, n))
         return 1

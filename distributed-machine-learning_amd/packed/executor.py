@@ -26,6 +26,7 @@ import torch
 
 from .engine import PackEngine, TorchPackEngine
 from .trainable import PackedTrainable
+from ..options import OPTIONS
 from ..parallel.comm import Comm, default_comm
 from ..tune import checkpoint as ckpt
 from ..tune.executor import Event, Executor
@@ -50,7 +51,7 @@ def make_engine(trainable: PackedTrainable, device: torch.device, capacity: Opti
         if device.type == "cuda":
             kind = "hip" if trainable.model == "mlp" else "graph"
             if trainable.model == "simple_transformer" and trainable.dtype == "f32" \
-                    and os.environ.get("MITUNE_SEQ_ENGINE", "1") != "0":
+                    and OPTIONS.seq_engine:
                 # small encoder trials share launches (grouped GEMMs, grouped attention / LayerNorm); shapes the grouped
                 # kernels do not cover stay on the one-graph-per-slot engine
                 from . import engine_seq

@@ -38,6 +38,7 @@ import torch
 import torch.nn.functional as F
 
 from .comm import Comm, LocalComm
+from ..options import OPTIONS
 from ..models.mlp import MLPTrialSpec, init_mlp_state, lr_factor
 from ..packed.permutation import permute, round_keys
 from ..train.losses import MAPE_EPS, elementwise_loss
@@ -324,9 +325,9 @@ class HipDPEngine:
         self._opt = torch.from_numpy(hp.view(np.uint8).reshape(-1).copy()).to(dev)
         # collectives: a direct RCCL communicator when there is more than one rank
         self.rccl = None
-        # MITUNE_DP_FORCE_COLLECTIVES=1 issues the per-bucket all-reduces even with one rank (over a one-rank communicator
+        # OPTIONS.dp_force_collectives issues the per-bucket all-reduces even with one rank (over a one-rank communicator
         # they are copies): the event / stream choreography of the C++ driver can then be exercised on a single GPU
-        force = os.environ.get("MITUNE_DP_FORCE_COLLECTIVES") == "1"
+        force = OPTIONS.dp_force_collectives
         if tr.comm.world_size > 1 or force:
             from .rccl import RcclComm
             self.rccl = RcclComm(tr.comm, dev)

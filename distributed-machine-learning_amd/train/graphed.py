@@ -32,6 +32,7 @@ import torch
 
 from .optim import OPT_CODES
 from ..ops import rng
+from ..options import OPTIONS
 
 log = logging.getLogger("mitune")
 
@@ -291,7 +292,7 @@ class GraphedTrainer:
         self._fast = False
         if dev.type == "cuda":
             from ..ops.batch_hip import cursor_batch_ok
-            self._fast = cursor_batch_ok(self.perm, self.pos, X, Y) and os.environ.get("MITUNE_FAST_BATCH", "1") != "0"
+            self._fast = cursor_batch_ok(self.perm, self.pos, X, Y) and OPTIONS.fast_batch
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.graphed = False
         if use_graph and not SHARED_GPU_THREADS and dev.type == "cuda" and self.N >= self.B:

@@ -1,4 +1,4 @@
-"""Per-trial checkpoints: ``checkpoint_<iter:06d>/{model.pt, optimizer.pt, meta.json}``.
+"""Per-trial checkpoints: ``checkpoint_<iter:06d>/{model.pt, optimizer.pt, <other tensor entries>.pt, meta.json}``.
 
 The reference never saves a model (its trainables end at ``tune.report``,
 /root/reference/ray-tune-hpo-regression.py:373); the layout here is the "per-trial model
@@ -11,7 +11,6 @@ from __future__ import annotations
 
 import json
 import os
-import pickle
 import re
 import shutil
 from typing import Any, Dict, List, Optional
@@ -30,33 +29,66 @@ def list_checkpoints(trial_dir: str) -> List[str]:
     return [os.path.join(trial_dir, n) for n in names]
 
 
+def _tensor_tree(v: Any) -> bool:
+    """True for what ``torch.load(..., weights_only=True)`` reads back: tensors, numbers, strings, None and lists /
+    tuples / string-keyed dicts of them."""
+    import torch
+    if isinstance(v, torch.Tensor) or v is None or isinstance(v, (bool, int, float, str)):
+        return True
+    if isinstance(v, dict):
+        return all(isinstance(k, (str, int)) and _tensor_tree(x) for k, x in v.items())
+    if isinstance(v, (list, tuple)):
+        return all(_tensor_tree(x) for x in v)
+    return False
+
+
+def _plain(v: Any) -> Any:
+    """numpy arrays and scalars become tensors / Python numbers, containers are walked; everything else is unchanged."""
+    import numpy as np
+    import torch
+    if isinstance(v, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(v))
+    if isinstance(v, np.generic):
+        return v.item()
+    if isinstance(v, dict):
+        return {k: _plain(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return type(v)(_plain(x) for x in v)
+    return v
+
+
 def save_checkpoint(trial_dir: str, iteration: int, checkpoint: Any, keep_num: Optional[int] = None) -> str:
     """Persist ``checkpoint`` (a dict) under ``trial_dir``.
 
-    Keys ``model`` / ``optimizer`` holding tensors dicts are written with ``torch.save`` as
-    ``model.pt`` / ``optimizer.pt``; everything JSON-able goes to ``meta.json``; anything else is
-    pickled to ``extra.pkl``.
+    Everything JSON-able goes to ``meta.json``; every other entry must be a tree of tensors / numpy arrays / numbers /
+    strings and is written with ``torch.save`` as ``<key>.pt`` (``model.pt`` and ``optimizer.pt`` among them), a file
+    that ``torch.load(..., weights_only=True)`` reads without executing anything from it.  A value that is neither (an
+    arbitrary Python object) raises ``TypeError``: a checkpoint directory is something users copy between machines, so
+    nothing in it is ever unpickled.
     """
     import torch
     d = checkpoint_dir(trial_dir, iteration)
     os.makedirs(d, exist_ok=True)
     meta: Dict[str, Any] = {"training_iteration": int(iteration)}
-    extra: Dict[str, Any] = {}
+    tensor_keys: List[str] = []
     if not isinstance(checkpoint, dict):
         checkpoint = {"value": checkpoint}
     for k, v in checkpoint.items():
-        if k in ("model", "optimizer") and isinstance(v, dict):
-            torch.save(v, os.path.join(d, f"{k}.pt"))
-        else:
+        if k not in ("model", "optimizer"):
             try:
                 json.dumps(v)
                 meta[k] = v
+                continue
             except (TypeError, ValueError):
-                extra[k] = v
+                pass
+        v = _plain(v)
+        if not re.fullmatch(r"[A-Za-z0-9_\-]+", str(k)) or not _tensor_tree(v):
+            raise TypeError(f"checkpoint entry {k!r} ({type(v).__name__}) is neither JSON-able nor a tree of tensors; "
+                            "convert it before reporting the checkpoint")
+        torch.save(v, os.path.join(d, f"{k}.pt"))
+        tensor_keys.append(str(k))
+    meta["tensor_entries"] = tensor_keys
     dump_json(meta, os.path.join(d, "meta.json"))
-    if extra:
-        with open(os.path.join(d, "extra.pkl"), "wb") as f:
-            pickle.dump(extra, f)
     if keep_num:
         for old in list_checkpoints(trial_dir)[:-keep_num]:
             shutil.rmtree(old, ignore_errors=True)
@@ -64,21 +96,21 @@ def save_checkpoint(trial_dir: str, iteration: int, checkpoint: Any, keep_num: O
 
 
 def load_checkpoint(path: str, map_location: Any = "cpu") -> Dict:
-    """Inverse of ``save_checkpoint`` (``extra.pkl`` is only ever a file this framework wrote)."""
+    """Inverse of ``save_checkpoint``: ``meta.json`` plus every ``<key>.pt`` it lists, each read with
+    ``weights_only=True``."""
     import torch
     out: Dict[str, Any] = {}
+    keys = ["model", "optimizer"]
     meta_path = os.path.join(path, "meta.json")
     if os.path.exists(meta_path):
         with open(meta_path) as f:
-            out.update(json.load(f))
-    for k in ("model", "optimizer"):
+            meta = json.load(f)
+        keys = list(dict.fromkeys(keys + list(meta.pop("tensor_entries", []))))
+        out.update(meta)
+    for k in keys:
         p = os.path.join(path, f"{k}.pt")
         if os.path.exists(p):
             out[k] = torch.load(p, map_location=map_location, weights_only=True)
-    p = os.path.join(path, "extra.pkl")
-    if os.path.exists(p):
-        with open(p, "rb") as f:
-            out.update(pickle.load(f))
     return out
 
 

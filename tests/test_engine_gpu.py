@@ -92,14 +92,15 @@ def test_packing_invariance_is_bitwise(dtype):
 
 def test_f32_results_do_not_depend_on_the_tile_edge(monkeypatch):
     """The exact-f32 engine picks 128-, 64- or 32-tiles from the size of the pack; a trial's weights must not notice."""
+    from mitune.options import OPTIONS
     from mitune.packed import PackedTrainable, engine_hip
     train, val = _data(seed=8)
     tr = PackedTrainable(train=train, val=val, max_epochs=2, val_chunk=512, dtype="f32",
                          model_kwargs={"max_width": 256, "max_layers": 3, "max_batch": 512})
     out = {}
     for edge, (small, tiny) in {128: (0, 0), 64: (10 ** 9, 0), 32: (10 ** 9, 10 ** 9)}.items():
-        monkeypatch.setattr(engine_hip, "F32_SMALL_TILES", small)
-        monkeypatch.setattr(engine_hip, "F32_TINY_TILES", tiny)
+        monkeypatch.setattr(OPTIONS, "f32_small_tiles", small)
+        monkeypatch.setattr(OPTIONS, "f32_tiny_tiles", tiny)
         _, out[edge] = _run(engine_hip.HipPackEngine, tr, [(7, CONFIGS[1]), (9, CONFIGS[3])], [0, 1], 2, device="cuda",
                             capacity=4, seed=5)
     for slot in (0, 1):
@@ -438,8 +439,9 @@ def test_dp_step_driver_with_collectives_on_the_communication_stream(monkeypatch
     y = (torch.tanh(X[:, 0]) - 0.3 * X[:, 5]).cuda()
     cfg = {"hidden_sizes": [512, 256], "batch_size": 256, "learning_rate": 1e-3, "optimizer": "adam"}
     out = []
+    from mitune.options import OPTIONS
     for force in ("0", "1"):
-        monkeypatch.setenv("MITUNE_DP_FORCE_COLLECTIVES", force)
+        monkeypatch.setattr(OPTIONS, "dp_force_collectives", force == "1")
         t = DPTrainer(cfg, X[:2560], y[:2560], X[2560:], y[2560:], seed=1, trial_index=0)
         assert (t.engine.rccl is not None) == (force == "1")
         losses = [t.train_epoch() for _ in range(2)]

@@ -45,14 +45,17 @@ def _rand_bf16(*shape, scale=1.0, gen=None):
 NSTAGE = 0          # 0: launcher picks the pipeline depth; the parametrised test below forces both forms
 
 
-@pytest.fixture(params=[2, 4, 256, 258], autouse=True)
-def _both_pipeline_depths(request, monkeypatch):
+@pytest.fixture(params=[2, 4, 256, 258])
+def pipeline_code(request, monkeypatch):
+    """The bf16 grouped GEMM tests run once per pipeline form of the launcher (two / four stages on 128-tiles, 256-tiles
+    on four / eight waves); every other test in this file runs once."""
     monkeypatch.setattr(sys.modules[__name__], "NSTAGE", request.param)
 
 
 SHAPES = [(256, 128, 64), (512, 512, 512), (200, 72, 40), (128, 64, 8), (384, 256, 192), (130, 136, 520)]
 
 
+@pytest.mark.usefixtures("pipeline_code")
 @pytest.mark.parametrize("relu", [False, True])
 def test_gemm_forward_nt(lib, relu):
     L, so = lib
@@ -83,6 +86,7 @@ def test_gemm_forward_nt(lib, relu):
             assert torch.all(y[:, n:] == 0)
 
 
+@pytest.mark.usefixtures("pipeline_code")
 def test_gemm_forward_identity_asymmetric(lib):
     """A = I with an asymmetric B: catches a transposed or permuted accumulator write."""
     L, so = lib
@@ -100,6 +104,7 @@ def test_gemm_forward_identity_asymmetric(lib):
     assert torch.equal(y.float(), w.float().t())
 
 
+@pytest.mark.usefixtures("pipeline_code")
 @pytest.mark.parametrize("mask", [False, True])
 def test_gemm_dgrad_nn(lib, mask):
     L, so = lib
@@ -125,6 +130,7 @@ def test_gemm_dgrad_nn(lib, mask):
         torch.testing.assert_close(dx[:, :k].float(), ref, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.usefixtures("pipeline_code")
 @pytest.mark.parametrize("ksplits", [1, 3])
 def test_gemm_wgrad_tn(lib, ksplits):
     L, so = lib
@@ -301,20 +307,17 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
-# launch codes of the f32 GEMM: the tile edge itself on the two-stage pipeline; 65 / 66 = 64-tiles with three / four stages,
-# 33 = 32-tiles with eight stages, 35 = the same with four K-steps per barrier (one-barrier pipeline)
-F32_FORMS = [128, 64, 32, 65, 66, 33, 35]
+# launch codes of the f32 GEMM: the tile edge
+F32_FORMS = [128, 64, 32]
 
 
 def _tile_of(code):
-    return {65: 64, 66: 64, 33: 32, 35: 32}.get(code, code)
+    return code
 
 
 @pytest.mark.parametrize("edge", F32_FORMS)
 @pytest.mark.parametrize("relu", [False, True])
 def test_gemm_f32_forward_nt(lib, relu, edge):
-    if NSTAGE != 2:
-        pytest.skip("the f32 kernels have one pipeline form per tile edge")
     L, so = lib
     g = torch.Generator(device="cuda").manual_seed(11)
     groups = np.zeros(len(F32_SHAPES) + 1, dtype=L.GEMM_GROUP_DTYPE)
@@ -345,8 +348,6 @@ def test_gemm_f32_forward_nt(lib, relu, edge):
 
 @pytest.mark.parametrize("edge", F32_FORMS)
 def test_gemm_f32_forward_identity_asymmetric(lib, edge):
-    if NSTAGE != 2:
-        pytest.skip("the f32 kernels have one pipeline form per tile edge")
     L, so = lib
     n = 128
     x = torch.eye(n, device="cuda")
@@ -365,8 +366,6 @@ def test_gemm_f32_forward_identity_asymmetric(lib, edge):
 @pytest.mark.parametrize("edge", F32_FORMS)
 @pytest.mark.parametrize("mask", [False, True])
 def test_gemm_f32_dgrad_nn(lib, mask, edge):
-    if NSTAGE != 2:
-        pytest.skip("the f32 kernels have one pipeline form per tile edge")
     L, so = lib
     g = torch.Generator(device="cuda").manual_seed(12)
     groups = np.zeros(len(F32_SHAPES), dtype=L.GEMM_GROUP_DTYPE)
@@ -394,8 +393,6 @@ def test_gemm_f32_dgrad_nn(lib, mask, edge):
 @pytest.mark.parametrize("edge", F32_FORMS)
 @pytest.mark.parametrize("ksplits", [1, 3])
 def test_gemm_f32_wgrad_tn(lib, ksplits, edge):
-    if NSTAGE != 2:
-        pytest.skip("the f32 kernels have one pipeline form per tile edge")
     L, so = lib
     g = torch.Generator(device="cuda").manual_seed(13)
     groups = np.zeros(len(F32_SHAPES), dtype=L.GEMM_GROUP_DTYPE)
@@ -431,8 +428,6 @@ def test_gemm_f32_wgrad_tn(lib, ksplits, edge):
 
 
 def test_gather_f32_rows(lib):
-    if NSTAGE != 2:
-        pytest.skip("not a GEMM test")
     L, so = lib
     from mitune.packed.permutation import half_bits, permute, round_keys
     n, F, Fpad, B = 5000, 10, 16, 96
@@ -458,8 +453,6 @@ def test_gather_f32_rows(lib):
 
 
 def test_head_loss_f32_activations(lib):
-    if NSTAGE != 2:
-        pytest.skip("not a GEMM test")
     L, so = lib
     g = torch.Generator(device="cuda").manual_seed(14)
     cfgs = [(256, 512), (100, 64), (96, 200)]
@@ -501,8 +494,6 @@ def test_head_loss_f32_activations(lib):
 @pytest.mark.parametrize("f32", [False, True])
 def test_head_loss_wide_layers(lib, f32):
     """Heads wider than 2048 columns (data-parallel trials) take the two-pass form of the head/loss kernels."""
-    if NSTAGE != 2:
-        pytest.skip("not a GEMM test")
     L, so = lib
     g = torch.Generator(device="cuda").manual_seed(24)
     cfgs = [(200, 8192), (64, 4096)]

@@ -30,8 +30,9 @@ def _data(n=8000, f=64, seed=0):
 
 
 def _run(form, monkeypatch, configs, slots, epochs=2, capacity=8, seed=5):
+    from mitune.options import OPTIONS
     from mitune.packed import PackedTrainable, engine_hip
-    monkeypatch.setattr(engine_hip, "ROWBLOCK", form)
+    monkeypatch.setattr(OPTIONS, "rowblock", form)
     train, val = _data(seed=3)
     tr = PackedTrainable(train=train, val=val, max_epochs=epochs, val_chunk=512, dtype="f32",
                          model_kwargs={"max_width": 512, "max_layers": 4, "max_batch": 512})

@@ -275,22 +275,33 @@ def test_in_kernel_dropout_masks_equal_the_materialised_mask():
 
 
 # ------------------------------------------------------------------ fused small-linear backward
+def _producer(y):
+    """The autograd node that produced ``y``, looking through the slice that drops padded output columns."""
+    fn = y.grad_fn
+    while fn is not None and type(fn).__name__.startswith(("Slice", "Alias", "View")):
+        fn = fn.next_functions[0][0]
+    return fn
+
+
 @pytest.mark.parametrize("R,in_f,out_f", [(1600, 64, 256), (1600, 256, 64), (1600, 10, 64), (32, 64, 1), (37, 50, 33),
                                           (1600, 128, 384), (3200, 32, 96), (800, 512, 128), (130, 36, 40)])
 @pytest.mark.parametrize("bias", [True, False])
 @pytest.mark.parametrize("tile", [16, 32])
 def test_small_linear_backward_matches_f32_reference(R, in_f, out_f, bias, tile, monkeypatch):
-    """One launch gives dX, dW and db of a small f32 layer; compared with a float64 product of the same operands."""
-    from mitune.ops.linear import SmallLinear
-    monkeypatch.setattr(SmallLinear, "TILE", tile)
-    linear = SmallLinear.apply                            # also past the size bound that ``linear`` applies
+    """One launch gives dX, dW and db of a small f32 layer (dimensions that are not multiples of 4 are padded with zeros
+    before it and sliced after); compared with a float64 product of the same operands."""
+    from mitune.options import OPTIONS
+    from mitune.ops.linear import linear
+    monkeypatch.setattr(OPTIONS, "small_linear_tile", tile)
     g = torch.Generator(device="cuda").manual_seed(R + in_f + out_f)
     x = torch.randn(R // 4, 4, in_f, device="cuda", generator=g).requires_grad_() if R % 4 == 0 else \
         torch.randn(R, in_f, device="cuda", generator=g).requires_grad_()
     w = (torch.randn(out_f, in_f, device="cuda", generator=g) * in_f ** -0.5).requires_grad_()
     b = torch.randn(out_f, device="cuda", generator=g).requires_grad_() if bias else None
     y = linear(x, w, b)
-    assert "SmallLinear" in type(y.grad_fn).__name__
+    assert "SmallLinear" in type(_producer(y)).__name__
+    ref = x.detach().double() @ w.detach().double().t() + (b.detach().double() if bias else 0)
+    assert torch.allclose(y.double(), ref, rtol=1e-4, atol=1e-4)
     dy = torch.randn(y.shape, device="cuda", generator=g)
     for rep in range(2):
         x.grad = w.grad = None
@@ -312,38 +323,49 @@ def test_small_linear_backward_matches_f32_reference(R, in_f, out_f, bias, tile,
     assert torch.equal(w.grad, first)
 
 
-@pytest.mark.parametrize("R,in_f,out_f", [(1600, 64, 256), (1600, 256, 64), (1600, 10, 64), (32, 64, 1), (37, 50, 33),
-                                          (1600, 128, 384), (800, 512, 128), (130, 260, 40), (10000, 64, 192)])
-@pytest.mark.parametrize("bias", [True, False])
-def test_small_linear_forward_matches_f32_reference(R, in_f, out_f, bias):
-    from mitune.ops import lib as L
-    so = L.load()
-    g = torch.Generator(device="cuda").manual_seed(R + in_f)
-    x = torch.randn(R, in_f, device="cuda", generator=g)
-    w = torch.randn(out_f, in_f, device="cuda", generator=g) * in_f ** -0.5
-    b = torch.randn(out_f, device="cuda", generator=g) if bias else None
-    for relu in (0, 1):
-        y = torch.full((R, out_f), float("nan"), device="cuda")
-        L.check(so.mt_small_linear_fwd_launch(x.data_ptr(), w.data_ptr(), b.data_ptr() if bias else None, y.data_ptr(), R, in_f,
-                                              out_f, relu, torch.cuda.current_stream().cuda_stream), "fwd")
-        ref = x.double() @ w.double().t() + (b.double() if bias else 0)
-        ref = ref.clamp_min(0) if relu else ref
-        assert torch.allclose(y.double(), ref, rtol=1e-4, atol=1e-4)
-
-
-def test_small_linear_forward_kernel_can_serve_training_and_validation_passes(monkeypatch):
-    from mitune.ops.linear import SmallLinear, linear
-    monkeypatch.setattr(SmallLinear, "OWN_FORWARD", True)
+def test_small_layers_serve_training_and_validation_passes_with_the_same_forward():
+    from mitune.ops.linear import linear
     x = torch.randn(4, 50, 32, device="cuda", requires_grad=True)
     w = torch.randn(48, 32, device="cuda", requires_grad=True)
     b = torch.randn(48, device="cuda", requires_grad=True)
     y = linear(x, w, b)
     assert y.shape == (4, 50, 48) and "SmallLinear" in type(y.grad_fn).__name__
-    ref = torch.nn.functional.linear(x, w, b)
+    ref = (x.detach().double() @ w.detach().double().t() + b.detach().double()).float()
     assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4)
     with torch.no_grad():
         z = linear(x, w, b)
     assert z.grad_fn is None and torch.equal(z, y.detach())
+
+
+def test_operands_the_kernels_cannot_take_raise_instead_of_reaching_a_library_gemm():
+    from mitune.ops.linear import linear
+    x, w = torch.randn(8, 16, device="cuda", dtype=torch.float64), torch.randn(4, 16, device="cuda", dtype=torch.float64)
+    with pytest.raises(TypeError):
+        linear(x, w)
+    with torch.autocast("cuda", dtype=torch.float16), pytest.raises(TypeError):
+        linear(x.float(), w.float())
+
+
+@pytest.mark.parametrize("rows,in_f,out_f", [(300, 81, 70), (5000, 20, 1), (64, 9, 3)])
+def test_unaligned_bf16_layers_are_padded_onto_the_tile_kernel(rows, in_f, out_f):
+    from mitune.ops.linear import DenseBF16, linear
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(rows, in_f, device="cuda", generator=g).requires_grad_(True)
+    w = (torch.randn(out_f, in_f, device="cuda", generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(out_f, device="cuda", generator=g).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = linear(x, w, b)
+    assert y.shape == (rows, out_f)
+    if out_f > 1:
+        assert isinstance(_producer(y), DenseBF16._backward_cls)
+    y.float().sum().backward()
+    xr = x.detach().to(torch.bfloat16).double()
+    wr = w.detach().to(torch.bfloat16).double() if out_f > 1 else w.detach().double()
+    xr = xr if out_f > 1 else x.detach().double()
+    torch.testing.assert_close(y.double(), xr @ wr.t() + b.detach().double(), rtol=2e-2, atol=2e-2)
+    assert w.grad.shape == (out_f, in_f) and b.grad.shape == (out_f,)
+    torch.testing.assert_close(w.grad.double(), xr.sum(0).expand(out_f, in_f), rtol=2e-2, atol=2e-2 * float(xr.sum(0).abs().max()))
+    torch.testing.assert_close(b.grad.double(), torch.full((out_f,), float(rows), device="cuda", dtype=torch.float64), rtol=1e-2, atol=1.0)
 
 
 def test_small_linear_is_not_used_under_autocast_or_for_large_layers():
