@@ -9,6 +9,7 @@
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -65,51 +66,70 @@ def config23(args, trials_per_gpu):
 
 
 def config4(args):
-    """Width-8192 MLP on a [rows x 256] table, each trial data-parallel over all ranks."""
+    """Width-8192 MLP on a [rows x 256] table: a learning-rate x batch-size search under ASHA in which every trial is
+    data-parallel over all ranks (``mitune.run(dp_mlp_trainable, ...)``, trials one after another, every rank running the
+    same replicated driver).  A trial reports after every ``--dp-steps`` optimiser steps ("epoch" of the scheduler);
+    ``--dp-dtype both`` runs the search once in bf16 and once in exact f32."""
     import mitune
     from mitune import tune
-    from mitune.parallel.dp import DPTrainer, shard_rows
+    from mitune.parallel.dp import dp_mlp_trainable, shard_rows
+    from mitune.schedulers import ASHAScheduler
     comm = _comm()
     dev, rank, world = comm.device, comm.rank, comm.world_size
     lo, hi = shard_rows(args.rows, rank, world)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     n_local = hi - lo
-    dt = torch.bfloat16 if dev.type == "cuda" else torch.float32
-    X = torch.empty(n_local, 256, device=dev, dtype=dt)
-    y = torch.empty(n_local, device=dev, dtype=torch.float32)
     w = torch.randn(256, generator=torch.Generator(device=dev).manual_seed(7), device=dev) / 16.0
-    for c0 in range(0, n_local, 1 << 20):        # generated in place, chunk by chunk: the shard never exists in f32
-        c1 = min(n_local, c0 + (1 << 20))
-        xc = torch.randn(c1 - c0, 256, generator=g, device=dev)
-        y[c0:c1] = torch.tanh(xc @ w) + 0.1 * xc[:, 0] * xc[:, 1] + 0.05 * torch.randn(c1 - c0, generator=g, device=dev)
-        X[c0:c1] = xc.to(dt)
-    n_val = max(1024, n_local // 50)
-    Xtr, ytr, Xva, yva = X[n_val:], y[n_val:], X[:n_val], y[:n_val]
-    results = []
-    for i, (lr, bs) in enumerate([(3e-4, 8192), (1e-3, 16384)][: args.trials]):
-        cfg = {"hidden_sizes": [args.width] * 3, "batch_size": bs, "learning_rate": lr, "optimizer": "adamw"}
-        tr = DPTrainer(cfg, Xtr, ytr, Xva, yva, comm=comm, seed=0, trial_index=i)
-        steps = min(args.dp_steps, tr.steps_per_epoch)
-        full_epoch = tr.steps_per_epoch
-        tr.steps_per_epoch = steps                 # a timed slice of the epoch (the same number of steps on every rank)
+    runs = []
+    dtypes = ["bf16", "f32"] if args.dp_dtype == "both" else [args.dp_dtype]
+    if dev.type != "cuda":
+        dtypes = ["f32"]
+    for dtype in dtypes:
+        dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        X = torch.empty(n_local, 256, device=dev, dtype=dt)
+        y = torch.empty(n_local, device=dev, dtype=torch.float32)
+        g.manual_seed(1000 + rank)
+        for c0 in range(0, n_local, 1 << 20):        # generated in place, chunk by chunk
+            c1 = min(n_local, c0 + (1 << 20))
+            xc = torch.randn(c1 - c0, 256, generator=g, device=dev)
+            y[c0:c1] = torch.tanh(xc @ w) + 0.1 * xc[:, 0] * xc[:, 1] + 0.05 * torch.randn(c1 - c0, generator=g, device=dev)
+            X[c0:c1] = xc.to(dt)
+        n_val = max(1024, n_local // 50)
+        trainable = tune.with_parameters(dp_mlp_trainable, train=(X[n_val:], y[n_val:]), val=(X[:n_val], y[:n_val]), comm=comm,
+                                         epochs=args.dp_epochs, seed=0)
+        space = {"hidden_sizes": [args.width] * 3, "optimizer": "adamw", "dtype": dtype, "steps_per_epoch": args.dp_steps,
+                 "weight_decay": 1e-4, "warmup_steps": args.dp_steps // 2,
+                 "learning_rate": tune.loguniform(3e-5, 1e-3), "batch_size": tune.choice([8192, 16384])}
         comm.barrier()
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        loss = tr.train_epoch()
+        an = mitune.run(trainable, config=space, num_samples=args.trials, max_concurrent_trials=1, seed=0,
+                        scheduler=ASHAScheduler(metric="validation_loss", mode="min", max_t=args.dp_epochs, grace_period=1,
+                                                reduction_factor=2),
+                        metric="validation_loss", mode="min", local_dir=None, verbose=args.verbose if rank == 0 else 0)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
-        tr.steps_per_epoch = full_epoch
-        m = tr.evaluate()
-        flop = 6.0 * (256 * args.width + 2 * args.width ** 2 + args.width) * bs * steps
-        results.append({"lr": lr, "global_batch": bs, "steps": steps, "ms_per_step": el / steps * 1e3,
-                        "samples_per_s": bs * steps / el, "tflops": flop / el / 1e12, "train_loss": loss,
-                        "validation_mse": m["validation_mse"], "engine": "hip-dp" if tr.engine is not None else "torch",
-                        "allreduce_gb_per_step": tr.reducer.bytes_reduced / 1e9 / max(steps, 1),
-                        "epoch_seconds_full_table": args.rows * 0.98 / (bs * steps / el)})
+        trials, flop, steps_total, train_s = [], 0.0, 0, 0.0
+        for t in an.trials:
+            bs, steps = int(t.config["batch_size"]), int(t.last_result.get("steps", 0))
+            flop += 6.0 * (256 * args.width + 2 * args.width ** 2 + args.width) * bs * steps
+            steps_total += steps
+            trials.append({"lr": t.config["learning_rate"], "global_batch": bs, "reports": t.training_iteration, "steps": steps,
+                           "train_loss": t.last_result.get("train_loss"), "validation_mse": t.last_result.get("validation_mse"),
+                           "status": t.status})
+        finite = [t["validation_mse"] for t in trials if t["validation_mse"] is not None and math.isfinite(t["validation_mse"])]
+        runs.append({"dtype": dtype, "trials": len(trials), "elapsed_s": el, "trials_per_hour": len(trials) / el * 3600.0,
+                     "optimiser_steps": steps_total, "useful_tflop": flop / 1e12, "tflops_whole_search": flop / el / 1e12,
+                     "best_validation_mse": min(finite) if finite else None, "diverged": len(trials) - len(finite),
+                     "budget": f"{args.dp_epochs} reports x {args.dp_steps} steps, ASHA reduction factor 2",
+                     "per_trial": trials})
+        del X, y, trainable
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
     comm.close()
-    return {"config": 4, "n_gpus": world, "rows": args.rows, "width": args.width, "trials": results} if rank == 0 else None
+    return {"config": 4, "n_gpus": world, "rows": args.rows, "width": args.width, "searches": runs} if rank == 0 else None
 
 
 def config5(args):
@@ -153,8 +173,10 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--rows", type=int, default=100_000_000, help="config 4: total table rows")
     ap.add_argument("--width", type=int, default=8192)
-    ap.add_argument("--trials", type=int, default=2)
-    ap.add_argument("--dp-steps", type=int, default=50)
+    ap.add_argument("--trials", type=int, default=6, help="config 4: trials of the search")
+    ap.add_argument("--dp-steps", type=int, default=25, help="config 4: optimiser steps between two reports of a trial")
+    ap.add_argument("--dp-epochs", type=int, default=4, help="config 4: reports of a trial that is never stopped")
+    ap.add_argument("--dp-dtype", default="both", choices=["bf16", "f32", "both"])
     ap.add_argument("--rows5", type=int, default=200_000)
     ap.add_argument("--steps5", type=int, default=6)
     ap.add_argument("--population", type=int, default=8)

@@ -154,7 +154,8 @@ extern "C" int mt_gemm_f32_single_launch(int mode, const void* A, const void* B,
   MtGemmGroup g = {};
   g.A = A; g.B = B; g.C = C; g.aux = aux; g.aux_out = aux_out;
   g.I = I; g.J = J; g.KK = KK;
-  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = 0;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.ldaux = mode == 1 ? ldc : 0;      // input gradient: aux is the layer input the ReLU mask is read from, shaped like C
   g.active_steps = 1;
   const int nblocks = ((tiles_i * tiles_j + 7) / 8) * 8;
   dim3 grid(nblocks), block(F32_THREADS);

@@ -75,7 +75,8 @@ class MlpPlan(C.Structure):
 class DpPlan(C.Structure):
     """Mirror of ``MtDpPlan`` (csrc/dp.hip): one data-parallel MLP trial's step, as the C++ driver walks it."""
     _fields_ = [("n_hidden", c_int32), ("batch", c_int32), ("F", c_int32), ("hb", c_int32), ("n_rows", c_uint32),
-                ("world", c_int32), ("widths", c_int32 * MT_MAX_LAYERS), ("ksplits", c_int32 * MT_MAX_LAYERS),
+                ("world", c_int32), ("f32", c_int32), ("use_clip", c_int32), ("clip_blocks", c_int32), ("pad0", c_int32),
+                ("widths", c_int32 * MT_MAX_LAYERS), ("ksplits", c_int32 * MT_MAX_LAYERS),
                 ("w_off", C.c_int64 * (MT_MAX_LAYERS + 1)), ("b_off", C.c_int64 * (MT_MAX_LAYERS + 1)),
                 ("bucket_lo", C.c_int64 * (MT_MAX_LAYERS + 1)), ("bucket_hi", C.c_int64 * (MT_MAX_LAYERS + 1)),
                 ("numel", C.c_int64), ("X", c_void_p), ("Y", c_void_p), ("X0", c_void_p), ("ybuf", c_void_p),
@@ -83,6 +84,7 @@ class DpPlan(C.Structure):
                 ("P", c_void_p), ("W", c_void_p), ("G32", c_void_p), ("Gb", c_void_p), ("M", c_void_p), ("V", c_void_p),
                 ("head", c_void_p), ("opt", c_void_p), ("ids", c_void_p), ("head_scratch", c_void_p),
                 ("all_reduce", c_void_p), ("comm", c_void_p), ("nccl_bf16", c_int32), ("nccl_avg", c_int32),
+                ("nccl_f32", c_int32), ("pad1", c_int32), ("clip_partials", c_void_p),
                 ("comm_stream", c_void_p), ("ready", c_void_p * (MT_MAX_LAYERS + 1)), ("reduced", c_void_p)]
 
 

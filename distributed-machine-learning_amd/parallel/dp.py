@@ -19,7 +19,16 @@ MI355X-first choices:
   ``torch.distributed`` all-reduces.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce moves
   2 * (n-1)/n * bytes per link, i.e. ~1.5 ms for one 8192 x 8192 bf16 bucket -- about one layer's backward,
   which is why per-layer buckets (not one big late bucket, not many tiny ones) are the right size here;
-* bf16 buckets halve the bytes on the links compared with f32 gradients.
+* bf16 buckets halve the bytes on the links compared with f32 gradients;
+* ``dtype="f32"`` (config key or argument) selects the exact-f32 form of the same driver: f32 table, activations and
+  buckets, every GEMM on the exact-f32 tile kernels, gradient clipping inside the optimiser launch.  Its results do not
+  depend on how many ranks share the batch beyond the order of the all-reduce's additions, and on the CPU path (gloo)
+  they are bitwise equal between 1, 2 and 4 ranks' worth of identical shards.
+
+A GPU trial always runs on the C++ driver: shapes it cannot take (a feature count or a width that is not a multiple
+of 8, more than 8 hidden layers, clipping with bf16 buckets) raise ``ValueError`` with the remedy instead of falling back
+to an eager loop.  The autograd implementation below is the CPU path (tests, gloo rehearsals) and the oracle the GPU
+tests compare with.
 
 Every rank runs the same HPO driver (same seed, same searcher, same scheduler): trials execute one
 after another, each using all ranks, and the reported metrics are all-reduced so the replicated
@@ -29,7 +38,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-import os
 import time
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -52,7 +60,8 @@ def _round_up(x: int, m: int) -> int:
 class FlatMLP:
     """MLP whose weights, gradients and optimiser state live in flat slabs (bucket = one layer)."""
 
-    def __init__(self, spec: MLPTrialSpec, device: torch.device, seed: int, trial_index: int, low_precision: bool):
+    def __init__(self, spec: MLPTrialSpec, device: torch.device, seed: int, trial_index: int, low_precision: bool,
+                 autograd: bool = True):
         self.spec, self.device, self.low = spec, device, low_precision
         dims = spec.layer_dims
         self.offsets: List[Tuple[int, int, int, int]] = []     # (w_off, b_off, out, in) per layer incl. head
@@ -75,8 +84,11 @@ class FlatMLP:
             self.P[b_off:b_off + o] = state[f"{name}.bias"].to(device)
         wdtype = torch.bfloat16 if low_precision else torch.float32
         self.W = self.P.to(wdtype) if low_precision else self.P      # compute weights (bf16 shadow on GPU)
-        self.Gf = torch.zeros(off, device=device, dtype=wdtype)      # flat gradients
         self.params: List[torch.Tensor] = []
+        if not autograd:        # the GPU engine has its own gradient buffers and never builds an autograd graph
+            self.Gf = None
+            return
+        self.Gf = torch.zeros(off, device=device, dtype=wdtype)      # flat gradients
         for w_off, b_off, o, i in self.offsets:
             w = self.W[w_off:w_off + o * i].view(o, i).requires_grad_(True)
             b = self.W[b_off:b_off + o].requires_grad_(True)
@@ -85,6 +97,7 @@ class FlatMLP:
             self.params += [w, b]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """The CPU path's forward (plain PyTorch: the oracle of the GPU driver)."""
         n = len(self.offsets)
         for l in range(n):
             x = F.linear(x, self.params[2 * l], self.params[2 * l + 1])
@@ -109,7 +122,7 @@ class BucketedAllReduce:
         self.pending: List[Any] = []
         self._ready = [0] * len(model.bucket_bounds)
         self.bytes_reduced = 0
-        if comm.world_size > 1:
+        if comm.world_size > 1 and model.params:
             for l in range(len(model.offsets)):
                 for p in (model.params[2 * l], model.params[2 * l + 1]):
                     p.register_post_accumulate_grad_hook(self._make_hook(l))
@@ -136,16 +149,22 @@ class DPTrainer:
     """One trial, all ranks.  ``X``/``y`` are this rank's shard (rows are disjoint across ranks)."""
 
     def __init__(self, config: Dict, X: torch.Tensor, y: torch.Tensor, Xval: torch.Tensor, yval: torch.Tensor,
-                 comm: Optional[Comm] = None, seed: int = 0, trial_index: int = 0):
+                 comm: Optional[Comm] = None, seed: int = 0, trial_index: int = 0, dtype: Optional[str] = None):
         self.comm = comm or LocalComm(X.device)
         self.device = X.device
         self.spec = MLPTrialSpec.from_config(config, int(X.shape[1]))
         self.gpu = self.device.type == "cuda"
+        self.dtype = str(config.get("dtype", dtype) or ("bf16" if self.gpu else "f32"))
+        if self.dtype not in ("bf16", "f32") or (self.dtype == "bf16" and not self.gpu):
+            raise ValueError(f"dtype {self.dtype!r}: a data-parallel trial computes in 'bf16' (GPU only) or 'f32'")
         self.X, self.y, self.Xval, self.yval = X, y, Xval, yval
-        if self.gpu:        # the table is kept in bf16: half the HBM, and it is what the GEMMs consume
-            self.X = X if X.dtype == torch.bfloat16 else X.to(torch.bfloat16)
-            self.Xval = Xval if Xval.dtype == torch.bfloat16 else Xval.to(torch.bfloat16)
-        self.model = FlatMLP(self.spec, self.device, seed, trial_index, low_precision=self.gpu)
+        if self.gpu:        # bf16: the table is kept in bf16 -- half the HBM, and it is what the GEMMs consume
+            want = torch.bfloat16 if self.dtype == "bf16" else torch.float32
+            self.X = X if X.dtype == want else X.to(want)
+            self.Xval = Xval if Xval.dtype == want else Xval.to(want)
+            self._check_gpu_shapes()
+        self.model = FlatMLP(self.spec, self.device, seed, trial_index, low_precision=self.gpu and self.dtype == "bf16",
+                             autograd=not self.gpu)
         self.reducer = BucketedAllReduce(self.model, self.comm)
         self.seed, self.trial_index = seed, trial_index
         self.global_batch = self.spec.batch_size
@@ -161,41 +180,42 @@ class DPTrainer:
         self.epoch, self.step = 0, 0
         self.stats = {"steps": 0, "train_s": 0.0}
         self.engine = None
-        if self.gpu and self.spec.gradient_clipping <= 0 and int(X.shape[1]) % 8 == 0 \
-                and all(h % 8 == 0 for h in self.spec.hidden_sizes) and len(self.spec.hidden_sizes) <= 8:
-            self.engine = HipDPEngine(self)
         if self.gpu:
-            from ..ops import lib as L
-            self.L, self.lib = L, L.load()
-            self.M = torch.zeros_like(self.model.P) if self.engine is None else self.engine.M
-            self.V = torch.zeros_like(self.model.P) if self.engine is None else self.engine.V
-            self.ids = torch.zeros(1, dtype=torch.int32, device=self.device)
-            self._hp_t = None
+            self.engine = HipDPEngine(self)
+            self.M, self.V = self.engine.M, self.engine.V
         else:
             self.opt = build_optimizer(self.spec.optimizer, [self.model.P], self.spec.learning_rate,
                                        self.spec.weight_decay, self.spec.momentum, self.spec.beta1, self.spec.beta2,
                                        self.spec.eps)
 
-    # ------------------------------------------------------------------ optimiser
+    def _check_gpu_shapes(self) -> None:
+        """What ``ops/csrc/dp.hip`` takes; anything else is an error with its remedy, never a silent slower path."""
+        F_, hidden = int(self.X.shape[1]), list(self.spec.hidden_sizes)
+        if F_ % 8:
+            raise ValueError(f"the table has {F_} features: the data-parallel engine reads rows in 16-byte pieces, pad the "
+                             f"table with {(-F_) % 8} zero column(s) to a multiple of 8")
+        if F_ // (8 if self.dtype == "bf16" else 4) > 256:
+            raise ValueError(f"{F_} features exceed the row gather of the data-parallel engine "
+                             f"({2048 if self.dtype == 'bf16' else 1024} in {self.dtype})")
+        if any(h % 8 for h in hidden) or not 1 <= len(hidden) <= 8:
+            raise ValueError(f"hidden_sizes {hidden}: the data-parallel engine takes 1 to 8 hidden layers whose widths are "
+                             "multiples of 8")
+        if self.spec.gradient_clipping > 0 and self.dtype == "bf16":
+            raise ValueError("gradient_clipping with bf16 gradient buckets is not supported (the norm would be taken of "
+                             "rounded gradients): use dtype='f32', which clips inside the optimiser launch")
+
+    def close(self) -> None:
+        """Destroy what the trial created outside the allocator: the direct RCCL communicator of the GPU engine."""
+        if self.engine is not None:
+            self.engine.close()
+
+    # ------------------------------------------------------------------ optimiser (CPU path)
     def _apply_update(self) -> None:
         sp = self.spec
-        if self.gpu:
-            if self._hp_t is None:
-                hp = np.zeros(1, dtype=self.L.OPT_DTYPE)
-                hp[0] = (sp.learning_rate, sp.beta1, sp.beta2, sp.eps, sp.weight_decay, sp.momentum, 0.0,
-                         OPT_CODES[sp.optimizer], sp.warmup_steps, sp.total_steps, self.model.numel, 1 << 30, 0,
-                         0, 0, 0)
-                self._hp_t = torch.from_numpy(hp.view(np.uint8).reshape(-1).copy()).to(self.device)
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            self.L.check(self.lib.mt_optim_launch_bf16g(
-                self.model.P.data_ptr(), self.model.Gf.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
-                self.model.W.data_ptr(), _round_up(self.model.numel, 8), self._hp_t.data_ptr(), self.ids.data_ptr(), 1,
-                self.model.numel, self.step, stream), "mt_optim_launch_bf16g")
-        else:
-            for g in self.opt.param_groups:
-                g["lr"] = sp.learning_rate * lr_factor(self.step, sp.warmup_steps, sp.total_steps)
-            self.model.P.grad = self.model.Gf
-            self.opt.step()
+        for g in self.opt.param_groups:
+            g["lr"] = sp.learning_rate * lr_factor(self.step, sp.warmup_steps, sp.total_steps)
+        self.model.P.grad = self.model.Gf
+        self.opt.step()
 
     # ------------------------------------------------------------------ epoch
     def train_epoch(self) -> float:
@@ -279,6 +299,8 @@ class HipDPEngine:
         self.tr, self.L, self.lib = tr, L, L.load()
         dev, m, sp = tr.device, tr.model, tr.spec
         self.device = dev
+        self.f32 = tr.dtype == "f32"
+        act = torch.float32 if self.f32 else torch.bfloat16
         hidden = list(sp.hidden_sizes)
         nl = len(hidden)
         self.F = int(tr.X.shape[1])
@@ -290,19 +312,20 @@ class HipDPEngine:
         # wgrad splits per layer: enough workgroups to fill the chip when a layer has few 128x128 tiles
         ks = []
         dims_in = [self.F] + hidden[:-1]
+        edge, rows_per_split = (64, 128) if self.f32 else (128, 64)       # tile edge of the weight-gradient kernel in use
         for h, k in zip(hidden, dims_in):
-            tiles = ((h + 127) // 128) * ((k + 127) // 128)
-            ks.append(max(1, min(8, (b + 63) // 64, (512 + tiles - 1) // tiles)))
+            tiles = ((h + edge - 1) // edge) * ((k + edge - 1) // edge)
+            ks.append(max(1, min(8, (b + rows_per_split - 1) // rows_per_split, (512 + tiles - 1) // tiles)))
         self.P, self.W = m.P, m.W
         if n != m.numel:
             raise ValueError("flat slab length must be a multiple of 8")      # FlatMLP rounds every tensor up to 8
         self.G32 = torch.zeros(max(ks) * n, device=dev, dtype=torch.float32)
-        self.Gb = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+        self.Gb = torch.zeros(n, device=dev, dtype=act)          # the buckets: what is all-reduced, what the optimiser reads
         self.M, self.V = torch.zeros_like(self.P), torch.zeros_like(self.P)
-        self.X0 = torch.zeros(b * self.F, device=dev, dtype=torch.bfloat16)
+        self.X0 = torch.zeros(b * self.F, device=dev, dtype=act)
         self.ybuf = torch.zeros(b, device=dev, dtype=torch.float32)
-        self.H = [torch.zeros(rows_max * h, device=dev, dtype=torch.bfloat16) for h in hidden]
-        self.dZ = [torch.zeros(b * h, device=dev, dtype=torch.bfloat16) for h in hidden]
+        self.H = [torch.zeros(rows_max * h, device=dev, dtype=act) for h in hidden]
+        self.dZ = [torch.zeros(b * h, device=dev, dtype=act) for h in hidden]
         self.loss_acc = torch.zeros(1, device=dev, dtype=torch.float32)
         self.metrics = torch.zeros(3, device=dev, dtype=torch.float64)
         self.ids = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -320,9 +343,12 @@ class HipDPEngine:
         self._head_train = head_table(b, self.ybuf.data_ptr())
         self._head_eval = head_table(rows_max, tr.yval.data_ptr())
         hp = np.zeros(1, dtype=L.OPT_DTYPE)
-        hp[0] = (sp.learning_rate, sp.beta1, sp.beta2, sp.eps, sp.weight_decay, sp.momentum, 0.0, OPT_CODES[sp.optimizer],
+        clip = float(sp.gradient_clipping) if self.f32 else 0.0
+        hp[0] = (sp.learning_rate, sp.beta1, sp.beta2, sp.eps, sp.weight_decay, sp.momentum, clip, OPT_CODES[sp.optimizer],
                  sp.warmup_steps, sp.total_steps, m.numel, 1 << 30, 0, 0, 0, 0)
         self._opt = torch.from_numpy(hp.view(np.uint8).reshape(-1).copy()).to(dev)
+        self._clip_blocks = (n + 2047) // 2048 if clip > 0 else 0              # one partial norm per optimiser workgroup
+        self._clip_partials = torch.zeros(max(self._clip_blocks, 1), device=dev, dtype=torch.float32)
         # collectives: a direct RCCL communicator when there is more than one rank
         self.rccl = None
         # OPTIONS.dp_force_collectives issues the per-bucket all-reduces even with one rank (over a one-rank communicator
@@ -338,6 +364,8 @@ class HipDPEngine:
         plan.n_hidden, plan.batch, plan.F = nl, b, self.F
         plan.n_rows, plan.hb = int(tr.X.shape[0]), half_bits(int(tr.X.shape[0]))
         plan.world = max(tr.comm.world_size, 2 if force else 1)
+        plan.f32, plan.use_clip, plan.clip_blocks = int(self.f32), int(clip > 0), self._clip_blocks
+        plan.clip_partials = self._clip_partials.data_ptr()
         for l, (h, k) in enumerate(zip(hidden, ks)):
             plan.widths[l], plan.ksplits[l] = h, k
             plan.H[l], plan.dZ[l] = self.H[l].data_ptr(), self.dZ[l].data_ptr()
@@ -354,7 +382,7 @@ class HipDPEngine:
         if self.rccl is not None:
             from .rccl import DTYPES, OPS
             plan.all_reduce, plan.comm = self.rccl.fn_all_reduce, self.rccl.comm_handle
-            plan.nccl_bf16, plan.nccl_avg = DTYPES[torch.bfloat16], OPS["avg"]
+            plan.nccl_bf16, plan.nccl_avg, plan.nccl_f32 = DTYPES[torch.bfloat16], OPS["avg"], DTYPES[torch.float32]
             plan.comm_stream = self.rccl.stream.cuda_stream
         for l in range(nl + 1):
             plan.ready[l] = self._events[l].cuda_event
@@ -374,8 +402,16 @@ class HipDPEngine:
         self.L.check(self.lib.mt_dp_train_steps(C.byref(self.plan), keys.ctypes.data, 0, steps, tr.step, stream.cuda_stream),
                      "mt_dp_train_steps")
         if self.rccl is not None:
-            self.bytes_reduced += steps * tr.model.numel * 2
+            self.bytes_reduced += steps * tr.model.numel * (4 if self.f32 else 2)
         return self.loss_acc[0] / max(steps, 1)
+
+    def close(self) -> None:
+        if self.rccl is not None:
+            torch.cuda.synchronize(self.device)
+            self.rccl.close()
+            self.rccl = None
+            self.plan.all_reduce = self.plan_eval.all_reduce = None
+            self.plan.world = self.plan_eval.world = 1
 
     def evaluate(self) -> torch.Tensor:
         self.metrics.zero_()
@@ -397,11 +433,18 @@ def dp_mlp_trainable(config: Dict, train: Tuple[torch.Tensor, torch.Tensor], val
     """Function trainable (SPMD): call under ``mitune.run`` on every rank with this rank's data shards."""
     from ..tune import session
     tid = session.get_trial_id() or "0"
+    digits = "".join(ch for ch in tid if ch.isdigit())
     trainer = DPTrainer(config, train[0], train[1], val[0], val[1], comm=comm, seed=seed,
-                        trial_index=int(tid) if tid.isdigit() else 0)
-    for _ in range(int(config.get("epochs", epochs))):
-        train_loss = trainer.train_epoch()
-        metrics = trainer.evaluate()
-        metrics["train_loss"] = train_loss
-        metrics["allreduce_gb"] = trainer.reducer.bytes_reduced / 1e9
-        session.report(metrics)
+                        trial_index=int(digits[-6:]) if digits else 0)
+    if "steps_per_epoch" in config:           # a report every so many steps instead of once per pass over the table
+        trainer.steps_per_epoch = max(1, min(int(config["steps_per_epoch"]), trainer.steps_per_epoch))
+    try:
+        for _ in range(int(config.get("epochs", epochs))):
+            train_loss = trainer.train_epoch()
+            metrics = trainer.evaluate()
+            metrics["train_loss"] = train_loss
+            metrics["allreduce_gb"] = trainer.reducer.bytes_reduced / 1e9
+            metrics["steps"] = trainer.step
+            session.report(metrics)
+    finally:
+        trainer.close()

@@ -1,4 +1,5 @@
 """The HIP pack engine against the per-trial PyTorch oracle, and packing invariance."""
+import numpy as np
 import pytest
 import torch
 
@@ -380,13 +381,27 @@ if w is not None:
     w.wait()
 out["avg"] = float(grad.float().mean().item())
 comm.barrier()
+# the repair path of a lost rank, as far as one GPU allows: abort the RCCL group, meet through files, form the next
+# group over a file store, and use it
+out["delivers_errors"] = bool(comm.delivers_errors)
+out["members"] = comm.shrink()
+out["after"] = [comm.rank, comm.world_size]
+t2 = torch.full((8,), 3.0, device=dev)
+comm.all_reduce(t2, op="sum")
+g2 = comm.all_gather(table)
+out["after_ok"] = bool(float(t2.sum().item()) == 24.0 and torch.equal(g2[0], table))
+out["members2"] = comm.shrink()                   # and once more: generations do not collide
+out["rdzv"] = comm.rendezvous_dir
+comm.barrier()
 comm.close()
 print("RESULT " + json.dumps(out))
 """
 
 
-def test_rccl_backend_one_rank_collectives():
-    """Every collective the executors use, on the real RCCL backend (a one-rank group: the test box has one GPU)."""
+def test_rccl_backend_one_rank_collectives_and_group_repair(tmp_path):
+    """Every collective the executors use, on the real RCCL backend (a one-rank group: the test box has one GPU), then
+    ``shrink()`` on it: abort of the RCCL process group, file rendezvous, re-initialisation over a ``FileStore``, and
+    collectives on the new group."""
     import json
     import os
     import socket
@@ -396,12 +411,16 @@ def test_rccl_backend_one_rank_collectives():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MITUNE_RENDEZVOUS_DIR=str(tmp_path))
     out = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=110)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
     assert rec["backend"] == "nccl" and rec["device"] == "cuda:0"
     assert rec["gather_ok"] and rec["bcast_ok"] and rec["max"] == 1.25 and rec["avg"] == 1.0 and rec["obj"] == {"epoch": 3}
+    assert rec["delivers_errors"] and rec["members"] == [0] and rec["members2"] == [0] and rec["after"] == [0, 1] and rec["after_ok"]
+    assert rec["rdzv"].startswith(str(tmp_path))
+    assert os.path.isdir(os.path.join(rec["rdzv"], "gen1")) and os.path.isdir(os.path.join(rec["rdzv"], "gen2"))
 
 
 # ----------------------------------------------------------------------------------------- data-parallel trial on the GPU
@@ -446,10 +465,78 @@ def test_dp_step_driver_with_collectives_on_the_communication_stream(monkeypatch
         assert (t.engine.rccl is not None) == (force == "1")
         losses = [t.train_epoch() for _ in range(2)]
         out.append((losses, t.evaluate(), t.model.P.clone(), t.reducer.bytes_reduced))
-        if t.engine.rccl is not None:
-            t.engine.rccl.close()
+        t.close()
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and torch.equal(out[0][2], out[1][2])
     assert out[0][3] == 0 and out[1][3] == 2 * 10 * out[1][2].numel() * 2          # bf16 bytes, every step, every element
+
+
+@pytest.mark.parametrize("cfg_extra", [{"optimizer": "adamw", "weight_decay": 1e-3},
+                                       {"optimizer": "sgd", "momentum": 0.9, "gradient_clipping": 0.5, "loss_function": "huber"}])
+def test_dp_engine_exact_f32_form_matches_the_cpu_reference(cfg_extra, monkeypatch):
+    """``dtype="f32"``: the same driver on the exact-f32 tile kernels with f32 buckets, against the autograd CPU path --
+    f32 tolerances, with and without gradient clipping -- and unchanged when the per-bucket all-reduces are forced on."""
+    from mitune.options import OPTIONS
+    from mitune.parallel.dp import DPTrainer
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(4096, 32, generator=g)
+    y = torch.tanh(X[:, 0]) + 0.5 * X[:, 1] + 0.05 * torch.randn(4096, generator=g)
+    cfg = dict({"hidden_sizes": [256, 128, 64], "batch_size": 512, "learning_rate": 2e-3, "dtype": "f32"}, **cfg_extra)
+    ref = DPTrainer(cfg, X[:3584], y[:3584], X[3584:], y[3584:], seed=4, trial_index=2)
+    runs = []
+    for force in (False, True):
+        monkeypatch.setattr(OPTIONS, "dp_force_collectives", force)
+        gpu = DPTrainer(cfg, X[:3584].cuda(), y[:3584].cuda(), X[3584:].cuda(), y[3584:].cuda(), seed=4, trial_index=2)
+        assert gpu.engine is not None and gpu.engine.f32 and gpu.model.W is gpu.model.P and gpu.X.dtype == torch.float32
+        assert (gpu.engine.rccl is not None) == force
+        hist = []
+        for epoch in range(3):
+            hist.append((gpu.train_epoch(), gpu.evaluate()))
+        runs.append((hist, gpu.model.P.clone(), gpu.reducer.bytes_reduced))
+        gpu.close()
+        assert gpu.engine.rccl is None
+    for epoch in range(3):
+        lr, mr = ref.train_epoch(), ref.evaluate()
+        lg, mg = runs[0][0][epoch]
+        assert lg == pytest.approx(lr, rel=2e-4, abs=1e-6), (epoch, lr, lg)
+        for k in ("validation_loss", "validation_mse", "validation_mape"):
+            assert mg[k] == pytest.approx(mr[k], rel=5e-4, abs=1e-6), (epoch, k, mr, mg)
+    torch.testing.assert_close(runs[0][1].cpu(), ref.model.P, rtol=2e-3, atol=2e-5)
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][2] == 0 and runs[1][2] == 3 * 7 * runs[1][1].numel() * 4           # f32 bytes, every step, every element
+
+
+def test_dp_engine_refuses_shapes_it_cannot_take_instead_of_running_eagerly():
+    from mitune.parallel.dp import DPTrainer
+    X, y = torch.randn(512, 30).cuda(), torch.randn(512).cuda()
+    with pytest.raises(ValueError, match="multiple of 8"):
+        DPTrainer({"hidden_sizes": [64], "batch_size": 64}, X, y, X[:64], y[:64])
+    X = torch.randn(512, 32).cuda()
+    with pytest.raises(ValueError, match="multiples of 8"):
+        DPTrainer({"hidden_sizes": [60], "batch_size": 64}, X, y, X[:64], y[:64])
+    with pytest.raises(ValueError, match="f32"):
+        DPTrainer({"hidden_sizes": [64], "batch_size": 64, "gradient_clipping": 1.0}, X, y, X[:64], y[:64])
+    with pytest.raises(ValueError, match="bf16"):
+        DPTrainer({"hidden_sizes": [64], "batch_size": 64, "dtype": "bf16"}, X.cpu(), y.cpu(), X[:64].cpu(), y[:64].cpu())
+
+
+def test_dp_trials_under_the_search_driver_on_the_gpu():
+    """``mitune.run(dp_mlp_trainable, ...)`` with ASHA over learning rate x batch size, both compute types in one space."""
+    import mitune
+    from mitune import tune
+    from mitune.parallel.dp import dp_mlp_trainable
+    from mitune.schedulers import ASHAScheduler
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(4096, 32, generator=g).cuda()
+    y = (torch.tanh(X[:, 0]) + 0.5 * X[:, 1]).cuda()
+    tr = tune.with_parameters(dp_mlp_trainable, train=(X[:3584], y[:3584]), val=(X[3584:], y[3584:]), epochs=3, seed=1)
+    an = mitune.run(tr, config={"hidden_sizes": [128, 64], "batch_size": tune.choice([256, 512]), "steps_per_epoch": 5,
+                                "learning_rate": tune.loguniform(1e-3, 1e-2), "dtype": tune.choice(["bf16", "f32"])},
+                    num_samples=6, max_concurrent_trials=1, seed=0, verbose=0, local_dir=None,
+                    scheduler=ASHAScheduler(metric="validation_loss", mode="min", max_t=3, reduction_factor=2))
+    assert len(an.trials) == 6 and {t.config["dtype"] for t in an.trials} == {"bf16", "f32"}
+    assert all(np.isfinite(t.last_result["validation_loss"]) and t.last_result["steps"] == 5 * t.training_iteration
+               for t in an.trials)
+    assert max(t.training_iteration for t in an.trials) == 3 and min(t.training_iteration for t in an.trials) < 3
 
 
 _RCCL_DIRECT = r"""

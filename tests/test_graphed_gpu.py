@@ -70,31 +70,6 @@ def test_depthwise_conv1d_matches_reference(B, S, d, k):
         assert torch.allclose(a, r, rtol=1e-4, atol=1e-4 * max(1.0, r.abs().max().item())), name
 
 
-# ------------------------------------------------------------------ fused head MLP
-@pytest.mark.parametrize("B,d,dims", [(32, 64, (128, 64, 32, 16, 1)), (5, 512, (128, 64, 32, 16, 1)),
-                                      (100, 192, (128, 64, 32, 16, 1)), (33, 40, (96, 24, 1)), (16, 128, (1,))])
-def test_head_mlp_matches_reference(B, d, dims):
-    from mitune.ops.head_mlp import head_mlp, head_mlp_reference
-    seq = _rand(B, 7, d, seed=5).requires_grad_()
-    ws, bs, k = [], [], d
-    for i, o in enumerate(dims):
-        ws.append(_rand(o, k, seed=10 + i, scale=1.0 / math.sqrt(k)).requires_grad_())
-        bs.append(_rand(o, seed=20 + i, scale=0.1).requires_grad_())
-        k = o
-    dout = _rand(B, dims[-1], seed=6)
-    out = head_mlp(seq[:, -1, :], ws, bs)                      # strided last-token view, read in place
-    out.backward(dout)
-    got = [out.detach(), seq.grad.clone()] + [w.grad.clone() for w in ws] + [b.grad.clone() for b in bs]
-    seq.grad = None
-    for t in ws + bs:
-        t.grad = None
-    ref = head_mlp_reference(seq[:, -1, :], ws, bs)
-    ref.backward(dout)
-    want = [ref.detach(), seq.grad] + [w.grad for w in ws] + [b.grad for b in bs]
-    for i, (a, r) in enumerate(zip(got, want)):
-        assert torch.allclose(a, r, rtol=2e-4, atol=2e-5 * max(1.0, r.abs().max().item())), i
-
-
 # ------------------------------------------------------------------ flat optimiser vs torch.optim
 @pytest.mark.parametrize("name", ["adam", "adamw", "sgd", "rmsprop"])
 @pytest.mark.parametrize("clip", [0.0, 0.5])
