@@ -79,6 +79,8 @@ struct MtDpPlan {
   void* W;                     // bf16 shadow (what the GEMMs read); f32 form: unused, the GEMMs read P
   float* G32;                  // f32 gradient staging: max(ksplits) slabs of numel
   void* Gb;                    // gradient buckets (what is all-reduced and what the optimiser reads): bf16, f32 form: f32
+  void* Gr;                    // where the all-reduce delivers and what the optimiser reads: Gb itself (in place) unless the
+                               // caller wants the one-rank rehearsal to move bytes (a one-rank in-place all-reduce is a no-op)
   float* M;
   float* V;
   const MtHeadSlot* head;      // one slot
@@ -143,7 +145,9 @@ static int dp_bucket(const MtDpPlan* p, int l, int ksplits, hipStream_t stream) 
     if (p->world > 1 && p->all_reduce != nullptr) {
       if (hipEventRecord(p->ready[l], stream) != hipSuccess) return -23;
       if (hipStreamWaitEvent(p->comm_stream, p->ready[l], 0) != hipSuccess) return -23;
-      if (p->all_reduce(buf, buf, hi - lo, p->nccl_f32, p->nccl_avg, p->comm, p->comm_stream) != 0) return -24;
+      if (p->all_reduce(buf, reinterpret_cast<float*>(p->Gr) + lo, hi - lo, p->nccl_f32, p->nccl_avg, p->comm,
+                        p->comm_stream) != 0)
+        return -24;
     }
     return 0;
   }
@@ -156,7 +160,9 @@ static int dp_bucket(const MtDpPlan* p, int l, int ksplits, hipStream_t stream) 
     if (hipEventRecord(p->ready[l], stream) != hipSuccess) return -23;
     if (hipStreamWaitEvent(p->comm_stream, p->ready[l], 0) != hipSuccess) return -23;
     uint16_t* buf = reinterpret_cast<uint16_t*>(p->Gb) + lo;
-    if (p->all_reduce(buf, buf, hi - lo, p->nccl_bf16, p->nccl_avg, p->comm, p->comm_stream) != 0) return -24;
+    if (p->all_reduce(buf, reinterpret_cast<uint16_t*>(p->Gr) + lo, hi - lo, p->nccl_bf16, p->nccl_avg, p->comm,
+                      p->comm_stream) != 0)
+      return -24;
   }
   return 0;
 }
@@ -188,6 +194,7 @@ extern "C" int mt_dp_train_steps(const MtDpPlan* p, const uint32_t* key, int ste
   for (int l = 0; l < L; ++l)
     if (p->widths[l] & 7) return -10;
   if (p->f32 && p->use_clip && p->clip_partials == nullptr) return -10;
+  if (p->Gr == nullptr) return -10;
   const uint16_t* W = reinterpret_cast<const uint16_t*>(p->W);
   const int rows_per_block = 256 / cpr;
   for (int s = 0; s < nsteps; ++s) {
@@ -230,11 +237,11 @@ extern "C" int mt_dp_train_steps(const MtDpPlan* p, const uint32_t* key, int ste
       if (hipStreamWaitEvent(stream, p->reduced, 0) != hipSuccess) return -23;
     }
     if (p->f32)
-      DP_TRY(mt_optim_launch(p->P, reinterpret_cast<const float*>(p->Gb), p->M, p->V, nullptr, (size_t)p->numel, p->opt, p->ids,
+      DP_TRY(mt_optim_launch(p->P, reinterpret_cast<const float*>(p->Gr), p->M, p->V, nullptr, (size_t)p->numel, p->opt, p->ids,
                              1, (int)p->numel, p->clip_partials, p->use_clip ? p->clip_blocks : (1 << 30), p->use_clip,
                              opt_step + s, 1, (size_t)0, stream));
     else
-      DP_TRY(mt_optim_launch_bf16g(p->P, p->Gb, p->M, p->V, p->W, (size_t)p->numel, p->opt, p->ids, 1, (int)p->numel,
+      DP_TRY(mt_optim_launch_bf16g(p->P, p->Gr, p->M, p->V, p->W, (size_t)p->numel, p->opt, p->ids, 1, (int)p->numel,
                                    opt_step + s, stream));
   }
   return 0;

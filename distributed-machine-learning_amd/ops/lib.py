@@ -81,7 +81,7 @@ class DpPlan(C.Structure):
                 ("bucket_lo", C.c_int64 * (MT_MAX_LAYERS + 1)), ("bucket_hi", C.c_int64 * (MT_MAX_LAYERS + 1)),
                 ("numel", C.c_int64), ("X", c_void_p), ("Y", c_void_p), ("X0", c_void_p), ("ybuf", c_void_p),
                 ("H", c_void_p * MT_MAX_LAYERS), ("dZ", c_void_p * MT_MAX_LAYERS),
-                ("P", c_void_p), ("W", c_void_p), ("G32", c_void_p), ("Gb", c_void_p), ("M", c_void_p), ("V", c_void_p),
+                ("P", c_void_p), ("W", c_void_p), ("G32", c_void_p), ("Gb", c_void_p), ("Gr", c_void_p), ("M", c_void_p), ("V", c_void_p),
                 ("head", c_void_p), ("opt", c_void_p), ("ids", c_void_p), ("head_scratch", c_void_p),
                 ("all_reduce", c_void_p), ("comm", c_void_p), ("nccl_bf16", c_int32), ("nccl_avg", c_int32),
                 ("nccl_f32", c_int32), ("pad1", c_int32), ("clip_partials", c_void_p),

@@ -376,6 +376,11 @@ class HipDPEngine:
         plan.X, plan.Y = tr.X.data_ptr(), tr.y.data_ptr()
         plan.X0, plan.ybuf = self.X0.data_ptr(), self.ybuf.data_ptr()
         plan.P, plan.W, plan.G32, plan.Gb = self.P.data_ptr(), self.W.data_ptr(), self.G32.data_ptr(), self.Gb.data_ptr()
+        # the all-reduce is in place, except in the forced one-rank rehearsal: RCCL turns a one-rank in-place all-reduce
+        # into nothing at all, an out-of-place one into a device copy on the communication stream -- bytes that really move
+        # while the next input gradient runs, which is what a profile of the overlap needs to show
+        self.Gr = torch.zeros_like(self.Gb) if (force and tr.comm.world_size == 1) else self.Gb
+        plan.Gr = self.Gr.data_ptr()
         plan.M, plan.V = self.M.data_ptr(), self.V.data_ptr()
         plan.head, plan.opt, plan.ids = self._head_train.data_ptr(), self._opt.data_ptr(), self.ids.data_ptr()
         plan.head_scratch = self.scratch.data_ptr()
