@@ -73,6 +73,16 @@ def make_engine(trainable: PackedTrainable, device: torch.device, capacity: Opti
     raise ValueError(f"unknown engine {kind!r}")
 
 
+class _Ready:
+    """A finished 'collective' (one rank): ``wait()`` returns the value."""
+
+    def __init__(self, value: torch.Tensor):
+        self.value = value
+
+    def wait(self) -> torch.Tensor:
+        return self.value
+
+
 class PackedExecutor(Executor):
     lockstep = True          # results of one epoch form one scheduler batch
     moves_weights = True     # PBT exploits are slab copies / send-recv, not checkpoint restarts
@@ -116,6 +126,18 @@ class PackedExecutor(Executor):
         self._diverged: set = set()
         self._lost_pending: List[Trial] = []      # trials of ranks lost while moving trials: reported with the next round
         self._t_total: Dict[str, float] = {}
+        # Asynchronous rounds (trainable.exchange == "async"): the all-gather of a round's table is posted and the next
+        # epoch is trained before anyone waits for it, so a rank waits for a slower one only once that one is a whole epoch
+        # behind; results -- and with them every decision -- arrive one round late, on every rank alike.
+        # "rungs" does the same only on rounds whose results cannot lead to a decision (the scheduler's ``decides_at``:
+        # between the rungs of ASHA, between the perturbations of PBT) and reads everything that is in flight before a
+        # round that can: the same results, decisions and work as lockstep, minus the waits in between.
+        self.exchange = getattr(self.t, "exchange", "lockstep")
+        self.async_rounds = self.exchange in ("async", "rungs")
+        self._inflight: List[Tuple[Any, torch.Tensor, Tuple[float, float, float, int]]] = []   # posted, not yet read
+        self._trained: Dict[str, int] = {}          # epochs a resident trial has trained (>= its reported iterations)
+        self._draining: Dict[str, Trial] = {}       # trained to max_epochs, slot already freed, last result in flight
+        self._must_read = False                     # "rungs": everything in flight is being read before the next epoch
         self.runner = None
         self.stats: Dict[str, Any] = {"epochs": 0, "slot_epochs": 0, "train_s": 0.0, "eval_s": 0.0,
                                       "comm_s": 0.0, "engine": self.engine.name, "world_size": self.world,
@@ -198,6 +220,7 @@ class PackedExecutor(Executor):
         self._load[owner] += cost
         self._place[trial.trial_id] = (owner, slot)
         self._live[trial.trial_id] = trial
+        self._trained[trial.trial_id] = int(trial.training_iteration)
         self._t_total.setdefault(trial.trial_id, float(trial.last_result.get("time_total_s", 0.0)))
         trial.placement = {"rank": owner, "slot": slot}
         state = trial.restore_from
@@ -222,9 +245,20 @@ class PackedExecutor(Executor):
             out, self._queued = self._queued, []
             return out
         if not self._live:
+            self._discard_inflight()
             return []
         if self._n_undecided > 0:
             return []      # the runner still owes decisions for the previous round
+        if self.async_rounds:
+            return self._async_round()
+        table, times = self._train_round()
+        lost_trials, self._lost_pending = self._lost_pending, []
+        gathered, lost = self._gather(table)
+        return self._report(gathered, times, lost_trials + lost)
+
+    def _train_round(self) -> Tuple[torch.Tensor, Tuple[float, float, float, int]]:
+        """Level the ranks, train every resident trial for one epoch, validate, and build this rank's record table (one
+        row per slot + one row of timings).  Returns it with (t0, end of training, end of validation, local trials)."""
         if self.world > 1 and self.t.rebalance_gap > 0:
             self._rebalance()      # the runner has filled what it could with pending trials; even out what is left
         t0 = time.time()
@@ -236,6 +270,8 @@ class PackedExecutor(Executor):
             self.engine.begin_round()
             self.engine.train_epoch()
             table = device_table()
+            if self.async_rounds:
+                table = table.clone()        # the next epoch rewrites the engine's buffer while this one is in flight
             if self.world == 1 and self.runner is not None and hasattr(self.engine, "prepare"):
                 self._prefetch(t0)      # the epoch and its validation are enqueued: build the next trials meanwhile
             if self.comm.device.type != "cuda":       # a CPU-side collective (gloo, in-process ranks): one copy down
@@ -258,30 +294,113 @@ class PackedExecutor(Executor):
             rows_local = [[-1.0] * _REC for _ in range(self.capacity)]
             for slot, m in local.items():
                 tr = self._live[mine[slot]]
-                rows_local[slot] = [float(tr.index), float(tr.training_iteration + 1), m["train_loss"], m["validation_loss"],
-                                    m["validation_mse"], m["validation_mape"]]
+                rows_local[slot] = [float(tr.index), float(self._trained[tr.trial_id] + 1), m["train_loss"],
+                                    m["validation_loss"], m["validation_mse"], m["validation_mape"]]
             # one more row: this rank's time for the round and how many trials it spent it on; gathered with the metrics,
             # so that every rank knows every rank's cost per trial and all of them weigh a move the same way
             rows_local.append([-2.0, t2 - t0, float(len(local)), t1 - t0, 0.0, 0.0])
             table = torch.tensor(rows_local, dtype=torch.float64)         # one conversion, not one per slot
-        lost_trials, self._lost_pending = self._lost_pending, []
+        for tid in self._place:
+            self._trained[tid] += 1
+        return table, (t0, t1, t2, n_local)
+
+    def _gather(self, table: torch.Tensor, handle: Any = None) -> Tuple[torch.Tensor, List[Trial]]:
+        """The ranks' tables stacked (read back to the host), and the trials of ranks that turned out to be gone.  With a
+        ``handle`` the collective was posted earlier and is only waited for here."""
+        t2 = time.time()
+        lost: List[Trial] = []
         try:
-            gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
+            if handle is not None:
+                gathered = handle.wait()
+            else:
+                gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
             gathered = gathered.cpu()
         except Exception as e:          # noqa: BLE001 - RCCL / gloo raise backend-specific types
             what = (f"rank {self.rank} of {self.world}: metric exchange after epoch {self.stats['epochs'] + 1} "
                     f"failed ({type(e).__name__}: {e})")
             if not self._repairable:
                 raise RankLostError(what) from e
-            lost_trials = lost_trials + self._repair(what, e)
+            lost = self._repair(what, e)
             try:        # the round's results of the trials that are still there, over the re-formed group
                 gathered = self.comm.all_gather(table) if self.world > 1 else table.unsqueeze(0)
                 gathered = gathered.cpu()
             except Exception as e2:     # noqa: BLE001
                 raise RankLostError(f"{what}; the exchange over the re-formed group failed too "
                                     f"({type(e2).__name__}: {e2})") from e2
-        t3 = time.time()
-        if device_table is not None:                  # the device's own clock split the round into training and validation
+            # tables posted on the group that is gone are posted again, in order, on the new one
+            self._inflight = [(self._post(tb), tb, tm) for _, tb, tm in self._inflight]
+        self.stats["comm_s"] += max(0.0, time.time() - t2)
+        return gathered, lost
+
+    def _post(self, table: torch.Tensor) -> Any:
+        return self.comm.all_gather_async(table) if self.world > 1 else _Ready(table.unsqueeze(0))
+
+    def _discard_inflight(self) -> None:
+        """Nothing is live any more: tables still in flight only hold rows of trials that were stopped meanwhile.  They
+        are waited for (a posted collective must complete on every rank) and dropped."""
+        while self._inflight:
+            handle, _, _ = self._inflight.pop(0)
+            try:
+                handle.wait()
+            except Exception:       # noqa: BLE001 - the search is over; a peer that already left is not an error
+                pass
+
+    def _async_round(self) -> List[Event]:
+        """One round without a wait for the slowest rank in it: train and validate what is resident, post the table,
+        free the slots of trials that have now trained ``max_epochs`` (their last results are in the table just posted),
+        then read the table posted a round ago -- its collective has had a whole epoch to complete -- and hand its results
+        to the runner.  Decisions therefore take effect one round late: a trial that a rung stops has trained one epoch
+        more, whose result is dropped; in exchange no rank idles at a barrier every epoch."""
+        posted = False
+        if self._place and not self._must_read:
+            table, times = self._train_round()
+            self._inflight.append((self._post(table), table, times))
+            posted = True
+            for tid in [t for t in self._place if self._trained[t] >= self.t.max_epochs]:
+                self._drain(self._live[tid])
+        if not self._inflight:
+            return []
+        if self.exchange == "rungs":
+            # read what is in flight only when something in it can be decided on (or nothing is left to train); then
+            # read all of it, oldest first, one batch of events per call, before the next epoch is trained
+            if not self._must_read:
+                self._must_read = (not self._place) or self._decision_due()
+            if not self._must_read:
+                return []
+        elif posted and len(self._inflight) < 2 and self._place:
+            return []       # first round of a search: nothing is a round old yet
+        handle, table, times = self._inflight.pop(0)
+        if not self._inflight:
+            self._must_read = False
+        lost_trials, self._lost_pending = self._lost_pending, []
+        gathered, lost = self._gather(table, handle)
+        return self._report(gathered, times, lost_trials + lost)
+
+    def _decision_due(self) -> bool:
+        """Does the table just posted hold a result that can be answered with anything but CONTINUE?  Replicated: it looks
+        at the iteration counts of the resident and the just-finished trials and asks the (replicated) scheduler."""
+        ask = getattr(self.runner, "decides_at", None)
+        if ask is None:
+            return True
+        its = {self._trained[tid] for tid in self._place} | {self._trained.get(tid, self.t.max_epochs) for tid in self._draining}
+        return any(it >= self.t.max_epochs or ask(it) for it in its)
+
+    def _drain(self, tr: Trial) -> None:
+        """Asynchronous rounds: the trial has trained its last epoch; its slot goes back now, its last result follows."""
+        owner, slot = self._place[tr.trial_id]
+        if self.t.checkpoint_at_end or (self.runner is not None and self.runner.checkpoint_at_end):
+            self._checkpoint(tr)
+        self._place.pop(tr.trial_id)
+        if owner == self.rank:
+            self.engine.evict(slot)
+        self._free[owner].append(slot)
+        self._free[owner].sort()
+        self._unload(tr.trial_id, owner)
+        self._draining[tr.trial_id] = tr
+
+    def _report(self, gathered: torch.Tensor, times: Tuple[float, float, float, int], lost_trials: List[Trial]) -> List[Event]:
+        t0, t1, t2, n_local = times
+        if getattr(self.engine, "device_table", None) is not None:      # the device's own clock split the round
             mine_row = gathered[self.rank, -1]
             total, train = float(mine_row[1]), float(mine_row[3])
             t1, t2 = t0 + train, t0 + total
@@ -292,7 +411,6 @@ class PackedExecutor(Executor):
         if hasattr(self.engine, "stream_window"):
             self.stats["stream_window"] = str(self.engine.stream_window)
         self.stats["eval_s"] += t2 - t1
-        self.stats["comm_s"] += max(0.0, t3 - t2)
 
         by_index = {tr.index: tr for tr in self._live.values()}
         # numpy, not torch: a masked select + argsort of a few hundred rows costs tens of milliseconds per call through
@@ -315,7 +433,9 @@ class PackedExecutor(Executor):
         self._n_undecided = 0
         on_nonfinite, isfinite, t_total, place = self.t.on_nonfinite, math.isfinite, self._t_total, self._place
         for idx, it, train_loss, val_loss, val_mse, val_mape in rows.tolist():
-            tr = by_index[int(idx)]
+            tr = by_index.get(int(idx))
+            if tr is None:
+                continue        # asynchronous rounds: the extra epoch of a trial that was stopped while it trained
             tid = tr.trial_id
             t_total[tid] += self._epoch_time
             diverged = not (isfinite(train_loss) and isfinite(val_loss))
@@ -326,7 +446,7 @@ class PackedExecutor(Executor):
                 events.append(Event("error", tr, error=f"non-finite loss at epoch {int(it)}: "
                                                        f"train_loss={train_loss}, validation_loss={val_loss}"))
                 continue
-            rank, slot = place[tid]
+            rank, slot = place.get(tid) or (tr.placement["rank"], tr.placement["slot"])
             result = dict(const, training_iteration=int(it), train_loss=train_loss, validation_loss=val_loss,
                           validation_mse=val_mse, validation_mape=val_mape, time_total_s=t_total[tid], trial_id=tid,
                           iterations_since_restore=int(it), rank=rank, slot=slot)
@@ -367,6 +487,7 @@ class PackedExecutor(Executor):
                 del self._place[tid]
                 del self._live[tid]
                 self._cost.pop(tid, None)
+                self._trained.pop(tid, None)
                 lost_trials.append(tr)
         lost_trials.sort(key=lambda t: t.index)
         trials = self.runner.trials if self.runner is not None else list(self._live.values()) + lost_trials
@@ -430,22 +551,26 @@ class PackedExecutor(Executor):
             finished = d == STOP or tr.training_iteration >= self.t.max_epochs
             if finished:
                 self._retire(tr)
-            elif self.t.checkpoint_freq and tr.training_iteration % self.t.checkpoint_freq == 0:
+            elif self.t.checkpoint_freq and tr.training_iteration % self.t.checkpoint_freq == 0 \
+                    and tid in self._place:
                 self._checkpoint(tr)
         self._retired_last, self._retired_now = self._retired_now, 0
 
     def _checkpoint(self, tr: Trial) -> None:
         owner, slot = self._place[tr.trial_id]
-        tr.checkpoint_iter, tr.checkpoint_rank = tr.training_iteration, owner      # known on every rank
+        # what the slot holds: the epochs it has trained, which under asynchronous rounds is one more than what has been
+        # reported so far
+        it = self._trained.get(tr.trial_id, tr.training_iteration) if self.async_rounds else tr.training_iteration
+        tr.checkpoint_iter, tr.checkpoint_rank = it, owner      # known on every rank
         if owner != self.rank:
             tr.checkpoint = None          # an older state held here (the trial has moved since) is out of date now
             return
         state = self.engine.export(slot)
-        state.setdefault("training_iteration", tr.training_iteration)
+        state.setdefault("training_iteration", it)
         tr.checkpoint = state
         if tr.logdir:
             keep = self.runner.keep_checkpoints_num if self.runner is not None else None
-            ckpt.save_checkpoint(tr.logdir, tr.training_iteration, state, keep)
+            ckpt.save_checkpoint(tr.logdir, it, state, keep)
 
     def _unload(self, tid: str, rank: int) -> None:
         """Take a trial's weight off its rank (call after its slot went back to the free list)."""
@@ -454,6 +579,10 @@ class PackedExecutor(Executor):
             self._load[rank] = 0.0          # no rounding residue on an empty rank
 
     def _drop(self, tr: Trial) -> None:
+        self._trained.pop(tr.trial_id, None)
+        if self._draining.pop(tr.trial_id, None) is not None:       # its slot went back when it finished training
+            self._live.pop(tr.trial_id)
+            return
         owner, slot = self._place.pop(tr.trial_id)
         if owner == self.rank:
             self.engine.evict(slot)
@@ -463,6 +592,12 @@ class PackedExecutor(Executor):
         self._live.pop(tr.trial_id)
 
     def _retire(self, tr: Trial) -> None:
+        self._trained.pop(tr.trial_id, None)
+        if self._draining.pop(tr.trial_id, None) is not None:       # its slot went back when it finished training
+            self._live.pop(tr.trial_id)
+            self._retired_now += 1
+            self._queued.append(Event("done", tr, result={"decision": STOP}))
+            return
         owner, slot = self._place.pop(tr.trial_id)
         if self.t.checkpoint_at_end or (self.runner is not None and self.runner.checkpoint_at_end):
             self._place[tr.trial_id] = (owner, slot)
@@ -480,7 +615,7 @@ class PackedExecutor(Executor):
     def _exploit(self, tr: Trial) -> None:
         req = getattr(tr, "pbt_request", None)
         tr.pbt_request = None
-        if not req or req["donor"] not in self._place:
+        if not req or req["donor"] not in self._place or tr.trial_id not in self._place:
             return
         (drank, dslot), (rrank, rslot) = self._place[req["donor"]], self._place[tr.trial_id]
         tr.config = req["config"]
@@ -608,4 +743,5 @@ class PackedExecutor(Executor):
         return True
 
     def shutdown(self) -> None:
+        self._discard_inflight()
         self.engine.close()

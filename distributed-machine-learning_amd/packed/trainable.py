@@ -33,6 +33,12 @@ class PackedTrainable:
                                                          # this much (0 = a trial never leaves its first GPU)
     on_rank_loss: str = "repair"                         # a peer process vanished: "repair" = the survivors re-form the
                                                          # group and restart its trials; "raise" = stop with RankLostError
+    exchange: str = "lockstep"                           # ranks' metric tables: "lockstep" = gathered and decided on every
+                                                         # round; "async" = the gather is posted and read one round later
+                                                         # (no rank waits for the slowest within a round; decisions and
+                                                         # early stops take effect one epoch late); "rungs" = posted on
+                                                         # rounds where the scheduler can decide nothing, read in full
+                                                         # before a round where it can (lockstep's results, fewer waits)
     name: str = "packed"
     model_kwargs: Dict[str, Any] = field(default_factory=dict)
 
@@ -46,6 +52,8 @@ class PackedTrainable:
             raise ValueError("train/val feature shapes differ")
         if self.on_rank_loss not in ("repair", "raise"):
             raise ValueError("on_rank_loss must be 'repair' or 'raise'")
+        if self.exchange not in ("lockstep", "async", "rungs"):
+            raise ValueError("exchange must be 'lockstep', 'async' or 'rungs'")
         if self.model == "mlp" and self.train[0].dim() != 2:
             raise ValueError("the MLP family trains on tabular X [N, F]")
 

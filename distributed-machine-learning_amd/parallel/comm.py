@@ -25,6 +25,19 @@ from typing import Any, List, Optional, Sequence
 import torch
 
 
+class GatherHandle:
+    """A posted all-gather: ``wait()`` completes it (once) and returns the [world, ...] result."""
+
+    def __init__(self, finish):
+        self._finish, self._value = finish, None
+
+    def wait(self) -> torch.Tensor:
+        if self._finish is not None:
+            finish, self._finish = self._finish, None
+            self._value = finish()
+        return self._value
+
+
 class Comm:
     rank: int = 0
     world_size: int = 1
@@ -36,6 +49,14 @@ class Comm:
     def all_gather(self, t: torch.Tensor) -> torch.Tensor:
         """Stack equal-shaped ``t`` from every rank along a new leading dim."""
         raise NotImplementedError
+
+    def all_gather_async(self, t: torch.Tensor) -> "GatherHandle":
+        """Post the all-gather of ``t`` and return at once; ``handle.wait()`` gives the stacked result.  Every rank posts
+        and waits in the same order.  The default takes a snapshot of ``t`` and meets the other ranks only at
+        ``wait()`` (no background progress, same result); backends with asynchronous collectives overlap the transfer
+        -- and the wait for slower ranks -- with whatever the caller does in between."""
+        snap = t.detach().clone()
+        return GatherHandle(lambda: self.all_gather(snap))
 
     def all_reduce(self, t: torch.Tensor, op: str = "sum", async_op: bool = False):
         raise NotImplementedError
@@ -227,6 +248,19 @@ class TorchDistComm(Comm):
         out = torch.empty(self.world_size * src.numel(), dtype=src.dtype, device=src.device)
         self.dist.all_gather_into_tensor(out, src)       # one collective, ranks concatenated along dim 0
         return out.reshape((self.world_size,) + tuple(t.shape)).to(t.device)
+
+    def all_gather_async(self, t):
+        src = self._dev(t.detach().contiguous()).reshape(-1)
+        if src.data_ptr() == t.data_ptr():
+            src = src.clone()                # the caller may rewrite its tensor while the collective is in flight
+        out = torch.empty(self.world_size * src.numel(), dtype=src.dtype, device=src.device)
+        work = self.dist.all_gather_into_tensor(out, src, async_op=True)
+        shape, back = (self.world_size,) + tuple(t.shape), t.device
+
+        def finish(keep=src):              # holds the send buffer until the collective has completed
+            work.wait()
+            return out.reshape(shape).to(back)
+        return GatherHandle(finish)
 
     def all_reduce(self, t, op="sum", async_op=False):
         assert t.device == self.device or self.backend != "nccl", "all_reduce tensor must live on the comm device"

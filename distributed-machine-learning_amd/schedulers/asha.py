@@ -107,6 +107,13 @@ class AsyncHyperBandScheduler(TrialScheduler):
     def milestones(self) -> List[float]:
         return sorted(r["milestone"] for r in self._brackets[0].rungs)
 
+    def decides_at(self, iteration: int) -> bool:
+        """A trial is only ever cut at a rung it has just reached (or at ``max_t``): between rungs its results are recorded
+        nowhere and answered CONTINUE.  Exact for trials that report every iteration from their first one."""
+        if self.time_attr != "training_iteration":
+            return True
+        return iteration >= self.max_t or any(abs(iteration - r["milestone"]) < 1e-9 for b in self._brackets for r in b.rungs)
+
     def on_trial_add(self, runner, trial: Trial) -> None:
         if trial.trial_id in self._trial_bracket:
             return

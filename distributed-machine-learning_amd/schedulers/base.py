@@ -53,6 +53,12 @@ class TrialScheduler:
             out[i] = self.on_trial_result(runner, trials[i], results[i])
         return out
 
+    def decides_at(self, iteration: int) -> bool:
+        """Can a result reported at this ``training_iteration`` be answered with anything but CONTINUE?  Executors that
+        exchange results between processes use it to skip the wait for each other on rounds where nothing can be
+        decided.  A scheduler that cannot tell says True."""
+        return True
+
     def on_trial_complete(self, runner, trial: Trial, result: Dict) -> None:
         pass
 
@@ -92,6 +98,9 @@ class TrialScheduler:
 
 class FIFOScheduler(TrialScheduler):
     """Run trials in submission order, never stop early."""
+
+    def decides_at(self, iteration: int) -> bool:
+        return False
 
 
 def is_nan(x) -> bool:

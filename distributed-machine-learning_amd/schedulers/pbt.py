@@ -108,6 +108,12 @@ class PopulationBasedTraining(TrialScheduler):
         self.num_perturbations += 1
         trial.pbt_request = {"donor": donor.trial_id, "config": new_cfg}
 
+    def decides_at(self, iteration: int) -> bool:
+        """Members that report every iteration from 0 are perturbed at multiples of the interval and nowhere else."""
+        if self.time_attr != "training_iteration" or float(self.interval) != int(self.interval) or self.interval < 1:
+            return True
+        return iteration % int(self.interval) == 0
+
     # ------------------------------------------------------------------ events
     def on_trial_result(self, runner, trial: Trial, result: Dict) -> str:
         t = result.get(self.time_attr, 0)

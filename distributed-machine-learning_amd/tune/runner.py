@@ -210,6 +210,13 @@ class TrialRunner:
                 self.progress.report(self, final=True)
 
     # ------------------------------------------------------------------ event handlers
+    def decides_at(self, iteration: int) -> bool:
+        """False when a result at this training iteration can only be answered CONTINUE: no stop criterion, no time
+        budget, and a scheduler that decides nothing there."""
+        if self.stop is not None or self.time_budget_s is not None:
+            return True
+        return bool(self.scheduler.decides_at(iteration))
+
     def _should_stop(self, trial: Trial, result: Dict) -> bool:
         if self.stop is None:
             return False

@@ -27,9 +27,9 @@ SPACE = {"width": tune.choice([8, 16, 32]), "num_layers": tune.choice([1, 2]),
          "learning_rate": tune.loguniform(1e-3, 3e-2), "batch_size": tune.choice([64, 128])}
 
 
-def _search(comm, num_samples=12, capacity=6, scheduler=None, epochs=4, seed=0):
+def _search(comm, num_samples=12, capacity=6, scheduler=None, epochs=4, seed=0, exchange="lockstep"):
     train, val = _data()
-    tr = PackedTrainable(train=train, val=val, max_epochs=epochs, engine="torch", capacity=capacity)
+    tr = PackedTrainable(train=train, val=val, max_epochs=epochs, engine="torch", capacity=capacity, exchange=exchange)
     ex = PackedExecutor(tr, comm=comm, device=torch.device("cpu"), capacity=capacity, seed=seed)
     sched = scheduler or ASHAScheduler(metric="validation_loss", mode="min", max_t=epochs, reduction_factor=2)
     an = mitune.run(tr, config=SPACE, num_samples=num_samples, scheduler=sched, executor=ex, seed=seed, verbose=0)
@@ -185,6 +185,114 @@ def test_gloo_two_process_search_agrees(tmp_path):
     assert a["res"] == b["res"] and a["sum"] == 3.0
     single, _ = _search(LocalComm(), num_samples=8, capacity=8)
     assert {k: v[:2] for k, v in a["res"].items()} == {k: list(v[:2]) for k, v in single.items()}
+
+
+# ---------------------------------------------------------------------------------------- asynchronous rounds
+def test_async_rounds_reach_identical_decisions_on_every_rank_and_do_not_depend_on_the_rank_count():
+    """``exchange="async"``: tables are read one round after they were posted, so a rung's verdict reaches a trial after
+    one more epoch.  Every rank must still see the same results in the same order and decide alike; and since decisions
+    depend only on the gathered tables, one rank with all the slots reaches the same verdicts as three ranks."""
+    single, an1 = _search(LocalComm(), capacity=12, exchange="async")
+    ranks = _run_ranks(3, lambda c: _search(c, capacity=4, exchange="async"))
+    (r0, a0), (r1, _), (r2, _) = ranks
+    assert r0 == r1 == r2
+    assert {k: v[:2] for k, v in r0.items()} == {k: v[:2] for k, v in single.items()}
+    assert any(v[0] < 4 for v in single.values()) and any(v[0] == 4 for v in single.values())
+    assert len(r0) == 12 and all(1 <= v[0] <= 4 for v in r0.values())
+    # the same search in lockstep stops the same trials at the same rungs (ASHA's rungs only ever grow, and with one cohort
+    # the late verdicts see the same rung contents); what differs is the work: a stopped trial trained one epoch more
+    lock, an_lock = _search(LocalComm(), capacity=12)
+    assert {k: v[0] for k, v in lock.items()} == {k: v[0] for k, v in single.items()}
+    stopped = sum(1 for v in lock.values() if v[0] < 4)
+    assert an1.stats["slot_epochs"] == an_lock.stats["slot_epochs"] + stopped
+
+
+def test_exchange_at_the_rungs_only_gives_lockstep_results_with_fewer_exchanges_waited_for():
+    """``exchange="rungs"``: tables of rounds on which ASHA can decide nothing (between rungs 1, 2, 4 of this search) stay
+    in flight and are read, in order, before the next round that can be decided on.  Results, verdicts and the work done
+    are those of lockstep, on one rank and on three."""
+    lock, an_lock = _search(LocalComm(), num_samples=20, capacity=6, epochs=8)
+    rung, an_rung = _search(LocalComm(), num_samples=20, capacity=6, epochs=8, exchange="rungs")
+    assert rung == lock and an_rung.stats["slot_epochs"] == an_lock.stats["slot_epochs"]
+    ranks = _run_ranks(3, lambda c: _search(c, num_samples=20, capacity=2, epochs=8, exchange="rungs")[0])
+    assert ranks[0] == ranks[1] == ranks[2]
+    assert {k: v[:2] for k, v in ranks[0].items()} == {k: v[:2] for k, v in lock.items()}
+    sched = ASHAScheduler(metric="validation_loss", mode="min", max_t=8, reduction_factor=2)
+    assert [sched.decides_at(i) for i in range(1, 9)] == [True, True, False, True, False, False, False, True]
+    pbt = PopulationBasedTraining(metric="validation_loss", mode="min", perturbation_interval=3,
+                                  hyperparam_mutations={"learning_rate": tune.loguniform(1e-3, 3e-2)})
+    assert [pbt.decides_at(i) for i in range(1, 7)] == [False, False, True, False, False, True]
+
+
+def test_async_rounds_refill_slots_and_finish_every_trial():
+    res, an = _search(LocalComm(), num_samples=20, capacity=4, epochs=4, exchange="async")
+    assert len(res) == 20 and all(1 <= v[0] <= 4 for v in res.values())
+    assert all(t.status == "TERMINATED" for t in an.trials)
+    assert an.stats["slot_epochs"] < 20 * 4 + 20          # early stopping still saves work, one extra epoch per stop at most
+    ranks = _run_ranks(2, lambda c: _search(c, num_samples=20, capacity=2, epochs=4, exchange="async")[0])
+    assert ranks[0] == ranks[1] and len(ranks[0]) == 20
+
+
+def test_async_rounds_with_population_based_training():
+    def fn(comm):
+        pbt = PopulationBasedTraining(metric="validation_loss", mode="min", perturbation_interval=2,
+                                      hyperparam_mutations={"learning_rate": tune.loguniform(1e-3, 3e-2)}, seed=0)
+        res, an = _search(comm, num_samples=6, capacity=3, scheduler=pbt, epochs=6, exchange="async")
+        return res, an.stats["exploits"]
+    (r0, e0), (r1, e1) = _run_ranks(2, fn)
+    assert r0 == r1 and e0 == e1 and e0 >= 1 and all(v[0] == 6 for v in r0.values())
+
+
+def _gloo_async_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import time
+    from mitune.packed.engine import TorchPackEngine
+    from mitune.parallel.comm import TorchDistComm
+
+    class UnevenEngine(TorchPackEngine):            # the ranks take turns at being 150 ms late
+        epochs_done = 0
+
+        def train_epoch(self):
+            super().train_epoch()
+            if self.epochs_done % 2 == rank:
+                time.sleep(0.15)
+            self.epochs_done += 1
+
+    out = {}
+    for exchange in ("lockstep", "async", "rungs"):
+        comm = TorchDistComm(backend="gloo", rank=rank, world_size=world) if exchange == "lockstep" else comm      # noqa: F821
+        train, val = _data()
+        tr = PackedTrainable(train=train, val=val, max_epochs=5, engine="torch", capacity=4, exchange=exchange)
+        ex = PackedExecutor(tr, comm=comm, device=torch.device("cpu"), capacity=4, seed=0,
+                            engine=UnevenEngine(tr, "cpu", 4, 0))
+        an = mitune.run(tr, config=SPACE, num_samples=8, executor=ex, seed=0, verbose=0,
+                        scheduler=ASHAScheduler(metric="validation_loss", mode="min", max_t=5, reduction_factor=2))
+        out[exchange] = {"res": {t.trial_id: (t.training_iteration, t.last_result["validation_loss"]) for t in an.trials},
+                         "comm_s": an.stats["comm_s"], "rounds": an.stats["epochs"]}
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(out, f)
+    comm.close()
+
+
+def test_gloo_async_rounds_agree_and_hide_the_wait_for_the_slower_rank(tmp_path):
+    """Two gloo processes that take turns at sleeping 150 ms after an epoch (skew that changes sides, as between GPUs whose
+    packs differ from round to round).  In lockstep the rank that is on time waits inside every round's exchange; with
+    asynchronous rounds the gather it reads was posted a whole epoch earlier and the two delays cancel."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gloo_async_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = json.load(open(tmp_path / "rank0.json"))
+    b = json.load(open(tmp_path / "rank1.json"))
+    for mode in ("lockstep", "async", "rungs"):
+        assert a[mode]["res"] == b[mode]["res"] and len(a[mode]["res"]) == 8
+    assert a["rungs"]["res"] == a["lockstep"]["res"]
+    assert {k: v[0] for k, v in a["async"]["res"].items()} == {k: v[0] for k, v in a["lockstep"]["res"].items()}
+    wait_lock = a["lockstep"]["comm_s"] + b["lockstep"]["comm_s"]
+    wait_async = a["async"]["comm_s"] + b["async"]["comm_s"]
+    assert wait_lock > 0.1 * a["lockstep"]["rounds"]           # one of the two waited ~150 ms in every round
+    assert wait_async < 0.5 * wait_lock, (wait_async, wait_lock)
+    assert a["rungs"]["comm_s"] + b["rungs"]["comm_s"] < 0.7 * wait_lock      # rungs at 1, 2, 4 (and 5 = max_t) of 5 rounds
 
 
 def _gloo_move_worker(rank, world, port, out_dir):

@@ -389,6 +389,10 @@ out["after"] = [comm.rank, comm.world_size]
 t2 = torch.full((8,), 3.0, device=dev)
 comm.all_reduce(t2, op="sum")
 g2 = comm.all_gather(table)
+h1, h2 = comm.all_gather_async(table), comm.all_gather_async(table + 1)          # two posted, read in order
+table += 100                                                                      # the caller's tensor may change meanwhile
+out["async_ok"] = bool(torch.equal(h1.wait()[0], g2[0]) and torch.equal(h2.wait()[0], g2[0] + 1))
+table -= 100
 out["after_ok"] = bool(float(t2.sum().item()) == 24.0 and torch.equal(g2[0], table))
 out["members2"] = comm.shrink()                   # and once more: generations do not collide
 out["rdzv"] = comm.rendezvous_dir
@@ -418,7 +422,7 @@ def test_rccl_backend_one_rank_collectives_and_group_repair(tmp_path):
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
     assert rec["backend"] == "nccl" and rec["device"] == "cuda:0"
     assert rec["gather_ok"] and rec["bcast_ok"] and rec["max"] == 1.25 and rec["avg"] == 1.0 and rec["obj"] == {"epoch": 3}
-    assert rec["delivers_errors"] and rec["members"] == [0] and rec["members2"] == [0] and rec["after"] == [0, 1] and rec["after_ok"]
+    assert rec["delivers_errors"] and rec["members"] == [0] and rec["members2"] == [0] and rec["after"] == [0, 1] and rec["after_ok"] and rec["async_ok"]
     assert rec["rdzv"].startswith(str(tmp_path))
     assert os.path.isdir(os.path.join(rec["rdzv"], "gen1")) and os.path.isdir(os.path.join(rec["rdzv"], "gen2"))
 
