@@ -1155,20 +1155,32 @@ static bool at_exact_fits(int S, int dk, int dv) { return S <= ATX_MAX_S && dk <
 // ---------------------------------------------------------------------------------------------------------------
 // Grouped form for packs of sequence-model trials: one launch covers the attention of one encoder layer of EVERY
 // resident trial.  Workgroup (x, y) is (batch, head) problem x of trial slot ids[y]; each slot brings its own head
-// count, head width, dropout rate and seed.  Operands are the slot's fused projection output [B*S][3d] = q | k | v
-// (f32, read in place) and its [B*S][d] attention output.
+// count, query / key width, value width, attention kind (0 softmax, 1 relu-normalised), dropout rate and seed.
+// Operands are read in place from the slot's projection output: q, k [B*S][..] with row stride ldq (head h at column
+// h * dk), v with row stride ldv (head h at column h * dv) -- the three blocks of one fused projection, or v from a
+// buffer of its own (values mixed by a local convolution) -- and the output o [B*S][H * dv] with row stride ldo.
 struct MtAttnSlot {
-  const float* qkv;
+  const float* q;
+  const float* k;
+  const float* v;
   float* o;
   float* stat;          // [B*H][S] row statistic saved for the backward pass
-  const float* d_o;     // backward: gradient of o
-  float* dqkv;          // backward: gradient of qkv, same layout
+  const float* d_o;     // backward: gradient of o (row stride ldo)
+  float* dq;            // backward: gradients, laid out like q, k, v
+  float* dkk;
+  float* dvv;
   const uint32_t* seed; // {lo, hi} dropout seed words of the slot's current epoch
-  int32_t B, H, dk, active_steps;
+  int32_t B, H, dk, dv;
+  int32_t ldq, ldv, ldo, kind;
+  int32_t active_steps, site;
   float scale, keep_scale;
   uint32_t thresh;      // p * 2^32, 0 = no attention dropout
-  int32_t site;
+  int32_t pad;
 };
+
+#define AT_SLOT_FWD_ARGS(a) (a).q, (a).k, (a).v, nullptr, (a).o, (a).stat, S, (a).dk, (a).dv, (a).scale
+#define AT_SLOT_BWD_ARGS(a) (a).q, (a).k, (a).v, (a).d_o, nullptr, (a).stat, (a).dq, (a).dkk, (a).dvv, S, (a).dk, (a).dv, (a).scale
+#define AT_SLOT_TAIL(a) (a).kind, (a).H, (long)(a).ldq, (long)(a).ldv, (long)(a).ldo, seeded, s0, s1, (a).thresh, blockIdx.x
 
 template <int NKB, int PCHQ>
 __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_grouped_kernel(const MtAttnSlot* __restrict__ slots,
@@ -1181,13 +1193,10 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_grouped_kernel(const M
   if (step >= a.active_steps) return;
   const int B = b_override > 0 ? b_override : a.B;
   if ((int)blockIdx.x >= B * a.H) return;
-  const int d = a.H * a.dk;
   const bool seeded = train && a.thresh != 0u && a.seed != nullptr;
   uint32_t s0 = 0u, s1 = 0u;
   if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
-  attn_fwd_body<NKB, PCHQ, true>(lds, a.qkv, a.qkv + d, a.qkv + 2 * d, nullptr, a.o, a.stat, S, a.dk, a.dk, a.scale,
-                                 seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1, a.thresh,
-                                 blockIdx.x);
+  attn_fwd_body<NKB, PCHQ, true>(lds, AT_SLOT_FWD_ARGS(a), seeded ? a.keep_scale : 1.f, AT_SLOT_TAIL(a));
 }
 
 template <int NKB, int PCHQ>
@@ -1199,13 +1208,10 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_kernel(const M
   const MtAttnSlot a = slots[ids[blockIdx.y]];
   if (step >= a.active_steps) return;
   if ((int)blockIdx.x >= a.B * a.H) return;
-  const int d = a.H * a.dk;
   const bool seeded = a.thresh != 0u && a.seed != nullptr;
   uint32_t s0 = 0u, s1 = 0u;
   if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
-  attn_bwd_body<NKB, PCHQ, true>(lds, a.qkv, a.qkv + d, a.qkv + 2 * d, a.d_o, nullptr, a.stat, a.dqkv, a.dqkv + d,
-                                 a.dqkv + 2 * d, S, a.dk, a.dk, a.scale, seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d,
-                                 (long)d, seeded, s0, s1, a.thresh, blockIdx.x);
+  attn_bwd_body<NKB, PCHQ, true>(lds, AT_SLOT_BWD_ARGS(a), seeded ? a.keep_scale : 1.f, AT_SLOT_TAIL(a));
 }
 
 __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_grouped_exact_kernel(const MtAttnSlot* __restrict__ slots,
@@ -1218,12 +1224,10 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_grouped_exact_kernel(c
   if (step >= a.active_steps) return;
   const int B = b_override > 0 ? b_override : a.B;
   if ((int)blockIdx.x >= B * a.H) return;
-  const int d = a.H * a.dk;
   const bool seeded = train && a.thresh != 0u && a.seed != nullptr;
   uint32_t s0 = 0u, s1 = 0u;
   if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
-  attn_fwd_exact_body(lds, a.qkv, a.qkv + d, a.qkv + 2 * d, nullptr, a.o, a.stat, S, a.dk, a.dk, a.scale,
-                      seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1, a.thresh, blockIdx.x);
+  attn_fwd_exact_body(lds, AT_SLOT_FWD_ARGS(a), seeded ? a.keep_scale : 1.f, AT_SLOT_TAIL(a));
 }
 
 __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_exact_kernel(const MtAttnSlot* __restrict__ slots,
@@ -1235,13 +1239,10 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_exact_kernel(c
   const MtAttnSlot a = slots[ids[blockIdx.y]];
   if (step >= a.active_steps) return;
   if ((int)blockIdx.x >= a.B * a.H) return;
-  const int d = a.H * a.dk;
   const bool seeded = a.thresh != 0u && a.seed != nullptr;
   uint32_t s0 = 0u, s1 = 0u;
   if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
-  attn_bwd_exact_body(lds, a.qkv, a.qkv + d, a.qkv + 2 * d, a.d_o, nullptr, a.stat, a.dqkv, a.dqkv + d, a.dqkv + 2 * d, S,
-                      a.dk, a.dk, a.scale, seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1,
-                      a.thresh, blockIdx.x);
+  attn_bwd_exact_body(lds, AT_SLOT_BWD_ARGS(a), seeded ? a.keep_scale : 1.f, AT_SLOT_TAIL(a));
 }
 
 // Sequences of 33..128 tokens, exact f32: the tiled bodies, dynamic LDS sized by the launcher for the widest head.
@@ -1256,12 +1257,10 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_grouped_tiled_kernel(c
   if (step >= a.active_steps) return;
   const int B = b_override > 0 ? b_override : a.B;
   if ((int)blockIdx.x >= B * a.H) return;
-  const int d = a.H * a.dk;
   const bool seeded = train && a.thresh != 0u && a.seed != nullptr;
   uint32_t s0 = 0u, s1 = 0u;
   if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
-  atl_fwd_body<NC>(atl_lds, a.qkv, a.qkv + d, a.qkv + 2 * d, nullptr, a.o, a.stat, S, a.dk, a.dk, a.scale,
-                   seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1, a.thresh, blockIdx.x);
+  atl_fwd_body<NC>(atl_lds, AT_SLOT_FWD_ARGS(a), seeded ? a.keep_scale : 1.f, AT_SLOT_TAIL(a));
 }
 
 template <int NC, int NE>
@@ -1274,17 +1273,14 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_tiled_kernel(c
   const MtAttnSlot a = slots[ids[blockIdx.y]];
   if (step >= a.active_steps) return;
   if ((int)blockIdx.x >= a.B * a.H) return;
-  const int d = a.H * a.dk;
   const bool seeded = a.thresh != 0u && a.seed != nullptr;
   uint32_t s0 = 0u, s1 = 0u;
   if (seeded) mt_site_seed(a.seed, a.site, step, s0, s1);
   // NE covers the widest head of the launch; a slot with narrower heads takes the body compiled for its own width
-#define ATL_SLOT_BWD(E)                                                                                                   \
-  atl_bwd_body<NC, E>(atl_lds, a.qkv, a.qkv + d, a.qkv + 2 * d, a.d_o, nullptr, a.stat, a.dqkv, a.dqkv + d, a.dqkv + 2 * d, S, \
-                      a.dk, a.dk, a.scale, seeded ? a.keep_scale : 1.f, 0, a.H, 3L * d, 3L * d, (long)d, seeded, s0, s1,  \
-                      a.thresh, blockIdx.x)
-  if constexpr (NE >= 8) { if (a.dk > 32) { ATL_SLOT_BWD(8); return; } }
-  if constexpr (NE >= 4) { if (a.dk > 16) { ATL_SLOT_BWD(4); return; } }
+  const int wmax = a.dk > a.dv ? a.dk : a.dv;
+#define ATL_SLOT_BWD(E) atl_bwd_body<NC, E>(atl_lds, AT_SLOT_BWD_ARGS(a), seeded ? a.keep_scale : 1.f, AT_SLOT_TAIL(a))
+  if constexpr (NE >= 8) { if (wmax > 32) { ATL_SLOT_BWD(8); return; } }
+  if constexpr (NE >= 4) { if (wmax > 16) { ATL_SLOT_BWD(4); return; } }
   ATL_SLOT_BWD(2);
 #undef ATL_SLOT_BWD
 }

@@ -52,8 +52,19 @@ struct MtLnSlot {
   int32_t M, d, active_steps, site;
   float keep_scale, eps;
   uint32_t thresh;
+  int32_t S;             // rows per sample (stochastic depth draws one keep flag per sample); 0 = no stochastic depth
+  uint32_t sd_thresh;    // drop-path rate * 2^32, 0 = the branch is always kept
+  float sd_scale;        // 1 / (1 - rate)
+  int32_t sd_site;       // the site the per-sample flags are drawn at
   int32_t pad;
 };
+
+// Stochastic depth: the whole branch of sample b = row / S is dropped (0) or kept and scaled (sd_scale), from the
+// counter hash of (slot seed, sd_site, step, b) -- forward and backward draw the same flag.
+__device__ __forceinline__ float mt_ln_sample_scale(const MtLnSlot& a, bool on, uint32_t q0, uint32_t q1, int row) {
+  if (!on) return 1.f;
+  return mt_rng_hash(q0, q1, (uint32_t)(row / a.S)) >= a.sd_thresh ? a.sd_scale : 0.f;
+}
 
 struct MtSeqHeadSlot {
   const float* H;        // [B*S][d] output of the slot's last encoder layer
@@ -137,8 +148,9 @@ __global__ __launch_bounds__(SQ_THREADS) void mt_seq_gather_kernel(const MtGathe
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm, forward
-// Rows of d <= 256 floats, one float4 per lane, SQ_LN_ROWS rows per wave with all loads issued before the first
-// reduction.  Grid (ceil(max rows / 16), active slots).
+// Rows of d <= 256 * NV floats, NV float4 per lane (columns 4 * (lane + 64 j)), SQ_LN_ROWS rows per wave with all loads
+// issued before the first reduction.  Grid (ceil(max rows / 16), active slots).
+template <int NV>
 __global__ __launch_bounds__(SQ_THREADS) void mt_seq_ln_fwd_kernel(const MtLnSlot* __restrict__ slots,
                                                                    const int32_t* __restrict__ ids, int step_imm,
                                                                    int m_override, int train,
@@ -150,28 +162,39 @@ __global__ __launch_bounds__(SQ_THREADS) void mt_seq_ln_fwd_kernel(const MtLnSlo
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = (blockIdx.x * 4 + wave) * SQ_LN_ROWS;
   if (row0 >= M) return;
-  const int d = a.d, nv = d >> 2;
-  const bool col_ok = lane < nv;
-  const int c4 = col_ok ? 4 * lane : 0;
+  const int d = a.d;
+  bool col_ok[NV];
+  int c4[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { col_ok[j] = 4 * (lane + 64 * j) < d; c4[j] = col_ok[j] ? 4 * (lane + 64 * j) : 0; }
   const bool drop = train && a.thresh != 0u && a.seed != nullptr;
-  uint32_t s0 = 0u, s1 = 0u;
+  const bool sdrop = train && a.sd_thresh != 0u && a.seed != nullptr && a.S > 0;
+  uint32_t s0 = 0u, s1 = 0u, q0 = 0u, q1 = 0u;
   if (drop) mt_site_seed(a.seed, a.site, step, s0, s1);
-  f32x4 v[SQ_LN_ROWS];
+  if (sdrop) mt_site_seed(a.seed, a.sd_site, step, q0, q1);
+  f32x4 v[SQ_LN_ROWS][NV];
   float sum[SQ_LN_ROWS];
 #pragma unroll
   for (int i = 0; i < SQ_LN_ROWS; ++i) {
-    const bool ok = col_ok && (row0 + i < M);
-    const size_t off = (size_t)(row0 + i < M ? row0 + i : row0) * d + c4;
-    f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + off);
-    const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + off);
-    if (drop) {
-      const uint32_t kw = mt_keep_word4s(s0, s1, a.thresh, (uint32_t)off);
+    const int rc = row0 + i < M ? row0 + i : row0;
+    const float sf = mt_ln_sample_scale(a, sdrop, q0, q1, rc);
+    sum[i] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) xv[e] *= ((kw >> (8 * e)) & 0xFFu) ? a.keep_scale : 0.f;
+    for (int j = 0; j < NV; ++j) {
+      const bool ok = col_ok[j] && (row0 + i < M);
+      const size_t off = (size_t)rc * d + c4[j];
+      f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + off);
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + off);
+      if (drop) {
+        const uint32_t kw = mt_keep_word4s(s0, s1, a.thresh, (uint32_t)off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] *= ((kw >> (8 * e)) & 0xFFu) ? a.keep_scale : 0.f;
+      }
+      if (sdrop) xv = xv * sf;
+      const f32x4 zv = xv + rv;
+      v[i][j] = ok ? zv : f32x4{0.f, 0.f, 0.f, 0.f};
+      sum[i] += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
     }
-    const f32x4 zv = xv + rv;
-    v[i] = ok ? zv : f32x4{0.f, 0.f, 0.f, 0.f};
-    sum[i] = (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
   float mean[SQ_LN_ROWS], rstd[SQ_LN_ROWS];
 #pragma unroll
@@ -179,77 +202,96 @@ __global__ __launch_bounds__(SQ_THREADS) void mt_seq_ln_fwd_kernel(const MtLnSlo
 #pragma unroll
   for (int i = 0; i < SQ_LN_ROWS; ++i) {
     float var = 0.f;
-    if (col_ok) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float c0 = v[i][e] - mean[i]; var += c0 * c0; }
-    }
+    for (int j = 0; j < NV; ++j)
+      if (col_ok[j]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float c0 = v[i][j][e] - mean[i]; var += c0 * c0; }
+      }
     sum[i] = var;
   }
 #pragma unroll
   for (int i = 0; i < SQ_LN_ROWS; ++i) rstd[i] = rsqrtf(wave_sum(sum[i]) / (float)d + a.eps);
-  const f32x4 wv = *reinterpret_cast<const f32x4*>(a.w + c4), bv = *reinterpret_cast<const f32x4*>(a.b + c4);
 #pragma unroll
-  for (int i = 0; i < SQ_LN_ROWS; ++i) {
-    if (col_ok && row0 + i < M) {
-      const size_t off = (size_t)(row0 + i) * d + c4;
-      f32x4 o;
+  for (int j = 0; j < NV; ++j) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.w + c4[j]), bv = *reinterpret_cast<const f32x4*>(a.b + c4[j]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean[i]) * rstd[i] * wv[e] + bv[e];
-      *reinterpret_cast<f32x4*>(a.z + off) = v[i];
-      *reinterpret_cast<f32x4*>(a.y + off) = o;
+    for (int i = 0; i < SQ_LN_ROWS; ++i) {
+      if (col_ok[j] && row0 + i < M) {
+        const size_t off = (size_t)(row0 + i) * d + c4[j];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][j][e] - mean[i]) * rstd[i] * wv[e] + bv[e];
+        *reinterpret_cast<f32x4*>(a.z + off) = v[i][j];
+        *reinterpret_cast<f32x4*>(a.y + off) = o;
+      }
     }
-    if (lane == 0 && row0 + i < M) { a.stats[2 * (size_t)(row0 + i)] = mean[i]; a.stats[2 * (size_t)(row0 + i) + 1] = rstd[i]; }
   }
+#pragma unroll
+  for (int i = 0; i < SQ_LN_ROWS; ++i)
+    if (lane == 0 && row0 + i < M) { a.stats[2 * (size_t)(row0 + i)] = mean[i]; a.stats[2 * (size_t)(row0 + i) + 1] = rstd[i]; }
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm, backward
-// dz = rstd (g - mean(g) - xhat mean(g xhat)), g = dy w;  dres = dz, dx = dz * dropout mask;  per-workgroup partial sums
-// of dw = sum dy xhat and db = sum dy over the 32 rows of the workgroup.  Grid (ceil(max rows / 32), active slots).
+// dz = rstd (g - mean(g) - xhat mean(g xhat)), g = dy w;  dres = dz, dx = dz * dropout mask * sample scale;  per-workgroup
+// partial sums of dw = sum dy xhat and db = sum dy over the 32 rows of the workgroup.  Grid (ceil(max rows / 32), slots).
+template <int NV>
 __global__ __launch_bounds__(SQ_THREADS) void mt_seq_ln_bwd_kernel(const MtLnSlot* __restrict__ slots,
                                                                    const int32_t* __restrict__ ids, int step_imm,
                                                                    const int* __restrict__ step_base) {
-  __shared__ float red[4][512];
+  __shared__ float red[4][2 * 256 * NV];
   const int step = mt_step(step_imm, step_base);
   const MtLnSlot a = slots[ids[blockIdx.y]];
   if (step >= a.active_steps) return;
   const int M = a.M, d = a.d;
   if ((int)blockIdx.x * 4 * SQ_LNB_ROWS >= M) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nv = d >> 2;
-  const bool col_ok = lane < nv;
-  const int c4 = col_ok ? 4 * lane : 0;
+  bool col_ok[NV];
+  int c4[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { col_ok[j] = 4 * (lane + 64 * j) < d; c4[j] = col_ok[j] ? 4 * (lane + 64 * j) : 0; }
   const bool drop = a.thresh != 0u && a.seed != nullptr;
-  uint32_t s0 = 0u, s1 = 0u;
+  const bool sdrop = a.sd_thresh != 0u && a.seed != nullptr && a.S > 0;
+  uint32_t s0 = 0u, s1 = 0u, q0 = 0u, q1 = 0u;
   if (drop) mt_site_seed(a.seed, a.site, step, s0, s1);
-  const f32x4 wv = *reinterpret_cast<const f32x4*>(a.w + c4);
-  f32x4 dw = f32x4{0.f, 0.f, 0.f, 0.f}, db = dw;
+  if (sdrop) mt_site_seed(a.seed, a.sd_site, step, q0, q1);
+  f32x4 wv[NV], dw[NV], db[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    wv[j] = *reinterpret_cast<const f32x4*>(a.w + c4[j]);
+    dw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    db[j] = dw[j];
+  }
   const int row0 = (blockIdx.x * 4 + wave) * SQ_LNB_ROWS;
   const float inv_d = 1.f / (float)d;
 #pragma unroll
   for (int it = 0; it < SQ_LNB_ROWS; it += SQ_LN_ROWS) {
     if (row0 + it >= M) break;                                   // wave-uniform
-    f32x4 g[SQ_LN_ROWS], xh[SQ_LN_ROWS];
+    f32x4 g[SQ_LN_ROWS][NV], xh[SQ_LN_ROWS][NV];
     float t1[SQ_LN_ROWS], t2[SQ_LN_ROWS], rstd[SQ_LN_ROWS];
 #pragma unroll
     for (int i = 0; i < SQ_LN_ROWS; ++i) {
       const int row = row0 + it + i;
-      const bool ok = col_ok && row < M;
       const int rc = row < M ? row : row0 + it;                  // clamped: loads never branch
-      const size_t off = (size_t)rc * d + c4;
-      const f32x4 dyv = *reinterpret_cast<const f32x4*>(a.dy + off);
-      const f32x4 zv = *reinterpret_cast<const f32x4*>(a.z + off);
       const float mean = a.stats[2 * (size_t)rc];
       rstd[i] = a.stats[2 * (size_t)rc + 1];
       t1[i] = 0.f; t2[i] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float dye = ok ? dyv[e] : 0.f;
-        xh[i][e] = ok ? (zv[e] - mean) * rstd[i] : 0.f;
-        g[i][e] = dye * wv[e];
-        t1[i] += g[i][e];
-        t2[i] += g[i][e] * xh[i][e];
-        dw[e] += dye * xh[i][e];
-        db[e] += dye;
+      for (int j = 0; j < NV; ++j) {
+        const bool ok = col_ok[j] && row < M;
+        const size_t off = (size_t)rc * d + c4[j];
+        const f32x4 dyv = *reinterpret_cast<const f32x4*>(a.dy + off);
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(a.z + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dye = ok ? dyv[e] : 0.f;
+          xh[i][j][e] = ok ? (zv[e] - mean) * rstd[i] : 0.f;
+          g[i][j][e] = dye * wv[j][e];
+          t1[i] += g[i][j][e];
+          t2[i] += g[i][j][e] * xh[i][j][e];
+          dw[j][e] += dye * xh[i][j][e];
+          db[j][e] += dye;
+        }
       }
     }
 #pragma unroll
@@ -259,33 +301,68 @@ __global__ __launch_bounds__(SQ_THREADS) void mt_seq_ln_bwd_kernel(const MtLnSlo
 #pragma unroll
     for (int i = 0; i < SQ_LN_ROWS; ++i) {
       const int row = row0 + it + i;
-      if (col_ok && row < M) {
-        const size_t off = (size_t)row * d + c4;
+      if (row >= M) continue;
+      const float sf = mt_ln_sample_scale(a, sdrop, q0, q1, row);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        if (!col_ok[j]) continue;
+        const size_t off = (size_t)row * d + c4[j];
         f32x4 dz, dxv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dz[e] = rstd[i] * (g[i][e] - t1[i] - xh[i][e] * t2[i]);
+        for (int e = 0; e < 4; ++e) dz[e] = rstd[i] * (g[i][j][e] - t1[i] - xh[i][j][e] * t2[i]);
         dxv = dz;
         if (drop) {
           const uint32_t kw = mt_keep_word4s(s0, s1, a.thresh, (uint32_t)off);
 #pragma unroll
           for (int e = 0; e < 4; ++e) dxv[e] *= ((kw >> (8 * e)) & 0xFFu) ? a.keep_scale : 0.f;
         }
+        if (sdrop) dxv = dxv * sf;
         *reinterpret_cast<f32x4*>(a.dres + off) = dz;
         *reinterpret_cast<f32x4*>(a.dx + off) = dxv;
       }
     }
   }
+  constexpr int W = 256 * NV;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    red[wave][lane * 4 + e] = dw[e];
-    red[wave][256 + lane * 4 + e] = db[e];
-  }
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[wave][4 * (lane + 64 * j) + e] = dw[j][e];
+      red[wave][W + 4 * (lane + 64 * j) + e] = db[j][e];
+    }
   __syncthreads();
   float* out = a.part + (size_t)blockIdx.x * 2 * d;
   for (int k = threadIdx.x; k < d; k += SQ_THREADS) {
     out[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-    out[d + k] = (red[0][256 + k] + red[1][256 + k]) + (red[2][256 + k] + red[3][256 + k]);
+    out[d + k] = (red[0][W + k] + red[1][W + k]) + (red[2][W + k] + red[3][W + k]);
   }
+}
+
+// Launchers: NV = 1 for packs whose widest slot has at most 256 columns (the arithmetic of NV = 1 and NV = 2 is the same
+// for such a slot except for the order in which a lane adds its second float4, which it does not have).
+extern "C" int mt_seq_ln_fwd_launch(const MtLnSlot* slots, const int32_t* ids, int n_active, int max_m, int max_d, int step,
+                                    int rows, int train, hipStream_t stream) {
+  if (n_active <= 0 || max_m <= 0) return 0;
+  if (max_d < 4 || max_d > 512 || (max_d & 3)) return -2;
+  const int m = rows > 0 ? rows : max_m;
+  const dim3 grid((m + 4 * SQ_LN_ROWS - 1) / (4 * SQ_LN_ROWS), n_active), block(SQ_THREADS);
+  if (max_d <= 256)
+    hipLaunchKernelGGL(mt_seq_ln_fwd_kernel<1>, grid, block, 0, stream, slots, ids, step, rows, train, mt_step_base_tls);
+  else
+    hipLaunchKernelGGL(mt_seq_ln_fwd_kernel<2>, grid, block, 0, stream, slots, ids, step, rows, train, mt_step_base_tls);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mt_seq_ln_bwd_launch(const MtLnSlot* slots, const int32_t* ids, int n_active, int max_m, int max_d, int step,
+                                    hipStream_t stream) {
+  if (n_active <= 0 || max_m <= 0) return 0;
+  if (max_d < 4 || max_d > 512 || (max_d & 3)) return -2;
+  const dim3 grid((max_m + 4 * SQ_LNB_ROWS - 1) / (4 * SQ_LNB_ROWS), n_active), block(SQ_THREADS);
+  if (max_d <= 256)
+    hipLaunchKernelGGL(mt_seq_ln_bwd_kernel<1>, grid, block, 0, stream, slots, ids, step, mt_step_base_tls);
+  else
+    hipLaunchKernelGGL(mt_seq_ln_bwd_kernel<2>, grid, block, 0, stream, slots, ids, step, mt_step_base_tls);
+  return (int)hipGetLastError();
 }
 
 // Sums the per-workgroup partial records of every LayerNorm of every slot in record order.  Grid (2 * layers, slots).
@@ -306,6 +383,15 @@ __global__ __launch_bounds__(SQ_THREADS) void mt_seq_ln_reduce_kernel(MtLnTables
     if (k < d) a.gw[k] = acc;
     else a.gb[k - d] = acc;
   }
+}
+
+// One LayerNorm table (engines that reduce layer by layer).
+extern "C" int mt_seq_ln_reduce_launch(const MtLnSlot* slots, const int32_t* ids, int n_active, int step, hipStream_t stream) {
+  if (n_active <= 0) return 0;
+  MtLnTables tabs = {};
+  tabs.t[0] = slots;
+  hipLaunchKernelGGL(mt_seq_ln_reduce_kernel, dim3(1, n_active), dim3(SQ_THREADS), 0, stream, tabs, ids, step, mt_step_base_tls);
+  return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ head + loss
@@ -413,20 +499,16 @@ static int seq_check(const MtSeqPlan* p) {
 #define SQ_TRY(call) do { int rc_ = (call); if (rc_ != 0) return rc_; } while (0)
 
 static int seq_forward(const MtSeqPlan* p, int step, int arow0, int rows, int nb, int train, hipStream_t stream) {
-  const dim3 block(SQ_THREADS);
-  const int max_m = rows > 0 ? rows : p->max_m;
   SQ_TRY(seq_fwd(p->in_proj, step, arow0, rows, stream));
   for (int l = 0; l < p->n_layers; ++l) {
     SQ_TRY(seq_fwd(p->qkv[l], step, 0, rows, stream));
     SQ_TRY(mt_attn_fwd_grouped_launch(p->attn[l], p->ids, p->n_active, nb > 0 ? nb * (p->max_bh / p->max_b) : p->max_bh,
                                       p->S, p->wide, step, nb, train, stream));
     SQ_TRY(seq_fwd(p->outp[l], step, 0, rows, stream));
-    hipLaunchKernelGGL(mt_seq_ln_fwd_kernel, dim3((max_m + 4 * SQ_LN_ROWS - 1) / (4 * SQ_LN_ROWS), p->n_active), block, 0,
-                       stream, p->ln1[l], p->ids, step, rows, train, mt_step_base_tls);
+    SQ_TRY(mt_seq_ln_fwd_launch(p->ln1[l], p->ids, p->n_active, p->max_m, 256, step, rows, train, stream));
     SQ_TRY(seq_fwd(p->ff1[l], step, 0, rows, stream));
     SQ_TRY(seq_fwd(p->ff2[l], step, 0, rows, stream));
-    hipLaunchKernelGGL(mt_seq_ln_fwd_kernel, dim3((max_m + 4 * SQ_LN_ROWS - 1) / (4 * SQ_LN_ROWS), p->n_active), block, 0,
-                       stream, p->ln2[l], p->ids, step, rows, train, mt_step_base_tls);
+    SQ_TRY(mt_seq_ln_fwd_launch(p->ln2[l], p->ids, p->n_active, p->max_m, 256, step, rows, train, stream));
   }
   return (int)hipGetLastError();
 }
@@ -442,7 +524,6 @@ extern "C" int mt_seq_train_steps(const MtSeqPlan* p, int step0, int nsteps, hip
   if (ok <= 0) return ok;
   if (!p->gather || !p->X || !p->Y || !p->opt || !p->P || !p->G || !p->M || !p->V) return -13;
   const dim3 block(SQ_THREADS);
-  const int ln_blocks = (p->max_m + 4 * SQ_LNB_ROWS - 1) / (4 * SQ_LNB_ROWS);
   const int zero_blocks = (p->max_m + SQ_ZERO_ROWS - 1) / SQ_ZERO_ROWS;
   MtLnTables tabs;
   for (int l = 0; l < MT_SEQ_MAX_LAYERS; ++l) {
@@ -456,12 +537,10 @@ extern "C" int mt_seq_train_steps(const MtSeqPlan* p, int step0, int nsteps, hip
     hipLaunchKernelGGL(mt_seq_head_kernel, dim3(1 + zero_blocks, p->n_active), block, 0, stream, p->head, p->ids, p->S, step,
                        mt_step_base_tls);
     for (int l = p->n_layers - 1; l >= 0; --l) {
-      hipLaunchKernelGGL(mt_seq_ln_bwd_kernel, dim3(ln_blocks, p->n_active), block, 0, stream, p->ln2[l], p->ids, step,
-                         mt_step_base_tls);
+      SQ_TRY(mt_seq_ln_bwd_launch(p->ln2[l], p->ids, p->n_active, p->max_m, 256, step, stream));
       SQ_TRY(seq_dgrad(p->d_ff2[l], step, stream));
       SQ_TRY(seq_dgrad(p->d_ff1[l], step, stream));
-      hipLaunchKernelGGL(mt_seq_ln_bwd_kernel, dim3(ln_blocks, p->n_active), block, 0, stream, p->ln1[l], p->ids, step,
-                         mt_step_base_tls);
+      SQ_TRY(mt_seq_ln_bwd_launch(p->ln1[l], p->ids, p->n_active, p->max_m, 256, step, stream));
       SQ_TRY(seq_dgrad(p->d_out[l], step, stream));
       SQ_TRY(mt_attn_bwd_grouped_launch(p->attn[l], p->ids, p->n_active, p->max_bh, p->S, p->wide, step, stream));
       SQ_TRY(seq_dgrad(p->d_qkv[l], step, stream));

@@ -90,14 +90,25 @@ class SeqPlan(C.Structure):
                 ("slot_stride", C.c_size_t), ("gsplit_stride", C.c_size_t), ("opt", c_void_p), ("partials", c_void_p)]
 
 
-ATTN_DTYPE = np.dtype([("qkv", "<u8"), ("o", "<u8"), ("stat", "<u8"), ("d_o", "<u8"), ("dqkv", "<u8"), ("seed", "<u8"),
-                       ("B", "<i4"), ("H", "<i4"), ("dk", "<i4"), ("active_steps", "<i4"),
-                       ("scale", "<f4"), ("keep_scale", "<f4"), ("thresh", "<u4"), ("site", "<i4")], align=True)
+ATTN_DTYPE = np.dtype([("q", "<u8"), ("k", "<u8"), ("v", "<u8"), ("o", "<u8"), ("stat", "<u8"), ("d_o", "<u8"),
+                       ("dq", "<u8"), ("dk_", "<u8"), ("dv_", "<u8"), ("seed", "<u8"),
+                       ("B", "<i4"), ("H", "<i4"), ("dk", "<i4"), ("dv", "<i4"),
+                       ("ldq", "<i4"), ("ldv", "<i4"), ("ldo", "<i4"), ("kind", "<i4"),
+                       ("active_steps", "<i4"), ("site", "<i4"),
+                       ("scale", "<f4"), ("keep_scale", "<f4"), ("thresh", "<u4"), ("pad", "<i4")], align=True)
+
+
+def attn_slot(q: int, k: int, v: int, o: int, stat: int, d_o: int, dq: int, dk_: int, dv_: int, seed: int, B: int, H: int,
+              dk: int, dv: int, ldq: int, ldv: int, ldo: int, kind: int, steps: int, site: int, scale: float, keep: float,
+              thresh: int) -> tuple:
+    """One ``MtAttnSlot`` record (csrc/attention.hip)."""
+    return (q, k, v, o, stat, d_o, dq, dk_, dv_, seed, B, H, dk, dv, ldq, ldv, ldo, kind, steps, site, scale, keep, thresh, 0)
 LN_DTYPE = np.dtype([("x", "<u8"), ("res", "<u8"), ("w", "<u8"), ("b", "<u8"), ("y", "<u8"), ("z", "<u8"),
                      ("stats", "<u8"), ("dy", "<u8"), ("dx", "<u8"), ("dres", "<u8"), ("part", "<u8"), ("gw", "<u8"),
                      ("gb", "<u8"), ("seed", "<u8"),
                      ("M", "<i4"), ("d", "<i4"), ("active_steps", "<i4"), ("site", "<i4"),
-                     ("keep_scale", "<f4"), ("eps", "<f4"), ("thresh", "<u4"), ("pad", "<i4")], align=True)
+                     ("keep_scale", "<f4"), ("eps", "<f4"), ("thresh", "<u4"), ("S", "<i4"),
+                     ("sd_thresh", "<u4"), ("sd_scale", "<f4"), ("sd_site", "<i4"), ("pad", "<i4")], align=True)
 SEQ_HEAD_DTYPE = np.dtype([("H", "<u8"), ("dH", "<u8"), ("w", "<u8"), ("b", "<u8"), ("gw", "<u8"), ("gb", "<u8"),
                            ("y", "<u8"), ("loss_acc", "<u8"), ("metrics", "<u8"),
                            ("B", "<i4"), ("d", "<i4"), ("loss_type", "<i4"), ("active_steps", "<i4")], align=True)
@@ -663,15 +674,17 @@ class SeqPackEngine(PackEngine):
                 g_ff2[slot] = grp(A(f"F1_{l}"), P(pre + "linear2.weight"), A("T"), P(pre + "linear2.bias"), 0,
                                   m, d, 4 * d, 4 * d, 4 * d, d, 0, st)
                 sh_ff2.append((slot, m, d, 4))
-                attn[slot] = (A(f"QKV{l}"), A(f"O{l}"), A(f"astat{l}"), A("dO"), A(f"dQKV{l}"), i["seed"], i["B"], sp.heads,
-                              sp.dk, st, 1.0 / math.sqrt(sp.dk), i["keep"], i["thresh"], 4 * l)
+                qkv, dqkv = A(f"QKV{l}"), A(f"dQKV{l}")
+                attn[slot] = attn_slot(qkv, qkv + 4 * d, qkv + 8 * d, A(f"O{l}"), A(f"astat{l}"), A("dO"), dqkv, dqkv + 4 * d,
+                                       dqkv + 8 * d, i["seed"], i["B"], sp.heads, sp.dk, sp.dk, 3 * d, 3 * d, d, 0, st, 4 * l,
+                                       1.0 / math.sqrt(sp.dk), i["keep"], i["thresh"])
                 ln1[slot] = (A("T"), h_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), A(f"H1_{l}"), A(f"Z1_{l}"),
                              A(f"st1_{l}"), A("dH"), A(f"dB1_{l}"), A("dR"), A(f"part1_{l}"), G(pre + "norm1.weight"),
-                             G(pre + "norm1.bias"), i["seed"], m, d, st, 4 * l + 1, i["keep"], 1e-5, i["thresh"], 0)
+                             G(pre + "norm1.bias"), i["seed"], m, d, st, 4 * l + 1, i["keep"], 1e-5, i["thresh"], 0, 0, 1.0, 0, 0)
                 ln2[slot] = (A("T"), A(f"H1_{l}"), P(pre + "norm2.weight"), P(pre + "norm2.bias"), A(f"H2_{l}"),
                              A(f"Z2_{l}"), A(f"st2_{l}"), A("dH"), A(f"dB2_{l}"), A("dR"), A(f"part2_{l}"),
                              G(pre + "norm2.weight"), G(pre + "norm2.bias"), i["seed"], m, d, st, 4 * l + 3, i["keep"],
-                             1e-5, i["thresh"], 0)
+                             1e-5, i["thresh"], 0, 0, 1.0, 0, 0)
                 if eval_mode:
                     continue
                 dB2, dF1, dB1, dQKV = A(f"dB2_{l}"), A(f"dF1_{l}"), A(f"dB1_{l}"), A(f"dQKV{l}")
