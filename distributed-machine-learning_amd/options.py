@@ -38,6 +38,7 @@ class EngineOptions:
     chain_debug: bool = False         # print every chain's composition when a plan is built
     # ---- packs of sequence-model trials on grouped launches (packed/engine_seq.py)
     seq_engine: bool = True           # False keeps sample-Transformer packs on one captured step per trial
+    xf_engine: bool = True            # False keeps packs of the configurable Transformer on one captured step per trial
     seq_prep_threads: int = 2         # host threads drawing the next trials' initial weights
     seq_ksplits: int = 2              # weight-gradient slabs over the token rows
     seq_chain_rule: str = "32:2"

@@ -34,12 +34,13 @@ import numpy as np
 import torch
 
 from .engine import PackEngine
-from .engine_hip import N_XCD, balanced_tiles
+from .engine_hip import N_XCD
 from .engine_seq import ATTN_DTYPE, LN_DTYPE, attn_slot, ceil4, ceil8
 from .permutation import half_bits, mix32, round_keys
 from .trainable import PackedTrainable
 from ..models.mlp import MLPTrialSpec
 from ..ops import lib as L
+from ..options import OPTIONS
 from ..train.losses import LOSS_CODES
 from ..train.optim import OPT_CODES
 
@@ -47,6 +48,7 @@ MAX_LAYERS = 16
 HEAD_DIMS = (128, 64, 32, 16)          # fc1 .. fc4 outputs; fc5 maps the last to the prediction
 PE_SITE = 4000                         # dropout site of the positional encoding (layer sites are 8 l + k)
 FUSED_MAX_HEAD = 64                    # widest head (query / key or value) the fused attention kernels take
+MAX_CHAINS = 4                         # concurrent training programs, one HIP stream each
 
 c_void_p, c_int32 = C.c_void_p, C.c_int32
 
@@ -326,6 +328,41 @@ def _uniform_tiles(n_groups: int, ti: int, tj: int) -> np.ndarray:
     return out.reshape(-1)
 
 
+def spread_tiles(shapes: List[Tuple[int, int, int]]) -> np.ndarray:
+    """Tile list of a launch with few, very unequal groups (a pack of a dozen Transformer trials whose token counts and
+    widths differ by orders of magnitude): ``shapes`` = (group, row tiles, column tiles).  Workgroup ids go round-robin
+    to the 8 XCDs, each with its own L2; here every group is cut into bands of row tiles and band r goes to XCD
+    (start + r) % 8, ``start`` being the lightest XCD when the group is placed (largest groups first).  All XCDs work on a
+    large group at once -- its activation rows are private to a band, its weights (the operand every band shares) are
+    small enough to sit in each L2 -- where one-group-per-XCD placement would leave seven eighths of the chip idle
+    behind the largest trial."""
+    load = np.zeros(N_XCD, dtype=np.int64)
+    per_bucket: List[List[np.ndarray]] = [[] for _ in range(N_XCD)]
+    for g, ti_n, tj_n in sorted(shapes, key=lambda x: (-x[1] * x[2], x[0])):
+        if ti_n <= 0 or tj_n <= 0:
+            continue
+        start = int(np.argmin(load))
+        ti = np.repeat(np.arange(ti_n, dtype=np.int64), tj_n)
+        tj = np.tile(np.arange(tj_n, dtype=np.int64), ti_n)
+        bucket = (start + ti) % N_XCD
+        for b in range(N_XCD):
+            sel = bucket == b
+            k = int(sel.sum())
+            if k:
+                rec = np.zeros(k, dtype=L.TILE_DTYPE)
+                rec["group"], rec["ti"], rec["tj"] = g, ti[sel], tj[sel]
+                per_bucket[b].append(rec)
+                load[b] += k
+    depth = int(load.max()) if len(shapes) else 0
+    out = np.zeros((depth, N_XCD), dtype=L.TILE_DTYPE)
+    out["group"] = -1
+    for b in range(N_XCD):
+        if per_bucket[b]:
+            col = np.concatenate(per_bucket[b])
+            out[:len(col), b] = col
+    return out.reshape(-1)
+
+
 class XfPackEngine(PackEngine):
     name = "xf"
     move_cost_s = 0.01
@@ -386,14 +423,14 @@ class XfPackEngine(PackEngine):
         self._tables: Dict[str, Any] = {}
         self._stage: Optional[torch.Tensor] = None
         self._dirty = True
-        self._prog: Dict[str, Tuple[Any, int]] = {}
-        self._keep: List[Any] = []
+        self._chains: List[Dict[str, Any]] = []
+        self._eval: Dict[str, Any] = {}
+        self._streams: List[torch.cuda.Stream] = []
         self._train_loss: Dict[int, float] = {}
         self._loss_pending = False
         self._round_steps: Dict[int, int] = {}
         self._table = torch.zeros(T + 1, 6, device=dev, dtype=torch.float64)
         self._stamps = torch.zeros(2, device=dev, dtype=torch.int64)
-        self._optim = XfOptim()
         self.prepared_total = 0
 
     # ------------------------------------------------------------------ slot management
@@ -539,12 +576,14 @@ class XfPackEngine(PackEngine):
         hi = int(mix32(np.uint32(lo ^ 0x9E3779B9)))
         return lo, hi
 
-    def _compile(self, eval_mode: bool) -> Tuple[Any, int]:
-        """The pack's program for training steps (``eval_mode`` False) or for one validation chunk."""
+    def _compile(self, eval_mode: bool, ids: Optional[List[int]] = None, tag: Optional[str] = None) -> Dict[str, Any]:
+        """The program of the slots ``ids`` (default: all) for training steps (``eval_mode`` False) or for one validation
+        chunk."""
         T, S, fp = self.capacity, self.S, self.fpad
-        tag = "e" if eval_mode else "t"
+        tag = tag or ("e" if eval_mode else "t")
         when = 2 if eval_mode else 1
-        ids = sorted(self.slots)
+        ids = sorted(self.slots) if ids is None else sorted(ids)
+        out: Dict[str, Any] = {"ids": ids}
         members = [(slot, self.slots[slot]) for slot in ids]
         ids_ptr = self._upload(tag + "ids", np.array(ids, dtype=np.int32))
         pP, pG = self.P.data_ptr(), self.G.data_ptr()
@@ -589,17 +628,23 @@ class XfPackEngine(PackEngine):
                               keep=1.0 / (1.0 - p) if p > 0 else 1.0, P=Pf, G=Gf,
                               A=lambda key, s=s, base=base: base + s.arena.off[key] * 4, seed=seeds + slot * 8)
 
-        def gemm(mode: int, recs: List[Tuple[int, tuple, int, int, int]], flags: int = 0, a_shared: int = 0, rows_kind: int = 0,
-                 edge: int = 64) -> None:
-            """One grouped GEMM launch: ``recs`` = (group index or -1 for 'next', record, out rows, out cols, weight)."""
+        def gemm(mode: int, recs: List[Tuple[int, tuple, int, int, int]], flags: int = 0, a_shared: int = 0,
+                 rows_kind: int = 0) -> None:
+            """One grouped GEMM launch: ``recs`` = (unused, record, out rows, out cols, weight).  The tile edge follows the
+            launch's size like the MLP engine's: 128 when that still leaves thousands of tiles, 32 when 64-tiles would not
+            fill the chip."""
             if not recs:
                 return
             groups = np.zeros(len(recs), dtype=L.GEMM_GROUP_DTYPE)
-            shapes = []
             for k, (_, rec, r, c, w) in enumerate(recs):
                 groups[k] = rec
-                shapes.append((k, (r + edge - 1) // edge, (c + edge - 1) // edge, w))
-            tiles = balanced_tiles(shapes, 1)
+            count = lambda e: sum(((r + e - 1) // e) * ((c + e - 1) // e) for _, _, r, c, _ in recs)      # noqa: E731
+            edge = 128 if count(128) >= OPTIONS.f32_small_tiles else 64
+            if edge == 64 and count(64) < OPTIONS.f32_tiny_tiles:
+                edge = 32
+            if mode == 2:
+                edge = min(edge, 64)        # weight gradients: few tiles, each as long as the token count
+            tiles = spread_tiles([(k, (r + edge - 1) // edge, (c + edge - 1) // edge) for k, (_, _, r, c, _) in enumerate(recs)])
             nm = name()
             op(K_GEMM, len(tiles), self._upload(nm + "g", groups), self._upload(nm + "t", tiles), a=mode, b=edge, c=a_shared,
                d=rows_kind, flags=flags)
@@ -622,8 +667,8 @@ class XfPackEngine(PackEngine):
         # ---- batch, input projection, positions
         if not eval_mode:
             gat = np.zeros(T, dtype=L.GATHER_DTYPE)       # keys and step counts are per epoch: refreshed by _epoch_tables
-            self._gather_name = name()
-            op(K_GATHER, len(ids), self._upload(self._gather_name, gat), ids_ptr, a=max_b, b=self.row_len,
+            out["gather"] = name()
+            op(K_GATHER, len(ids), self._upload(out["gather"], gat), ids_ptr, a=max_b, b=self.row_len,
                c=half_bits(self.n_train), d=self.n_train, p2=self.Xtr.data_ptr(), p3=self.ytr.data_ptr())
         recs = []
         for slot, s in members:
@@ -685,7 +730,7 @@ class XfPackEngine(PackEngine):
                 op(K_ATTN_FWD, at_n, at_ptr, ids_ptr, a=max_bh, b=S, c=wide, d=max(s.spec.heads for _, s in fused))
             # ... explicit score matrices for wider ones
             wide_slots = [(slot, s) for slot, s in act if not s.spec.fused]
-            comp = self._score_products(wide_slots, info, l, name, op, ids_ptr, site) if wide_slots else None
+            comp = self._score_products(wide_slots, info, l, name, op, ids_ptr, site, len(ids)) if wide_slots else None
             if comp is not None:
                 comp["forward"]()
 
@@ -821,11 +866,15 @@ class XfPackEngine(PackEngine):
                           self.loss_acc.data_ptr() + slot * 4, self.metrics.data_ptr() + slot * 24, i["B"], HEAD_DIMS[-1],
                           HEAD_DIMS[-1], LOSS_CODES[s.spec.opt.loss_function], i["steps"], 0)
         head_ptr = self._upload(name(), head)
+        # the head kernels' partial records are laid out by (slot, row chunk of THIS launch): programs that run next to
+        # each other on different streams must not share them
+        out["scratch"] = self._tables.setdefault(tag + "scratch", torch.zeros_like(self.head_scratch))
+        scratch_ptr = out["scratch"].data_ptr()
         if eval_mode:
-            op(K_HEAD_EVAL, len(ids), head_ptr, ids_ptr, a=self.eval_chunk, b=HEAD_DIMS[-1], p2=self.head_scratch.data_ptr())
-            return self._finish(ops, tag)
+            op(K_HEAD_EVAL, len(ids), head_ptr, ids_ptr, a=self.eval_chunk, b=HEAD_DIMS[-1], p2=scratch_ptr)
+            return self._finish(ops, out)
 
-        op(K_HEAD_LOSS, len(ids), head_ptr, ids_ptr, a=max_b, b=HEAD_DIMS[-1], p2=self.head_scratch.data_ptr())
+        op(K_HEAD_LOSS, len(ids), head_ptr, ids_ptr, a=max_b, b=HEAD_DIMS[-1], p2=scratch_ptr)
         ptr, n = table(FILL_DTYPE, lambda slot, s, i: (i["A"]("dH"), i["m"] * s.spec.d, i["steps"], 0))
         op(K_FILL, n, ptr, ids_ptr, a=max_m * max_d)
         wg = []
@@ -860,17 +909,17 @@ class XfPackEngine(PackEngine):
                     s.spec.layers, i["steps"], 0)
         ptr, n = table(SUM_DTYPE, sum_rec)
         op(K_SUM, n, ptr, ids_ptr, a=max((s.layout.layer_span for _, s in members if s.spec.shared), default=0))
-        q = self._optim
+        q = out["optim"] = XfOptim()
         q.P, q.G, q.M, q.V = self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr()
         q.partials, q.slot_stride = self.partials.data_ptr(), self.stride
         q.max_params = max(s.layout.total for _, s in members)
         q.max_blocks = self.max_blocks
         q.use_clip = int(any(s.spec.opt.gradient_clipping > 0 for _, s in members))
-        self._opt_name = name()
-        op(K_OPTIM, len(ids), self._upload(self._opt_name, np.zeros(T, dtype=L.OPT_DTYPE)), ids_ptr, p2=C.addressof(q))
-        return self._finish(ops, tag)
+        out["opt"] = name()
+        op(K_OPTIM, len(ids), self._upload(out["opt"], np.zeros(T, dtype=L.OPT_DTYPE)), ids_ptr, p2=C.addressof(q))
+        return self._finish(ops, out)
 
-    def _score_products(self, wide_slots, info, l, name, op, ids_ptr, site) -> Dict[str, Callable[[], None]]:
+    def _score_products(self, wide_slots, info, l, name, op, ids_ptr, site, n_ids) -> Dict[str, Callable[[], None]]:
         """Attention of the slots whose heads are too wide for the fused kernels, as grouped GEMMs per (sample, head):
         scores = q k^T, a row kernel (scale, softmax or relu-normalise, dropout), o = p v; and backwards dP = dO v^T,
         dV = p^T dO, the row kernel's gradient, dQ = dS k, dK = dS^T q.  All exact f32."""
@@ -944,7 +993,7 @@ class XfPackEngine(PackEngine):
         row_ptr = self._upload(name(), rows)
         max_bh = max(info[slot]["B"] * s.spec.heads for slot, s in wide_slots)
         max_h = max(s.spec.heads for _, s in wide_slots)
-        n = len(self.slots)              # the kernels walk every resident slot; the others' records are empty
+        n = n_ids                        # the kernels walk every slot of the program; the others' records are empty
 
         def forward() -> None:
             launch("qk", 0)
@@ -960,17 +1009,29 @@ class XfPackEngine(PackEngine):
 
         return {"forward": forward, "backward": backward}
 
-    def _finish(self, ops: List[XfOp], tag: str) -> Tuple[Any, int]:
-        arr = (XfOp * len(ops))(*ops)
-        self._keep.append(arr)
-        return arr, len(ops)
+    def _finish(self, ops: List[XfOp], out: Dict[str, Any]) -> Dict[str, Any]:
+        out["prog"], out["n"] = (XfOp * len(ops))(*ops), len(ops)
+        return out
 
     def _refresh(self) -> None:
-        if self._dirty or "t" not in self._prog:
-            self._keep = []
-            self._prog["t"] = self._compile(False)
-            self._prog["e"] = self._compile(True)
-            self._dirty = False
+        """Programs of the current pack: one validation program over all slots, and one training program per CHAIN.  A
+        chain holds the slots of one batch size -- they take the same number of steps per epoch, so no launch of a chain
+        ever carries finished slots -- and runs on a HIP stream of its own, next to the others (at most ``MAX_CHAINS``;
+        with more batch sizes than that the rarest ones share a chain)."""
+        if not (self._dirty or not self._chains):
+            return
+        by_batch: Dict[int, List[int]] = {}
+        for slot, s in self.slots.items():
+            by_batch.setdefault(min(s.spec.opt.batch_size, self.n_train), []).append(slot)
+        groups = sorted(by_batch.values(), key=lambda g: (-len(g), g[0]))
+        while len(groups) > MAX_CHAINS:
+            groups[-2] = groups[-2] + groups[-1]
+            groups.pop()
+        self._chains = [self._compile(False, g, f"t{c}_") for c, g in enumerate(groups)]
+        while len(self._streams) < len(self._chains) - 1:
+            self._streams.append(torch.cuda.Stream(self.device))
+        self._eval = self._compile(True)
+        self._dirty = False
 
     def _epoch_tables(self) -> int:
         T = self.capacity
@@ -989,8 +1050,9 @@ class XfPackEngine(PackEngine):
             opt[slot] = (sp.learning_rate, sp.beta1, sp.beta2, sp.eps, sp.weight_decay, sp.momentum, sp.gradient_clipping,
                          OPT_CODES[sp.optimizer], sp.warmup_steps, sp.total_steps, s.layout.total, steps, s.step, 0, 0, 0)
             seeds[slot] = self._slot_seed(s)
-        self._upload(self._gather_name, gat)
-        self._upload(self._opt_name, opt)
+        for ch in self._chains:          # the per-epoch tables are indexed by slot: every chain gets the same ones
+            self._upload(ch["gather"], gat)
+            self._upload(ch["opt"], opt)
         self.seeds.copy_(torch.from_numpy(seeds.view(np.int32)))
         return max_steps
 
@@ -999,11 +1061,22 @@ class XfPackEngine(PackEngine):
         if not self.slots:
             return
         self._refresh()
-        steps = self._epoch_tables()
+        self._epoch_tables()
         self.loss_acc.zero_()
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        prog, n = self._prog["t"]
-        L.check(self.lib.mt_xf_run(C.cast(prog, c_void_p), n, 0, steps, 1, 0, 0, self.S, stream), "mt_xf_run")
+        main = torch.cuda.current_stream(self.device)
+        stream = main.cuda_stream
+        lanes = [main] + self._streams[:len(self._chains) - 1]
+        for st in lanes[1:]:
+            st.wait_stream(main)             # tables, seeds and zeroed accumulators were issued on the main stream
+        steps = [max(self.n_train // min(self.slots[k].spec.opt.batch_size, self.n_train) for k in ch["ids"])
+                 for ch in self._chains]
+        for step in range(max(steps)):       # interleaved step by step: no chain gets a head start
+            for ch, st, n_steps in zip(self._chains, lanes, steps):
+                if step < n_steps:
+                    L.check(self.lib.mt_xf_run(C.cast(ch["prog"], c_void_p), ch["n"], step, 1, 1, 0, 0, self.S, st.cuda_stream),
+                            "mt_xf_run")
+        for st in lanes[1:]:
+            main.wait_stream(st)
         L.check(self.lib.mt_stamp_launch(self._stamps[1:].data_ptr(), stream), "mt_stamp_launch")
         self._round_steps = {}
         for slot, s in self.slots.items():
@@ -1029,10 +1102,11 @@ class XfPackEngine(PackEngine):
         self._refresh()
         self.metrics.zero_()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        prog, n = self._prog["e"]
+        ev = self._eval
         for c0 in range(0, self.n_val, self.eval_chunk):
             nb = min(self.eval_chunk, self.n_val - c0)
-            L.check(self.lib.mt_xf_run(C.cast(prog, c_void_p), n, 0, 1, 0, nb, c0, self.S, stream), "mt_xf_run (evaluation)")
+            L.check(self.lib.mt_xf_run(C.cast(ev["prog"], c_void_p), ev["n"], 0, 1, 0, nb, c0, self.S, stream),
+                    "mt_xf_run (evaluation)")
 
     def device_table(self) -> torch.Tensor:
         T = self.capacity

@@ -57,8 +57,16 @@ def make_engine(trainable: PackedTrainable, device: torch.device, capacity: Opti
                 from . import engine_seq
                 if engine_seq.supports(trainable) is None:
                     kind = "seq"
+            if trainable.model == "transformer" and OPTIONS.xf_engine:
+                # the configurable Transformer family: one program of grouped launches for the whole pack
+                from . import engine_xf
+                if engine_xf.supports(trainable) is None:
+                    kind = "xf"
         else:
             kind = "torch"
+    if kind == "xf":
+        from .engine_xf import XfPackEngine
+        return XfPackEngine(trainable, device, capacity, seed)
     if kind == "seq":
         from .engine_seq import SeqPackEngine
         return SeqPackEngine(trainable, device, capacity, seed)
@@ -152,17 +160,30 @@ class PackedExecutor(Executor):
         self.runner = runner
 
     def adapt_to_space(self, config: Optional[Dict]) -> None:
-        """Called by ``run()`` with the search space before the first trial starts.  The grouped-launch sequence engine is
-        chosen from the trainable alone, but whether it can hold a trial depends on the trial's d_model / num_heads /
-        num_layers / batch_size: every combination the space can produce is checked here, the engine's limits are set from
-        them, and a space with a combination outside the grouped kernels' envelope (or with a non-enumerable domain on
-        one of those keys) gets the one-graph-per-slot engine instead, which takes any shape."""
-        if self.engine.name != "seq" or self.t.engine != "auto" or self._place or not config:
+        """Called by ``run()`` with the search space before the first trial starts.  The grouped-launch engines (``seq``
+        for the sample Transformer, ``xf`` for the configurable one) are chosen from the trainable alone, but whether they
+        can hold a trial depends on the trial's shape: every combination of the shape keys the space can produce is
+        checked here, the engine's limits are set from them, and a space with a combination outside the grouped kernels'
+        envelope (or with a non-enumerable domain on one of those keys) gets the one-graph-per-slot engine instead, which
+        takes any shape."""
+        if self.engine.name not in ("seq", "xf") or self.t.engine != "auto" or self._place or not config:
             return
         import itertools
-        from . import engine_seq
         from ..tune.space import Categorical, Domain
-        keys = ("d_model", "num_heads", "num_layers", "batch_size")
+        if self.engine.name == "seq":
+            from . import engine_seq as mod
+            keys = ("d_model", "num_heads", "num_layers", "batch_size")
+            limits = (("d_model", "max_d_model"), ("num_heads", "max_heads"), ("num_layers", "max_layers"),
+                      ("batch_size", "max_batch"))
+            need = {"d_model", "num_heads"}
+            base = {"num_layers": 1}
+        else:
+            from . import engine_xf as mod
+            keys = ("d_model", "num_heads", "num_encoder_layers", "batch_size", "key_dim_scaling", "attention_type",
+                    "attn_kernel_size")
+            limits = (("d_model", "max_d_model"), ("num_encoder_layers", "max_layers"), ("batch_size", "max_batch"))
+            need = {"d_model"}
+            base = {}
         options: List[List[Any]] = []
         for k in keys:
             v = config.get(k, self.t.model_kwargs.get(k))
@@ -177,16 +198,23 @@ class PackedExecutor(Executor):
         combos = [dict(zip(keys, c)) for c in itertools.product(*options)] if options else []
         for c in combos:
             c = {k: v for k, v in c.items() if v is not None}
-            why = engine_seq.supports(self.t, {**{"num_layers": 1}, **c}) if {"d_model", "num_heads"} <= set(c) else None
+            why = mod.supports(self.t, {**base, **c}) if need <= set(c) else None
             if why:
                 break
         if why is None and combos:
             kw = dict(self.t.model_kwargs)
             have = lambda k: [c[k] for c in combos if c.get(k) is not None]      # noqa: E731
-            for k, limit in (("d_model", "max_d_model"), ("num_heads", "max_heads"), ("num_layers", "max_layers"),
-                             ("batch_size", "max_batch")):
+            for k, limit in limits:
                 if have(k):
                     kw[limit] = max(int(kw.get(limit, 0) or 0), max(int(x) for x in have(k)))
+            if self.engine.name == "xf":
+                ff = config.get("dim_feedforward", self.t.model_kwargs.get("dim_feedforward"))
+                if isinstance(ff, Categorical):
+                    kw["max_dim_feedforward"] = max(int(x) for x in ff.categories)
+                elif isinstance(ff, (int, float)):
+                    kw["max_dim_feedforward"] = int(ff)
+                else:       # a multiple of d_model drawn per trial (the reference's space: 2, 3 or 4 times): the kernels' limit
+                    kw["max_dim_feedforward"] = min(2048, 4 * int(kw.get("max_d_model", 512)))
             if kw != self.t.model_kwargs:
                 self.t.model_kwargs = kw
                 self.engine.close()

@@ -196,3 +196,39 @@ def test_export_load_round_trip_and_clone():
     for k in x["model"]:
         assert torch.equal(x["model"][k], y["model"][k]) and torch.equal(x["optimizer"]["exp_avg"][k], y["optimizer"]["exp_avg"][k])
     assert a.slots[1].spec.opt.learning_rate == 1e-4 and a.slots[1].trial_index == 51
+
+
+def test_search_through_the_executor_uses_the_program_engine_and_adapts_its_limits():
+    import mitune
+    from mitune import tune
+    from mitune.schedulers import ASHAScheduler
+    tr = _trainable(engine="auto", capacity=6, model_kwargs={"max_d_model": 64, "max_layers": 2, "max_dim_feedforward": 128,
+                                                             "max_batch": 16})
+    space = dict(BASE, d_model=tune.choice([64, 128, 192]), num_heads=tune.choice([2, 4, 32]),
+                 num_encoder_layers=tune.choice([1, 2, 4]), batch_size=tune.choice([16, 32]),
+                 dim_feedforward=tune.sample_from(lambda spec: spec.config.d_model * tune.choice([2, 3])),
+                 attention_type=tune.choice(["scaled_dot_product", "linear_attention", "multi_head_attention"]),
+                 key_dim_scaling=tune.choice([1.0, 0.5, 0.25]), attn_kernel_size=tune.choice([3, 5, 7]),
+                 depthwise_separable_conv=tune.choice([True, False]), shared_weights=tune.choice([True, False]),
+                 dropout=tune.uniform(0.0, 0.3), stochastic_depth_rate=tune.uniform(0.0, 0.2),
+                 learning_rate=tune.loguniform(1e-4, 1e-2), loss_function=tune.choice(["mse", "mae", "huber", "mape"]),
+                 optimizer=tune.choice(["adam", "adamw", "sgd", "rmsprop"]), gradient_clipping=tune.uniform(0.0, 1.0),
+                 warmup_steps=tune.choice([2, 8]), total_steps=tune.choice([50, 100]))
+    an = mitune.run(tr, config=space, num_samples=14, scheduler=ASHAScheduler(metric="validation_mape", mode="min", max_t=3),
+                    local_dir=None, verbose=0, seed=1, metric="validation_mape", mode="min", device=torch.device("cuda"))
+    assert an.stats["engine"] == "xf" and "engine_fallback" not in an.stats
+    assert len(an.trials) == 14 and all(t.status == "TERMINATED" for t in an.trials)
+    assert all(np.isfinite(t.last_result["validation_mape"]) for t in an.trials)
+    assert an.best_config is not None
+
+
+def test_a_space_outside_the_program_engine_runs_on_the_per_slot_engine():
+    import mitune
+    from mitune import tune
+    from mitune.schedulers import ASHAScheduler
+    tr = _trainable(engine="auto", capacity=3)
+    space = dict(BASE, d_model=tune.choice([64, 66]), num_heads=2, num_encoder_layers=1, dim_feedforward=128)     # 66 / 2 = 33-wide heads: fine; nq = 2*2*33+66 = 198: not a multiple of 4
+    an = mitune.run(tr, config=space, num_samples=3, scheduler=ASHAScheduler(metric="validation_mape", mode="min", max_t=2),
+                    local_dir=None, verbose=0, seed=1, metric="validation_mape", mode="min", device=torch.device("cuda"))
+    assert an.stats["engine"] == "graph" and "engine_fallback" in an.stats
+    assert all(np.isfinite(t.last_result["validation_mape"]) for t in an.trials)
