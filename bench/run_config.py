@@ -94,7 +94,7 @@ def config4(args):
             xc = torch.randn(c1 - c0, 256, generator=g, device=dev)
             y[c0:c1] = torch.tanh(xc @ w) + 0.1 * xc[:, 0] * xc[:, 1] + 0.05 * torch.randn(c1 - c0, generator=g, device=dev)
             X[c0:c1] = xc.to(dt)
-        n_val = max(1024, n_local // 50)
+        n_val = min(max(1024, n_local // 50), 262144)      # a quarter million held-out rows bound the cost of a report
         trainable = tune.with_parameters(dp_mlp_trainable, train=(X[n_val:], y[n_val:]), val=(X[:n_val], y[:n_val]), comm=comm,
                                          epochs=args.dp_epochs, seed=0)
         space = {"hidden_sizes": [args.width] * 3, "optimizer": "adamw", "dtype": dtype, "steps_per_epoch": args.dp_steps,
