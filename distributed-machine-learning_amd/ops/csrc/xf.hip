@@ -362,7 +362,8 @@ static inline unsigned xf_blocks(long n, int per) { return (unsigned)((n + per -
 //   GATHER      a = max batch, b = row_len, c = hb, d = n_rows;  p2 = X, p3 = Y
 //   GEMM        n = tiles, a = mode, b = tile edge, c = 1 if the A operand is the shared evaluation table (row offset and
 //               row count of the evaluation chunk apply), d = which row count an evaluation chunk overrides: 0 token rows,
-//               1 one row per SAMPLE (head layers), 2 none (per-head score products); flags = launch flags
+//               1 one row per SAMPLE (head layers), 2 none (per-head score products); flags = launch flags; p2 (mode 2) =
+//               floats between the partial results of two contraction splits
 //   PE_*        a = max rows, b = max d
 //   ATTN_*      a = max B * H, b = S, c = widest head, d = max H (evaluation: B * H of a chunk = nb * its own H, so the
 //               grid is sized nb * d)
@@ -393,8 +394,10 @@ extern "C" int mt_xf_run(const MtXfOp* ops, int n_ops, int step0, int nsteps, in
         case XF_GEMM: {
           const int over = (train || o.d == 2) ? 0 : (o.d == 1 ? nb : rows);
           const int arow0 = (!train && o.c) ? row0 * S : 0;
+          // weight gradients: groups split over the contraction say so themselves (MtGemmGroup.site = splits); p2 carries
+          // the distance in floats between two splits' partial results
           XF_TRY(mt_gemm_f32_launch(o.a, reinterpret_cast<const MtGemmGroup*>(o.p0), reinterpret_cast<const MtTile*>(o.p1), o.n,
-                                    step, o.flags, arow0, over, 1, 0, o.b, stream));
+                                    step, o.flags, arow0, over, 1, (size_t)o.p2, o.b, stream));
           break;
         }
         case XF_PE_FWD:

@@ -35,6 +35,7 @@ class EngineOptions:
     rowblock: str = "auto"            # exact-f32 row-block step: "auto" (chains of <= rowblock_max_blocks blocks), "1", "0"
     rowblock_max_blocks: int = 400
     rowblock_mt: int = 1              # 16-row tiles per row-block workgroup (2: at most 4 layers)
+    rowblock_big: bool = False        # "auto": chains past rowblock_max_blocks take the row-block step with 32-row blocks
     chain_debug: bool = False         # print every chain's composition when a plan is built
     # ---- packs of sequence-model trials on grouped launches (packed/engine_seq.py)
     seq_engine: bool = True           # False keeps sample-Transformer packs on one captured step per trial

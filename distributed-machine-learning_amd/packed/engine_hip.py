@@ -590,6 +590,9 @@ class HipPackEngine(PackEngine):
                 return 0
             blocks += (min(s.spec.batch_size, self.n_train) + ROWBLOCK_ROWS - 1) // ROWBLOCK_ROWS
         if OPTIONS.rowblock != "1" and blocks > OPTIONS.rowblock_max_blocks:
+            # big chains: 32-row blocks (half the weight bytes streamed per row) where the kernel has them, if asked for
+            if OPTIONS.rowblock_big and all(len(self.slots[k].layout.hidden) <= 4 for k in ids):
+                return 2
             return 0
         if OPTIONS.rowblock_mt == 2 and all(len(self.slots[k].layout.hidden) <= 4 for k in ids):
             return 2

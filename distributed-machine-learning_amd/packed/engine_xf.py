@@ -49,6 +49,7 @@ HEAD_DIMS = (128, 64, 32, 16)          # fc1 .. fc4 outputs; fc5 maps the last t
 PE_SITE = 4000                         # dropout site of the positional encoding (layer sites are 8 l + k)
 FUSED_MAX_HEAD = 64                    # widest head (query / key or value) the fused attention kernels take
 MAX_CHAINS = 4                         # concurrent training programs, one HIP stream each
+WGRAD_TARGET_TILES = 64                # weight gradients with fewer tiles than this split their contraction up to it
 
 c_void_p, c_int32 = C.c_void_p, C.c_int32
 
@@ -328,9 +329,10 @@ def _uniform_tiles(n_groups: int, ti: int, tj: int) -> np.ndarray:
     return out.reshape(-1)
 
 
-def spread_tiles(shapes: List[Tuple[int, int, int]]) -> np.ndarray:
+def spread_tiles(shapes: List[Tuple[int, ...]]) -> np.ndarray:
     """Tile list of a launch with few, very unequal groups (a pack of a dozen Transformer trials whose token counts and
-    widths differ by orders of magnitude): ``shapes`` = (group, row tiles, column tiles).  Workgroup ids go round-robin
+    widths differ by orders of magnitude): ``shapes`` = (group, row tiles, column tiles[, contraction splits: one entry
+    per split, index in the high byte of ``ti``]).  Workgroup ids go round-robin
     to the 8 XCDs, each with its own L2; here every group is cut into bands of row tiles and band r goes to XCD
     (start + r) % 8, ``start`` being the lightest XCD when the group is placed (largest groups first).  All XCDs work on a
     large group at once -- its activation rows are private to a band, its weights (the operand every band shares) are
@@ -338,13 +340,17 @@ def spread_tiles(shapes: List[Tuple[int, int, int]]) -> np.ndarray:
     behind the largest trial."""
     load = np.zeros(N_XCD, dtype=np.int64)
     per_bucket: List[List[np.ndarray]] = [[] for _ in range(N_XCD)]
-    for g, ti_n, tj_n in sorted(shapes, key=lambda x: (-x[1] * x[2], x[0])):
+    for shape in sorted(shapes, key=lambda x: (-x[1] * x[2], x[0])):
+        g, ti_n, tj_n = shape[:3]
+        splits = shape[3] if len(shape) > 3 else 1
         if ti_n <= 0 or tj_n <= 0:
             continue
         start = int(np.argmin(load))
-        ti = np.repeat(np.arange(ti_n, dtype=np.int64), tj_n)
-        tj = np.tile(np.arange(tj_n, dtype=np.int64), ti_n)
-        bucket = (start + ti) % N_XCD
+        ti = np.repeat(np.arange(ti_n, dtype=np.int64), tj_n * splits)
+        tj = np.tile(np.repeat(np.arange(tj_n, dtype=np.int64), splits), ti_n)
+        sp = np.tile(np.arange(splits, dtype=np.int64), ti_n * tj_n)
+        bucket = (start + ti + sp) % N_XCD if splits > 1 else (start + ti) % N_XCD
+        ti = ti | (sp << 8)
         for b in range(N_XCD):
             sel = bucket == b
             k = int(sel.sum())
@@ -632,22 +638,58 @@ class XfPackEngine(PackEngine):
                  rows_kind: int = 0) -> None:
             """One grouped GEMM launch: ``recs`` = (unused, record, out rows, out cols, weight).  The tile edge follows the
             launch's size like the MLP engine's: 128 when that still leaves thousands of tiles, 32 when 64-tiles would not
-            fill the chip."""
+            fill the chip.  Weight gradients (mode 2) of small layers are a handful of tiles as long as the trial's token
+            count: those groups split the contraction, every split writes its partial result to a scratch slab, and a sum
+            kernel adds the slabs in split order into the gradient (fixed order: bitwise repeatable)."""
             if not recs:
                 return
-            groups = np.zeros(len(recs), dtype=L.GEMM_GROUP_DTYPE)
-            for k, (_, rec, r, c, w) in enumerate(recs):
-                groups[k] = rec
             count = lambda e: sum(((r + e - 1) // e) * ((c + e - 1) // e) for _, _, r, c, _ in recs)      # noqa: E731
             edge = 128 if count(128) >= OPTIONS.f32_small_tiles else 64
             if edge == 64 and count(64) < OPTIONS.f32_tiny_tiles:
                 edge = 32
             if mode == 2:
                 edge = min(edge, 64)        # weight gradients: few tiles, each as long as the token count
-            tiles = spread_tiles([(k, (r + edge - 1) // edge, (c + edge - 1) // edge) for k, (_, _, r, c, _) in enumerate(recs)])
+            groups = np.zeros(len(recs), dtype=L.GEMM_GROUP_DTYPE)
+            shapes, sums, slab = [], [], 0
+            for k, (_, rec, r, c, w) in enumerate(recs):
+                rec = list(rec)
+                ti, tj = (r + edge - 1) // edge, (c + edge - 1) // edge
+                ks = 1
+                if mode == 2:
+                    C0, db, KK = rec[2], rec[4], rec[8]
+                    n = r * c + (r if db else 0)
+                    ks = max(1, min(16, (WGRAD_TARGET_TILES + ti * tj - 1) // (ti * tj), (KK // 32) // 4))
+                    if ks > 1 and n % 4 == 0 and (not db or db == C0 + r * c * 4):
+                        sums.append((k, C0, slab, n, ks, rec[13]))
+                        slab += n
+                    else:
+                        ks = 1
+                    rec[17] = ks
+                groups[k] = tuple(rec)
+                shapes.append((k, ti, tj, ks))
+            stride = 0
+            if sums:
+                stride = (slab + 63) // 64 * 64
+                need = stride * max(x[4] for x in sums)
+                if out.get("wg_scratch") is None or out["wg_scratch"].numel() < need:
+                    out.setdefault("keep", []).append(out.get("wg_scratch"))       # earlier launches keep theirs
+                    out["wg_scratch"] = torch.empty(max(need, 2 * (out["wg_scratch"].numel() if out.get("wg_scratch") is not None
+                                                                   else 0)), device=self.device, dtype=torch.float32)
+                base = out["wg_scratch"].data_ptr()
+                for k, C0, off, n, ks, steps in sums:
+                    groups[k]["C"] = base + off * 4
+                    if groups[k]["aux_out"]:
+                        groups[k]["aux_out"] = base + (off + int(groups[k]["I"]) * int(groups[k]["J"])) * 4
+            tiles = spread_tiles(shapes)
             nm = name()
             op(K_GEMM, len(tiles), self._upload(nm + "g", groups), self._upload(nm + "t", tiles), a=mode, b=edge, c=a_shared,
-               d=rows_kind, flags=flags)
+               d=rows_kind, flags=flags, p2=stride)
+            if sums:
+                tab = np.zeros(len(sums), dtype=SUM_DTYPE)
+                for j, (k, C0, off, n, ks, steps) in enumerate(sums):
+                    tab[j] = (base + off * 4, C0, stride, n, ks, steps, 0)
+                op(K_SUM, len(sums), self._upload(nm + "s", tab), self._upload(nm + "si", np.arange(len(sums), dtype=np.int32)),
+                   a=max(x[3] for x in sums))
 
         def table(dtype, fill: Callable[[int, _XSlot, Dict[str, Any]], Optional[tuple]]) -> Tuple[int, int]:
             arr = np.zeros(T, dtype=dtype)
