@@ -34,6 +34,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # device-memory sharing between ranks goes through dmabuf here
 
 import torch  # noqa: E402
 

@@ -5,8 +5,8 @@ it is the model family of the "tabular regression in bf16 with population-based 
 configuration.  Every numeric feature becomes one token (``x_j * w_j + b_j``), a learned [CLS] token
 is appended, ``n_blocks`` post-norm encoder blocks with a ReGLU feed-forward mix the tokens, and the
 [CLS] representation is regressed to a scalar.  With F <= 127 features the token sequence fits the fused
-short-sequence attention kernel (S <= 128); the projections are plain GEMMs left to the BLAS library,
-under bf16 autocast on a GPU.
+short-sequence attention kernel (S <= 128); tokenizer, projections, LayerNorm and ReGLU run on this package's own
+kernels, under bf16 autocast on a GPU.
 """
 from __future__ import annotations
 
@@ -21,6 +21,7 @@ from .transformer import SelfAttention
 from ..ops.elementwise import reglu_dropout
 from ..ops.layernorm import residual_layer_norm_mixed
 from ..ops.linear import linear
+from ..ops.tokens import feature_tokens
 
 
 class FeatureTokenizer(nn.Module):
@@ -31,9 +32,8 @@ class FeatureTokenizer(nn.Module):
         self.bias = nn.Parameter(torch.empty(n_features, d_token).uniform_(-bound, bound))
         self.cls = nn.Parameter(torch.empty(1, 1, d_token).uniform_(-bound, bound))
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:            # [B, F] -> [B, F + 1, d]
-        tok = x.unsqueeze(-1) * self.weight + self.bias
-        return torch.cat([tok, self.cls.expand(x.size(0), -1, -1).to(tok.dtype)], dim=1)
+    def forward(self, x: torch.Tensor, want_bf16: bool = False):   # [B, F] -> ([B, F + 1, d] f32, its bf16 copy or None)
+        return feature_tokens(x, self.weight, self.bias, self.cls, want_bf16)
 
 
 class ReGLU(nn.Module):
@@ -86,7 +86,7 @@ class FTTransformer(nn.Module):
         self.head = nn.Linear(d_token, 1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:            # [B, F] -> [B]
-        t, t16 = self.tokenizer(x), None
+        t, t16 = self.tokenizer(x, want_bf16=torch.is_autocast_enabled() and x.is_cuda)
         for i, blk in enumerate(self.blocks):
             t, t16 = blk(t, t16, last=i == len(self.blocks) - 1)
         cls = t[:, -1, :]

@@ -174,6 +174,10 @@ __device__ __forceinline__ float group_max(float v) {
   return v;
 }
 
+// NKB counts the blocks of 16 keys (queries) that hold any real token; images and contraction steps come in pairs of
+// blocks (the 16x16x32 products take 32 keys a step), so an odd count is padded by one block of zero rows.
+constexpr int at_padded_blocks(int nkb) { return (nkb + 1) / 2 * 2; }
+
 // Scores for 16 queries (block qb) against all keys, transposed: acc[kb][j] = S[query][key = 16kb + 4g + j].
 template <int NKB, int PCHQ>
 __device__ __forceinline__ void scores_T(f32x4 (&acc)[NKB], const uint8_t* ldsK, const uint8_t* ldsQ, int qb, int dsteps,
@@ -190,21 +194,20 @@ __device__ __forceinline__ void scores_T(f32x4 (&acc)[NKB], const uint8_t* ldsK,
   }
 }
 
-// The keep flags (one byte each, 1 = keep) of keys key0 .. key0 + 3 for one query: read from the stored mask, or drawn
-// from the seed words at the element's index in the [BH, S, S] mask.
-__device__ __forceinline__ uint32_t keep_word(const uint8_t* __restrict__ keep, uint32_t seed_lo, uint32_t seed_hi,
-                                              uint32_t thresh, size_t at, int key0, int S) {
-  uint32_t kw = 0u;
+// Dropout multipliers (on or 0) of keys key0 .. key0 + 3 for one query: from the stored byte mask if there is one, else
+// drawn from the seed words at the element's index in the [BH, S, S] mask.  Straight to floats: the vector ALUs set
+// these kernels' time, and flags packed into a word and picked apart again were a good part of their instructions.
+// Padding keys may get any value (their probability is zero).
+__device__ __forceinline__ void keep_mult4(float (&mk)[4], const uint8_t* __restrict__ keep, uint32_t seed_lo,
+                                           uint32_t seed_hi, uint32_t thresh, size_t at, int key0, int S, float on) {
   if (keep != nullptr) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (key0 + j < S) kw |= (uint32_t)keep[at + j] << (8 * j);
+    for (int j = 0; j < 4; ++j) mk[j] = (key0 + j < S && keep[at + j]) ? on : 0.f;
   } else {
+    const uint32_t i0 = (uint32_t)at;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (key0 + j < S) kw |= (mt_rng_hash(seed_lo, seed_hi, (uint32_t)(at + j)) >= thresh ? 1u : 0u) << (8 * j);
+    for (int j = 0; j < 4; ++j) mk[j] = (mt_rng_hash(seed_lo, seed_hi, i0 + (uint32_t)j) >= thresh) ? on : 0.f;
   }
-  return kw;
 }
 
 // Scores of one block of 16 queries -> probabilities (dropout applied), in place; writes the row statistic.  KIND and
@@ -254,24 +257,23 @@ __device__ __forceinline__ void fwd_probs(f32x4 (&acc)[NKB], float* __restrict__
     norm = 1.f / z;
     if (g == 0 && query < S) stat[(size_t)bh * S + query] = z;
   }
+  const size_t row_at = ((size_t)bh * S + (query < S ? query : 0)) * S;      // a padding query reads row 0: in bounds, unused
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
     if constexpr (MASKED) {
-      uint32_t kw = 0x01010101u;
-      if (query < S) {
-        const int key0 = kb * 16 + g * 4;
-        kw = keep_word(keep, seed_lo, seed_hi, thresh, ((size_t)bh * S + query) * S + key0, key0, S);
-      }
+      float mk[4];
+      const int key0 = kb * 16 + g * 4;
+      keep_mult4(mk, keep, seed_lo, seed_hi, thresh, row_at + key0, key0, S, norm * keep_scale);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[kb][j] *= norm * (((kw >> (8 * j)) & 0xFFu) ? keep_scale : 0.f);
+      for (int j = 0; j < 4; ++j) acc[kb][j] *= mk[j];
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[kb][j] *= norm * 1.f;
+      for (int j = 0; j < 4; ++j) acc[kb][j] *= norm;
     }
   }
 }
 
-// NKB = padded sequence length / 16 (2, 4, 6 or 8); PCHQ = 16-byte chunks per image row; F32: Q, K, V, O are f32
+// NKB = blocks of 16 tokens (2 .. 8); PCHQ = 16-byte chunks per image row; F32: Q, K, V, O are f32
 // (converted while staging) instead of bf16.  Operands are [B, S, H * d] with row strides ldq (Q and K), ldv, ldo, so
 // the halves of a fused QK projection and a [B, S, d_model] value / output tensor are used in place; H = 1 with
 // ld = d is the plain contiguous [BH, S, d] form.
@@ -283,7 +285,8 @@ __device__ __forceinline__ void attn_fwd_body(uint8_t* lds, const void* __restri
                                               bool seeded, uint32_t seed_lo, uint32_t seed_hi, uint32_t thresh, int bh) {
   // attention dropout: a stored [BH, S, S] byte mask if `keep` is given, else drawn here from the seed words
   const bool masked = keep != nullptr || seeded;
-  constexpr int SP = NKB * 16;
+  constexpr int NKP = at_padded_blocks(NKB);
+  constexpr int SP = NKP * 16;
   constexpr int IMG = SP * PCHQ * 16;
   uint8_t *ldsQ = lds, *ldsK = lds + IMG, *ldsV = lds + 2 * IMG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -320,8 +323,8 @@ __device__ __forceinline__ void attn_fwd_body(uint8_t* lds, const void* __restri
     for (int nb = 0; nb < nvb; ++nb) {
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s2 = 0; s2 < NKB / 2; ++s2) {
-        const bf16x8 pf = pack_frag(acc[2 * s2], acc[2 * s2 + 1]);
+      for (int s2 = 0; s2 < NKP / 2; ++s2) {
+        const bf16x8 pf = pack_frag(acc[2 * s2], (2 * s2 + 1 < NKB) ? acc[(2 * s2 + 1 < NKB) ? 2 * s2 + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
         const bf16x8 vf = frag_cols(ldsV, nb * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, lane, PCHQ);
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o, 0, 0, 0);
       }
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_kernel(const void* __r
                                                                  int S, int dk, int dv, float scale, float keep_scale,
                                                                  int kind, int H, long ldq, long ldv, long ldo,
                                                                  const int64_t* __restrict__ seed, uint32_t thresh) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * NKB * 16 * PCHQ * 16];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * at_padded_blocks(NKB) * 16 * PCHQ * 16];
   uint32_t seed_lo = 0u, seed_hi = 0u;
   if (seed != nullptr) { const uint64_t sv = (uint64_t)seed[0]; seed_lo = (uint32_t)sv; seed_hi = (uint32_t)(sv >> 32); }
   attn_fwd_body<NKB, PCHQ, F32>(lds, Q_, K_, V_, keep, O_, stat, S, dk, dv, scale, keep_scale, kind, H, ldq, ldv, ldo,
@@ -373,14 +376,13 @@ __device__ __forceinline__ void bwd_block(f32x4 (&p)[NKB], f32x4 (&dp)[NKB], uin
   constexpr int KB_STEP = 16 * PCH * 16;
   float delta = 0.f;
   uint32_t relu_pos = 0u;       // bit (kb*4 + j): pre-activation > 0 (kind 1)
+  const size_t row_at = ((size_t)bh * S + (query < S ? query : 0)) * S;
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
-    uint32_t kw = 0x01010101u;
+    float mk[4] = {1.f, 1.f, 1.f, 1.f};
     if constexpr (MASKED) {
-      if (query < S) {
-        const int key0 = kb * 16 + g * 4;
-        kw = keep_word(keep, seed_lo, seed_hi, thresh, ((size_t)bh * S + query) * S + key0, key0, S);
-      }
+      const int key0 = kb * 16 + g * 4;
+      keep_mult4(mk, keep, seed_lo, seed_hi, thresh, row_at + key0, key0, S, keep_scale);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -389,13 +391,13 @@ __device__ __forceinline__ void bwd_block(f32x4 (&p)[NKB], f32x4 (&dp)[NKB], uin
       float pv;
       if constexpr (KIND == 0) pv = (key < S && query < S) ? __expf(s - st) : 0.f;
       else { pv = fmaxf(s, 0.f) * inv_z; if (s > 0.f) relu_pos |= 1u << (kb * 4 + j); }
-      const float mk = MASKED ? (((kw >> (8 * j)) & 0xFFu) ? keep_scale : 0.f) : 1.f;
-      const float dpe = dp[kb][j] * mk;      // gradient w.r.t. the un-dropped probability
+      const float dpe = MASKED ? dp[kb][j] * mk[j] : dp[kb][j];      // gradient w.r.t. the un-dropped probability
       delta += dpe * pv;
       p[kb][j] = pv;
       dp[kb][j] = dpe;
       // P^T with dropout applied feeds dV
-      *reinterpret_cast<uint16_t*>(ldsPT + at_row[j] + kb * KB_STEP) = (uint16_t)f32_to_bf16_bits(pv * mk);
+      *reinterpret_cast<uint16_t*>(ldsPT + at_row[j] + kb * KB_STEP) =
+          (uint16_t)f32_to_bf16_bits(MASKED ? pv * mk[j] : pv);
     }
   }
   delta = group_sum(delta);
@@ -428,7 +430,8 @@ __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restri
                                               long ldv, long ldo, bool seeded, uint32_t seed_lo, uint32_t seed_hi,
                                               uint32_t thresh, int bh, bool gbf = false) {
   const bool masked = keep != nullptr || seeded;
-  constexpr int SP = NKB * 16;
+  constexpr int NKP = at_padded_blocks(NKB);
+  constexpr int SP = NKP * 16;
   constexpr int PCH = (SP <= 64) ? 8 : 16;        // chunks per row of the [key][query] images
   constexpr int PT_BYTES = SP * PCH * 16;
   constexpr int IMG = SP * PCHQ * 16;
@@ -458,7 +461,7 @@ __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restri
   const int dsteps = (dk + 31) / 32, vsteps = (dv + 31) / 32, nkd = (dk + 15) / 16, nvb = (dv + 15) / 16;
 
   // ---------------------------------------------------------------- query-parallel phase
-  for (int qb = wave; qb < NKB; qb += 4) {
+  for (int qb = wave; qb < NKP; qb += 4) {
     if (qb * 16 >= S) {      // a block of padding queries: its 32 bytes of every P^T and dS^T row are zero, nothing else
       for (int idx = lane; idx < SP * 2; idx += 64) {
         const int off = img_off(idx >> 1, qb * 2 + (idx & 1), PCH);
@@ -482,9 +485,9 @@ __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restri
     for (int db = 0; db < nkd; ++db) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s2 = 0; s2 < NKB / 2; ++s2) {
+      for (int s2 = 0; s2 < NKP / 2; ++s2) {
         const bf16x8 kf = frag_cols(ldsK, db * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, lane, PCHQ);
-        const bf16x8 sf = pack_frag(dp[2 * s2], dp[2 * s2 + 1]);
+        const bf16x8 sf = pack_frag(dp[2 * s2], (2 * s2 + 1 < NKB) ? dp[(2 * s2 + 1 < NKB) ? 2 * s2 + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, a, 0, 0, 0);
       }
       // a[j] = dQ[query = qb*16 + fr][d = db*16 + 4g + j]
@@ -504,7 +507,7 @@ __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restri
     for (int nb = 0; nb < nvb; ++nb) {       // dV[key][n] = sum_query P^T[key][query] dO[query][n]
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s2 = 0; s2 < NKB / 2; ++s2) {
+      for (int s2 = 0; s2 < NKP / 2; ++s2) {
         const bf16x8 pf = frag_rows(ldsPT, kb * 16, s2, lane, PCH);
         const bf16x8 of = frag_cols(ldsdO, nb * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, lane, PCHQ);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, of, a, 0, 0, 0);
@@ -519,7 +522,7 @@ __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restri
     for (int db = 0; db < nkd; ++db) {       // dK[key][d] = sum_query dS^T[key][query] Q[query][d]
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s2 = 0; s2 < NKB / 2; ++s2) {
+      for (int s2 = 0; s2 < NKP / 2; ++s2) {
         const bf16x8 sf = frag_rows(ldsST, kb * 16, s2, lane, PCH);
         const bf16x8 qf = frag_cols(ldsQ, db * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, lane, PCHQ);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, qf, a, 0, 0, 0);
@@ -536,7 +539,7 @@ __device__ __forceinline__ void attn_bwd_body(uint8_t* lds, const void* __restri
 
 template <int NKB, int PCHQ>
 constexpr int at_bwd_lds_bytes() {
-  constexpr int SP = NKB * 16;
+  constexpr int SP = at_padded_blocks(NKB) * 16;
   return 4 * SP * PCHQ * 16 + 2 * SP * ((SP <= 64) ? 8 : 16) * 16;
 }
 
@@ -1187,7 +1190,7 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_fwd_grouped_kernel(const M
                                                                          const int32_t* __restrict__ ids, int S,
                                                                          int step_imm, int b_override, int train,
                                                                          const int* __restrict__ step_base) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * NKB * 16 * PCHQ * 16];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * at_padded_blocks(NKB) * 16 * PCHQ * 16];
   const int step = mt_step(step_imm, step_base);
   const MtAttnSlot a = slots[ids[blockIdx.y]];
   if (step >= a.active_steps) return;
@@ -1287,7 +1290,10 @@ __global__ __launch_bounds__(AT_THREADS) void mt_attn_bwd_grouped_tiled_kernel(c
 
 extern "C" int mt_attn_slot_sizeof() { return (int)sizeof(MtAttnSlot); }
 
-static int nkb_for(int S) { return ((S + 31) / 32) * 2; }   // pad the sequence to a multiple of 32
+static int nkb_for(int S) { return ((S + 31) / 32) * 2; }   // grouped launches: the sequence padded to a multiple of 32
+// one problem shape per launch: blocks of 16 tokens that hold any (3, 5 and 7 have kernels of their own: a sequence of
+// 65 tokens -- 64 features and a summary token -- then does 5 x 5 blocks of score work instead of 6 x 6)
+static int nkb_live_for(int S) { const int n = (S + 15) / 16; return n < 2 ? 2 : n; }
 
 // Strided form.  Q, K: [B, S, H * dk] with row stride ldq elements (the two halves of a fused QK projection pass the
 // same ldq and pointers dk * H apart); V: row stride ldv; O (and dO): row stride ldo.  f32 != 0: operands and output
@@ -1337,10 +1343,13 @@ extern "C" int mt_attn_fwd_strided_launch(const void* Q, const void* K, const vo
 #define AT_FWD1(N, P) do { if (f32) AT_FWD2(N, P, true); else AT_FWD2(N, P, false); } while (0)
   const bool wide = dk > 64 || dv > 64;       // heads of 65..128 elements: 256-byte image rows (S <= 96, checked above)
 #define AT_FWD(N) do { if (narrow) AT_FWD1(N, 4); else if (!wide) AT_FWD1(N, 8); else AT_FWD1(N, 16); } while (0)
-  switch (nkb_for(S)) {
+  switch (nkb_live_for(S)) {
     case 2: AT_FWD(2); break;
+    case 3: AT_FWD(3); break;
     case 4: AT_FWD(4); break;
+    case 5: AT_FWD(5); break;
     case 6: AT_FWD(6); break;
+    case 7: if (narrow) AT_FWD1(7, 4); else AT_FWD1(7, 8); break;
     case 8: if (narrow) AT_FWD1(8, 4); else AT_FWD1(8, 8); break;
     default: return -3;
   }
@@ -1390,10 +1399,13 @@ extern "C" int mt_attn_bwd_strided_launch(const void* Q, const void* K, const vo
 #define AT_BWD1(N, P) do { if (f32) AT_BWD2(N, P, true); else AT_BWD2(N, P, false); } while (0)
   const bool wide = dk > 64 || dv > 64;
 #define AT_BWD(N) do { if (narrow) AT_BWD1(N, 4); else if (!wide) AT_BWD1(N, 8); else AT_BWD1(N, 16); } while (0)
-  switch (nkb_for(S)) {
+  switch (nkb_live_for(S)) {
     case 2: AT_BWD(2); break;
+    case 3: AT_BWD(3); break;
     case 4: AT_BWD(4); break;
+    case 5: AT_BWD(5); break;
     case 6: AT_BWD(6); break;
+    case 7: if (narrow) AT_BWD1(7, 4); else AT_BWD1(7, 8); break;
     case 8: if (narrow) AT_BWD1(8, 4); else AT_BWD1(8, 8); break;
     default: return -3;
   }

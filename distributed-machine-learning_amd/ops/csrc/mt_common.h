@@ -132,8 +132,10 @@ __device__ __forceinline__ uint32_t mt_mix32(uint32_t x) {
 // Counter-based dropout: element i of a tensor is kept iff mt_rng_hash(seed, i) >= p * 2^32.  The 64-bit seed lives in
 // device memory (ops/rng.py), so captured graphs draw fresh masks per replay and a backward pass recomputes the
 // forward's mask instead of reading a stored one.
+// One mixing round per element: 32-bit integer multiplies issue at a quarter of the vector rate, and in the attention
+// kernels (one draw per score, forward and again in backward) a second round was most of the kernel's vector work.
 __device__ __forceinline__ uint32_t mt_rng_hash(uint32_t s0, uint32_t s1, uint32_t i) {
-  return mt_mix32(i * 0x9E3779B9u + s0) ^ mt_mix32((i >> 5) + s1 * 0x85EBCA6Bu + 0x27D4EB2Fu);
+  return mt_mix32((i * 0x9E3779B9u + s0) ^ s1);
 }
 // Keep flags (one byte each, 0 or 1) of elements i .. i+3, from a stored mask if there is one, else from the seed.
 // Seed words of one dropout site at one step: derived from the slot's epoch seed so that forward and backward of the

@@ -71,7 +71,8 @@ class FusedDepthwiseConv1d(torch.autograd.Function):
         part = torch.empty(chunks, k + 1, d, device=xc.device, dtype=torch.float32)
         L.check(so.mt_dwconv_wgrad_launch(xc.data_ptr(), dyc.data_ptr(), part.data_ptr(), B * S, S, d, k, _stream(dy)),
                 "mt_dwconv_wgrad_launch")
-        g = part.sum(0)                                   # [k + 1, d], fixed summation order
+        g = torch.empty(k + 1, d, device=xc.device, dtype=torch.float32)     # fixed summation order
+        L.check(so.mt_colsum_launch(part.data_ptr(), g.data_ptr(), chunks, (k + 1) * d, _stream(dy)), "mt_colsum_launch")
         dw = g[:k].t().reshape(wshape)
         return dx, dw, (g[k] if has_bias else None)
 

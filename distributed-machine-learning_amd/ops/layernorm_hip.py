@@ -57,7 +57,8 @@ class FusedResidualLayerNorm(torch.autograd.Function):
                                     dres.data_ptr(), part.data_ptr(), M, d, keep_scale,
                                     ctx.seed.data_ptr() if ctx.seed is not None else None, ctx.p,
                                     L.raw_stream(z.device)), "mt_ln_bwd_launch")
-        dwb = part.sum(0)
+        dwb = torch.empty(2, d, device=z.device, dtype=torch.float32)
+        L.check(so.mt_colsum_launch(part.data_ptr(), dwb.data_ptr(), nblk, 2 * d, L.raw_stream(z.device)), "mt_colsum_launch")
         return dx.view(shape), dres.view(shape), dwb[0], dwb[1], None, None, None, None
 
 
@@ -115,5 +116,6 @@ class MixedResidualLayerNorm(torch.autograd.Function):
                                           w.data_ptr(), dx.data_ptr(), int(xb), dres.data_ptr(), part.data_ptr(), M, d,
                                           keep_scale, ctx.seed.data_ptr() if ctx.seed is not None else None, ctx.p,
                                           L.raw_stream(z.device)), "mt_ln_bwd_mixed_launch")
-        dwb = part.sum(0)
+        dwb = torch.empty(2, d, device=z.device, dtype=torch.float32)
+        L.check(so.mt_colsum_launch(part.data_ptr(), dwb.data_ptr(), nblk, 2 * d, L.raw_stream(z.device)), "mt_colsum_launch")
         return dx.view(shape), dres.view(shape), dwb[0], dwb[1], None, None, None, None

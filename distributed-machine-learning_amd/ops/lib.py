@@ -272,6 +272,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
                                                              c_float, c_void_p]
     for fn in (lib.mt_reglu_fwd_launch, lib.mt_reglu_bwd_launch, lib.mt_ln_fwd_mixed_launch, lib.mt_ln_bwd_mixed_launch):
         fn.restype = C.c_int
+    lib.mt_tokens_fwd_launch.argtypes = [c_void_p] * 6 + [C.c_long, C.c_int, C.c_int, c_void_p]
+    lib.mt_tokens_bwd_launch.argtypes = [c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_int, c_void_p]
+    lib.mt_colsum_launch.argtypes = [c_void_p, c_void_p, C.c_long, C.c_int, c_void_p]
+    lib.mt_tokens_fwd_launch.restype = lib.mt_tokens_bwd_launch.restype = lib.mt_colsum_launch.restype = C.c_int
     lib.mt_dwconv_chunks.argtypes = [C.c_long]
     lib.mt_dwconv_launch.argtypes = [c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]
     lib.mt_dwconv_wgrad_launch.argtypes = [c_void_p] * 3 + [C.c_long, C.c_int, C.c_int, C.c_int, c_void_p]

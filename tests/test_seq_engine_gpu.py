@@ -70,7 +70,7 @@ def _keep(seed_words, site, step, index, p):
         s0 = u(seed_words[0]) + u(site) * u(0x9E3779B9)
         s1 = u(seed_words[1]) ^ mix32(u(step) * u(0x85EBCA6B) + u(site) + u(0x51ED270B))
         i = np.asarray(index).astype(np.uint32)
-        h = mix32(i * u(0x9E3779B9) + s0) ^ mix32((i >> u(5)) + s1 * u(0x85EBCA6B) + u(0x27D4EB2F))
+        h = mix32((i * u(0x9E3779B9) + s0) ^ s1)
     return torch.from_numpy(h >= u(min(int(p * 4294967296.0), 0xFFFFFFFF)))
 
 

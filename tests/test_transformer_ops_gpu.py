@@ -10,7 +10,8 @@ def _bf16r(t):
 
 
 @pytest.mark.parametrize("kind", ["softmax", "relu"])
-@pytest.mark.parametrize("S,dk,dv", [(50, 16, 16), (96, 32, 32), (128, 64, 64), (17, 8, 24), (65, 24, 8)])
+@pytest.mark.parametrize("S,dk,dv", [(50, 16, 16), (96, 32, 32), (128, 64, 64), (17, 8, 24), (65, 24, 8), (40, 16, 16),
+                                      (100, 32, 48)])      # 3, 5 and 7 blocks of 16 tokens have kernels of their own
 @pytest.mark.parametrize("drop", [0.0, 0.2])
 def test_fused_attention_forward_backward(kind, S, dk, dv, drop):
     from mitune.ops.attention import attention_reference
@@ -624,3 +625,46 @@ def test_layernorm_backward_over_more_rows_than_one_block_per_group(d, mixed):
     torch.testing.assert_close(x.grad.double(), x64.grad, rtol=xtol, atol=xtol)
     for got, ref in ((w.grad, w64.grad), (b.grad, b64.grad)):       # sums of 40 000 terms of order one
         torch.testing.assert_close(got.double(), ref, rtol=1e-4, atol=5e-3)
+
+
+@pytest.mark.parametrize("B,F,d", [(64, 64, 192), (37, 5, 8), (1024, 12, 64)])
+@pytest.mark.parametrize("two_outputs", [False, True])
+def test_feature_tokens_match_tensor_ops(B, F, d, two_outputs):
+    """Tokenizer kernels (forward with the bf16 copy, backward over both outputs) against x * W + b | cls in f32."""
+    from mitune.ops.tokens import FeatureTokens, feature_tokens_reference
+    g = torch.Generator(device="cuda").manual_seed(B + F)
+    x = torch.randn(B, F, device="cuda", generator=g)
+    W, b = (torch.randn(F, d, device="cuda", generator=g).requires_grad_(True) for _ in range(2))
+    cls = torch.randn(1, 1, d, device="cuda", generator=g).requires_grad_(True)
+    g32 = torch.randn(B, F + 1, d, device="cuda", generator=g)
+    g16 = torch.randn(B, F + 1, d, device="cuda", generator=g).to(torch.bfloat16)
+    if two_outputs:
+        out, out16 = FeatureTokens.apply(x, W, b, cls, True)
+        torch.autograd.backward([out, out16], [g32, g16])
+    else:
+        out = FeatureTokens.apply(x, W, b, cls, False)
+        out.backward(g32)
+    got = [out.detach(), W.grad.clone(), b.grad.clone(), cls.grad.clone()]
+    W.grad = b.grad = cls.grad = None
+    ref = feature_tokens_reference(x, W, b, cls)
+    ref.backward(g32 + g16.float() if two_outputs else g32)
+    assert torch.equal(got[0], ref.detach())
+    if two_outputs:
+        assert torch.equal(out16, ref.detach().to(torch.bfloat16))
+    for name, a, e in zip(("dW", "dbias", "dcls"), got[1:], (W.grad, b.grad, cls.grad)):
+        assert a.shape == e.shape, name
+        assert (a - e).abs().max().item() <= 2e-5 * (e.abs().max().item() + 1.0) * max(1.0, B ** 0.5 / 8), name
+
+
+@pytest.mark.parametrize("rows,cols", [(694, 384), (1, 7), (33, 16), (100, 130)])
+def test_column_sums(rows, cols):
+    from mitune.ops import lib as L
+    so = L.load()
+    src = torch.randn(rows, cols, device="cuda")
+    out = torch.empty(cols, device="cuda")
+    L.check(so.mt_colsum_launch(src.data_ptr(), out.data_ptr(), rows, cols, L.raw_stream(src.device)), "mt_colsum_launch")
+    ref = src.double().sum(0)
+    assert (out.double() - ref).abs().max().item() < 1e-4 * max(1.0, rows ** 0.5)
+    again = torch.empty(cols, device="cuda")
+    L.check(so.mt_colsum_launch(src.data_ptr(), again.data_ptr(), rows, cols, L.raw_stream(src.device)), "mt_colsum_launch")
+    assert torch.equal(out, again)
