@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .transformer import SelfAttention
+from ..ops.attention import self_attention_qkv
 from ..ops.elementwise import reglu_dropout
 from ..ops.layernorm import residual_layer_norm_mixed
 from ..ops.linear import linear
@@ -60,15 +61,30 @@ class FTBlock(nn.Module):
     def forward(self, x: torch.Tensor, x16=None, last: bool = False):
         """``x``: the f32 residual stream; ``x16``: its bf16 copy when the caller has one (under bf16 autocast the GEMMs
         read that, and the LayerNorm kernels take the GEMMs' bf16 outputs as they are: no cast kernels in between).
-        Returns the new stream and its bf16 copy (``None`` for the last block or outside autocast)."""
+        Returns the new stream and its bf16 copy (``None`` outside autocast).
+
+        ``last``: only the summary token of the last block's output is ever read, so past the attention (which needs
+        every token as key and value) the block carries that one row per sample: output projection, both LayerNorms and
+        the feed-forward run on ``[B, d]`` instead of ``[B, F + 1, d]``.  Returns ``([B, d], None)``."""
         p = self.p if self.training else 0.0
         amp = torch.is_autocast_enabled() and x.is_cuda
-        a, _ = self.attn(x16 if x16 is not None else x)
+        src = x16 if x16 is not None else x
+        if last:
+            at = self.attn
+            qkv = linear(src, at.qkv_proj.weight, at.qkv_proj.bias)
+            o = self_attention_qkv(qkv, at.h, at.dk, kind=at.kind, dropout_p=at.p if self.training else 0.0)
+            a = linear(o[:, -1, :], at.out_proj.weight, at.out_proj.bias)
+            y, y16 = residual_layer_norm_mixed(a, x[:, -1, :].float(), self.norm1.weight, self.norm1.bias, self.norm1.eps,
+                                               dropout_p=p, want_bf16=amp)
+            f = self.ffn(y16 if y16 is not None else y)
+            return residual_layer_norm_mixed(f, y, self.norm2.weight, self.norm2.bias, self.norm2.eps, dropout_p=p,
+                                             want_bf16=False)
+        a, _ = self.attn(src)
         x, x16 = residual_layer_norm_mixed(a, x.float(), self.norm1.weight, self.norm1.bias, self.norm1.eps, dropout_p=p,
                                            want_bf16=amp)
         f = self.ffn(x16 if x16 is not None else x)
         return residual_layer_norm_mixed(f, x, self.norm2.weight, self.norm2.bias, self.norm2.eps, dropout_p=p,
-                                         want_bf16=amp and not last)
+                                         want_bf16=amp)
 
 
 class FTTransformer(nn.Module):
@@ -89,7 +105,7 @@ class FTTransformer(nn.Module):
         t, t16 = self.tokenizer(x, want_bf16=torch.is_autocast_enabled() and x.is_cuda)
         for i, blk in enumerate(self.blocks):
             t, t16 = blk(t, t16, last=i == len(self.blocks) - 1)
-        cls = t[:, -1, :]
+        cls = t if t.dim() == 2 else t[:, -1, :]          # the last block hands back the summary token only
         return linear(F.relu(self.head_norm(cls.float())), self.head.weight, self.head.bias).squeeze(-1)
 
     @classmethod

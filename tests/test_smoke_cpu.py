@@ -53,3 +53,28 @@ def test_ft_transformer_population_based_training_cpu():
     assert an.stats["exploits"] >= 1
     first = min(t.results[0]["validation_loss"] for t in an.trials)
     assert an.best_result["validation_loss"] < first
+
+
+def test_ft_transformer_last_block_carries_only_the_summary_token():
+    """The last block runs its output projection, LayerNorms and feed-forward on the summary token alone; prediction and
+    every parameter gradient equal those of the block run over all tokens."""
+    import torch
+    from mitune.models.ft_transformer import FTTransformer
+    torch.manual_seed(3)
+    model = FTTransformer(7, d_token=16, n_blocks=2, n_heads=2, attn_dropout=0.0, ffn_dropout=0.0)
+    x = torch.randn(5, 7)
+
+    def full(m, x):
+        t, _ = m.tokenizer(x)
+        for blk in m.blocks:
+            t, _ = blk(t, None, last=False)
+        cls = t[:, -1, :]
+        return torch.nn.functional.linear(torch.relu(m.head_norm(cls)), m.head.weight, m.head.bias).squeeze(-1)
+
+    a = model(x)
+    ga = torch.autograd.grad(a.square().sum(), list(model.parameters()))
+    b = full(model, x)
+    gb = torch.autograd.grad(b.square().sum(), list(model.parameters()))
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    for (name, _), u, v in zip(model.named_parameters(), ga, gb):
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-5), name
