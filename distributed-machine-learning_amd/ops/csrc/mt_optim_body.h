@@ -5,6 +5,10 @@
 
 #define OPT_THREADS 256
 #define OPT_PER_BLOCK 2048   // 8 elements per thread
+// A slot of more than this many blocks (a million parameters) has its clipping norm added up once, by
+// mt_sqnorm_total_kernel, instead of by every one of its optimiser blocks: the per-block loop is nb loads long, and a
+// 38-million-parameter Transformer trial has 18 thousand blocks.
+#define OPT_TOTAL_BLOCKS 512
 
 __device__ __forceinline__ float lr_factor(int t, int warmup, int total) {
   if (warmup > 0 && t < warmup) return (float)(t + 1) / (float)warmup;
@@ -32,7 +36,11 @@ __device__ __forceinline__ void optim_body(float* __restrict__ P, const float* _
   if (h.clip > 0.f && partials != nullptr) {
     const int nb = (h.n_params + OPT_PER_BLOCK - 1) / OPT_PER_BLOCK;
     float tot = 0.f;
-    for (int i = 0; i < nb; ++i) tot += partials[(size_t)slot * max_blocks + i];   // uniform -> scalar loads
+    if (nb <= OPT_TOTAL_BLOCKS) {
+      for (int i = 0; i < nb; ++i) tot += partials[(size_t)slot * max_blocks + i];   // uniform -> scalar loads
+    } else {
+      tot = partials[(size_t)slot * max_blocks];      // mt_sqnorm_total_kernel left the slot's sum here
+    }
     const float c = h.clip / (sqrtf(tot) + 1e-6f);
     gscale = c < 1.f ? c : 1.f;
   }

@@ -10,7 +10,8 @@
 //
 // Global-norm clipping: mt_sqnorm_kernel writes one partial sum of squares per (slot, block); each
 // optimiser block re-adds its slot's partials in index order (a fixed order, so bitwise reproducible)
-// and scales gradients by min(1, clip / (norm + 1e-6)).
+// and scales gradients by min(1, clip / (norm + 1e-6)).  Slots of more than OPT_TOTAL_BLOCKS blocks get their sum from
+// one workgroup of mt_sqnorm_total_kernel instead (also a fixed order).
 #include "mt_optim_body.h"
 
 __global__ __launch_bounds__(OPT_THREADS) void mt_sqnorm_kernel(const float* __restrict__ G, size_t slot_stride,
@@ -39,6 +40,32 @@ __global__ __launch_bounds__(OPT_THREADS) void mt_sqnorm_kernel(const float* __r
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) partials[(size_t)slot * max_blocks + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Sum of a big slot's partials, in a fixed order (256 consecutive runs added one after the other, then the 256 run sums
+// in index order), left in the slot's first partial.  Slots of at most OPT_TOTAL_BLOCKS blocks are not touched: their
+// optimiser blocks add the partials themselves.
+__global__ __launch_bounds__(OPT_THREADS) void mt_sqnorm_total_kernel(const MtOptSlot* __restrict__ hp,
+                                                                      const int32_t* __restrict__ ids,
+                                                                      float* __restrict__ partials, int max_blocks,
+                                                                      int step_imm, const int* __restrict__ step_base) {
+  const int step = mt_step(step_imm, step_base);
+  const int slot = ids[blockIdx.x];
+  const MtOptSlot h = hp[slot];
+  const int nb = (h.n_params + OPT_PER_BLOCK - 1) / OPT_PER_BLOCK;
+  if (step >= h.active_steps || h.clip <= 0.f || nb <= OPT_TOTAL_BLOCKS) return;
+  __shared__ float run[OPT_THREADS];
+  const int per = (nb + OPT_THREADS - 1) / OPT_THREADS;
+  const int i0 = threadIdx.x * per, i1 = (i0 + per < nb) ? i0 + per : nb;
+  float a = 0.f;
+  for (int i = i0; i < i1; ++i) a += partials[(size_t)slot * max_blocks + i];
+  run[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int t = 0; t < OPT_THREADS; ++t) tot += run[t];
+    partials[(size_t)slot * max_blocks] = tot;
+  }
 }
 
 template <bool G_BF16>
@@ -104,6 +131,9 @@ extern "C" int mt_optim_gather_launch(float* P, const float* G, float* M, float*
     if (partials == nullptr) return -3;
     hipLaunchKernelGGL(mt_sqnorm_kernel, dim3(nb, n_active), block, 0, stream, G, slot_stride, hp, ids, partials, max_blocks,
                        step, gsplits, gsplit_stride, mt_step_base_tls);
+    if (nb > OPT_TOTAL_BLOCKS)
+      hipLaunchKernelGGL(mt_sqnorm_total_kernel, dim3(n_active), block, 0, stream, hp, ids, partials, max_blocks, step,
+                         mt_step_base_tls);
   }
   if (f32)
     hipLaunchKernelGGL(mt_optim_gather_kernel<true>, dim3(nb + ga.blocks, n_active), block, 0, stream, P, G, M, V,
@@ -131,6 +161,9 @@ extern "C" int mt_optim_launch(float* P, const float* G, float* M, float* V, voi
     if (partials == nullptr) return -3;
     hipLaunchKernelGGL(mt_sqnorm_kernel, grid, block, 0, stream, G, slot_stride, hp, ids, partials, max_blocks, step, gsplits,
                        gsplit_stride, mt_step_base_tls);
+    if (nb > OPT_TOTAL_BLOCKS)
+      hipLaunchKernelGGL(mt_sqnorm_total_kernel, dim3(n_slots), block, 0, stream, hp, ids, partials, max_blocks, step,
+                         mt_step_base_tls);
   }
   hipLaunchKernelGGL(mt_optim_kernel<false>, grid, block, 0, stream, P, G, M, V, reinterpret_cast<uint16_t*>(Pb),
                      slot_stride, hp, ids, use_clip ? partials : nullptr, max_blocks, step, gsplits, gsplit_stride,
