@@ -15,14 +15,13 @@ from typing import Dict
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .transformer import SelfAttention
 from ..ops.attention import self_attention_qkv
 from ..ops.elementwise import reglu_dropout
 from ..ops.layernorm import residual_layer_norm_mixed
 from ..ops.linear import linear
-from ..ops.tokens import feature_tokens
+from ..ops.tokens import cls_head, feature_tokens
 
 
 class FeatureTokenizer(nn.Module):
@@ -106,7 +105,8 @@ class FTTransformer(nn.Module):
         for i, blk in enumerate(self.blocks):
             t, t16 = blk(t, t16, last=i == len(self.blocks) - 1)
         cls = t if t.dim() == 2 else t[:, -1, :]          # the last block hands back the summary token only
-        return linear(F.relu(self.head_norm(cls.float())), self.head.weight, self.head.bias).squeeze(-1)
+        return cls_head(cls.float(), self.head_norm.weight, self.head_norm.bias, self.head.weight, self.head.bias,
+                        self.head_norm.eps)
 
     @classmethod
     def from_config(cls, config: Dict, n_features: int) -> "FTTransformer":

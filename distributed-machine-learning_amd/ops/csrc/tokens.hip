@@ -122,3 +122,135 @@ extern "C" int mt_colsum_launch(const float* src, float* out, long rows, int col
   hipLaunchKernelGGL(mt_colsum_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(TK_THREADS), 0, stream, src, out, rows, cols);
   return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Regression head on the summary token: pred[b] = w . relu(LayerNorm(x[b]) * gamma + beta) + b0, rows of at most 512
+// columns.  One wave per row; as separate tensor operations this is a LayerNorm, a clamp, a multiply, a row sum and an
+// add going forward and a dozen small launches going back.  Backward writes dx and, per workgroup, partial sums of the
+// four parameter gradients ([3][d] + 1 floats, rows added in index order); mt_colsum_launch adds the workgroups.
+#define CH_MAXV 8          // columns per lane: d <= 512
+
+__global__ __launch_bounds__(TK_THREADS) void mt_cls_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta,
+                                                                     const float* __restrict__ w, const float* __restrict__ b0,
+                                                                     float* __restrict__ pred, float* __restrict__ stats,
+                                                                     int B, int d, float eps) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float v[CH_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < d ? x[(size_t)row * d + c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    const float t = c < d ? v[i] - mean : 0.f;
+    q += t * t;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d) {
+      const float a = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      acc += fmaxf(a, 0.f) * w[c];
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    pred[row] = acc + b0[0];
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+}
+
+// part: [gridDim.x][3 * d + 1]: d gamma | d beta | d w | d b0
+__global__ __launch_bounds__(TK_THREADS) void mt_cls_head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta,
+                                                                     const float* __restrict__ w,
+                                                                     const float* __restrict__ stats,
+                                                                     const float* __restrict__ dpred, float* __restrict__ dx,
+                                                                     float* __restrict__ part, int B, int d, int rows_per_wg) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * rows_per_wg;
+  float gg[CH_MAXV], gb[CH_MAXV], gw[CH_MAXV], ga[CH_MAXV], wv[CH_MAXV], bv[CH_MAXV];
+#pragma unroll
+  for (int i = 0; i < CH_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    gg[i] = gb[i] = gw[i] = 0.f;
+    ga[i] = c < d ? gamma[c] : 0.f;
+    wv[i] = c < d ? w[c] : 0.f;
+    bv[i] = c < d ? beta[c] : 0.f;
+  }
+  float g0 = 0.f;
+  for (int row = r0 + wave; row < r0 + rows_per_wg && row < B; row += 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1], dp = dpred[row];
+    float z[CH_MAXV], dz[CH_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      z[i] = c < d ? (x[(size_t)row * d + c] - mean) * rstd : 0.f;
+      const float a = z[i] * ga[i] + bv[i];
+      const float h = fmaxf(a, 0.f);
+      const float dh = (c < d && a > 0.f) ? dp * wv[i] : 0.f;
+      gw[i] += dp * h;
+      gb[i] += dh;
+      gg[i] += dh * z[i];
+      dz[i] = dh * ga[i];
+      s1 += dz[i];
+      s2 += dz[i] * z[i];
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int i = 0; i < CH_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d) dx[(size_t)row * d + c] = rstd * (dz[i] - s1 - z[i] * s2);
+    }
+    g0 += dp;
+  }
+  // the four waves' sums are added in wave order, one quantity at a time (the LDS image holds one quantity of four waves)
+  float* out = part + (size_t)blockIdx.x * (3 * d + 1);
+  __shared__ float img4[4][64 * CH_MAXV];
+  for (int qn = 0; qn < 3; ++qn) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CH_MAXV; ++i) img4[wave][lane + 64 * i] = qn == 0 ? gg[i] : (qn == 1 ? gb[i] : gw[i]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += TK_THREADS)
+      out[qn * d + c] = ((img4[0][c] + img4[1][c]) + img4[2][c]) + img4[3][c];
+  }
+  __syncthreads();
+  if (lane == 0) img4[wave][0] = g0;
+  __syncthreads();
+  if (threadIdx.x == 0) out[3 * d] = ((img4[0][0] + img4[1][0]) + img4[2][0]) + img4[3][0];
+}
+
+extern "C" int mt_cls_head_fwd_launch(const float* x, const float* gamma, const float* beta, const float* w, const float* b0,
+                                      float* pred, float* stats, int B, int d, float eps, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (d < 1 || d > 64 * CH_MAXV) return -2;
+  hipLaunchKernelGGL(mt_cls_head_fwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(TK_THREADS), 0, stream, x, gamma, beta, w, b0,
+                     pred, stats, B, d, eps);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mt_cls_head_bwd_blocks(int B) { return (B + 31) / 32; }
+
+extern "C" int mt_cls_head_bwd_launch(const float* x, const float* gamma, const float* beta, const float* w,
+                                      const float* stats, const float* dpred, float* dx, float* part, int B, int d,
+                                      hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (d < 1 || d > 64 * CH_MAXV) return -2;
+  hipLaunchKernelGGL(mt_cls_head_bwd_kernel, dim3((unsigned)mt_cls_head_bwd_blocks(B)), dim3(TK_THREADS), 0, stream, x, gamma,
+                     beta, w, stats, dpred, dx, part, B, d, 32);
+  return (int)hipGetLastError();
+}

@@ -276,6 +276,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.mt_tokens_bwd_launch.argtypes = [c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_int, c_void_p]
     lib.mt_colsum_launch.argtypes = [c_void_p, c_void_p, C.c_long, C.c_int, c_void_p]
     lib.mt_tokens_fwd_launch.restype = lib.mt_tokens_bwd_launch.restype = lib.mt_colsum_launch.restype = C.c_int
+    lib.mt_cls_head_fwd_launch.argtypes = [c_void_p] * 7 + [C.c_int, C.c_int, c_float, c_void_p]
+    lib.mt_cls_head_bwd_launch.argtypes = [c_void_p] * 8 + [C.c_int, C.c_int, c_void_p]
+    lib.mt_cls_head_bwd_blocks.argtypes = [C.c_int]
+    lib.mt_cls_head_fwd_launch.restype = lib.mt_cls_head_bwd_launch.restype = lib.mt_cls_head_bwd_blocks.restype = C.c_int
     lib.mt_dwconv_chunks.argtypes = [C.c_long]
     lib.mt_dwconv_launch.argtypes = [c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]
     lib.mt_dwconv_wgrad_launch.argtypes = [c_void_p] * 3 + [C.c_long, C.c_int, C.c_int, C.c_int, c_void_p]

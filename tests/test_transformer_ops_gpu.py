@@ -668,3 +668,23 @@ def test_column_sums(rows, cols):
     again = torch.empty(cols, device="cuda")
     L.check(so.mt_colsum_launch(src.data_ptr(), again.data_ptr(), rows, cols, L.raw_stream(src.device)), "mt_colsum_launch")
     assert torch.equal(out, again)
+
+
+@pytest.mark.parametrize("B,d", [(1024, 192), (7, 16), (130, 512), (33, 100)])
+def test_summary_token_head_matches_tensor_ops(B, d):
+    from mitune.ops.tokens import ClsHead, cls_head_reference
+    g = torch.Generator(device="cuda").manual_seed(B + d)
+    x = torch.randn(B, d, device="cuda", generator=g).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(d, device="cuda", generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(d, device="cuda", generator=g)).requires_grad_(True)
+    w = torch.randn(1, d, device="cuda", generator=g).requires_grad_(True)
+    b0 = torch.randn(1, device="cuda", generator=g).requires_grad_(True)
+    dp = torch.randn(B, device="cuda", generator=g)
+    leaves = [x, gamma, beta, w, b0]
+    out = ClsHead.apply(x, gamma, beta, w, b0, 1e-5)
+    got = [out.detach()] + list(torch.autograd.grad(out, leaves, dp))
+    ref = cls_head_reference(*[t.double() for t in leaves])
+    exp = [ref.detach()] + list(torch.autograd.grad(ref, leaves, dp.double()))
+    for name, a, e in zip(("pred", "dx", "dgamma", "dbeta", "dw", "db0"), got, exp):
+        assert a.shape == e.shape, name
+        assert (a.double() - e).abs().max().item() <= 3e-5 * (e.abs().max().item() + 1.0) * max(1.0, B ** 0.5 / 8), name
