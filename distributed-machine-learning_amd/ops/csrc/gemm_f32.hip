@@ -27,14 +27,14 @@
 // output columns of one row (16-byte epilogue stores).
 #include "mt_gemm_f32_tile.h"
 
-template <int MODE, int NSTAGE, int T, int KU = 1>
+template <int MODE, int NSTAGE, int T, int KU = 1, int PROD = 0>
 __global__ __launch_bounds__(F32_THREADS) void mt_gemm_f32_kernel(const MtGemmGroup* __restrict__ groups,
                                                                   const MtTile* __restrict__ tiles, int step, int flags,
                                                                   int arow0, int i_override, int ksplits,
                                                                   size_t split_stride, const int* __restrict__ step_base) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * 2 * T * 128];
-  f32_gemm_tile<MODE, NSTAGE, T, KU>(groups, tiles[blockIdx.x], mt_step(step, step_base), flags, arow0, i_override,
-                                     ksplits, split_stride, lds);
+  f32_gemm_tile<MODE, NSTAGE, T, KU, PROD>(groups, tiles[blockIdx.x], mt_step(step, step_base), flags, arow0, i_override,
+                                           ksplits, split_stride, lds);
 }
 
 // Backward of one layer in ONE launch (weight-gradient tiles, input-gradient tiles, and optionally the head
@@ -94,7 +94,15 @@ extern "C" int mt_gemm_f32_launch(int mode, const MtGemmGroup* groups, const MtT
       hipLaunchKernelGGL((mt_gemm_f32_kernel<2, __VA_ARGS__>), grid, block, 0, stream, groups, tiles, step, flags, arow0,       \
                          i_override, ksplits, split_stride, mt_step_base_tls);                                            \
   } while (0)
-  MT_F32_FORMS(MT_F32_GO)
+  if (flags & MT_GEMM_FLAG_BF16_PRODUCTS) {       // f32 operands, bf16 products (packs that train at autocast precision)
+    switch (tile_edge) {
+      case 128: { MT_F32_GO(2, 128, 1, 1); } break;
+      case 64: { MT_F32_GO(2, 64, 1, 1); } break;
+      default: { MT_F32_GO(2, 32, 1, 1); } break;
+    }
+  } else {
+    MT_F32_FORMS(MT_F32_GO)
+  }
 #undef MT_F32_GO
   return (int)hipGetLastError();
 }

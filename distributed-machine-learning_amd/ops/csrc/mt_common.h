@@ -84,6 +84,7 @@ struct MtTile {
 #define MT_GEMM_FLAG_RELU 1   // mode 0: ReLU after bias
 #define MT_GEMM_FLAG_MASK 1   // mode 1: multiply by (aux > 0)
 #define MT_GEMM_FLAG_DBIAS 1  // mode 2: also produce aux_out = column sums of A
+#define MT_GEMM_FLAG_BF16_PRODUCTS 0x100   // grouped f32 launches: round the operands to bf16 for the matrix instruction
 
 // ------------------------------------------------------------------------------------------------
 struct MtGatherSlot {

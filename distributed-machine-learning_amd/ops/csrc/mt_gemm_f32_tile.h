@@ -88,6 +88,59 @@ __device__ __forceinline__ void f32_mma_stage(f32x4 (&acc)[T / 32][T / 32], cons
   }
 }
 
+// The same stage with bf16 PRODUCTS (f32 operands in memory and LDS, f32 accumulation): the eight values a lane holds
+// per 16-row block and stage (kk = 4 g + e and 16 + 4 g + e) are rounded to bf16 and go through ONE
+// v_mfma_f32_16x16x32_bf16 -- the instruction contracts 32 kk in whatever order its two operands agree on -- in place of
+// eight v_mfma_f32_16x16x4_f32, at a sixteenth of their issue cycles.  The arithmetic of bf16 autocast with f32 outputs.
+template <int T, bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void f32_mma_stage_bf16(f32x4 (&acc)[T / 32][T / 32], const uint8_t* ldsA, const uint8_t* ldsB,
+                                                   int wr, int wc, int lane) {
+  constexpr int R = T / 32, W = T / 2;
+  const int g = lane >> 4, i = lane & 15;
+  bf16x8 af[R], bfr[R];
+#pragma unroll
+  for (int m = 0; m < R; ++m) {
+    const int mn = wr * W + m * 16 + i;
+    f32x4 v[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if constexpr (A_KMAJ) {
+        v[ks] = *reinterpret_cast<const f32x4*>(ldsA + f32_kmaj_off(mn, ks * 4 + g));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[ks][e] = *reinterpret_cast<const float*>(ldsA + f32_mnmaj_off<T>(ks * 16 + g * 4 + e, mn >> 2) + ((mn & 3) << 2));
+      }
+    }
+    const u32x4 pk = {pack_bf16x2(v[0][0], v[0][1]), pack_bf16x2(v[0][2], v[0][3]), pack_bf16x2(v[1][0], v[1][1]),
+                      pack_bf16x2(v[1][2], v[1][3])};
+    af[m] = __builtin_bit_cast(bf16x8, pk);
+  }
+#pragma unroll
+  for (int n = 0; n < R; ++n) {
+    const int mn = wc * W + n * 16 + i;
+    f32x4 v[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if constexpr (B_KMAJ) {
+        v[ks] = *reinterpret_cast<const f32x4*>(ldsB + f32_kmaj_off(mn, ks * 4 + g));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[ks][e] = *reinterpret_cast<const float*>(ldsB + f32_mnmaj_off<T>(ks * 16 + g * 4 + e, mn >> 2) + ((mn & 3) << 2));
+      }
+    }
+    const u32x4 pk = {pack_bf16x2(v[0][0], v[0][1]), pack_bf16x2(v[0][2], v[0][3]), pack_bf16x2(v[1][0], v[1][1]),
+                      pack_bf16x2(v[1][2], v[1][3])};
+    bfr[n] = __builtin_bit_cast(bf16x8, pk);
+  }
+#pragma unroll
+  for (int m = 0; m < R; ++m)
+#pragma unroll
+    for (int n = 0; n < R; ++n)
+      acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[n], af[m], acc[m][n], 0, 0, 0);
+}
+
 // Column sums of the MN-major A image (bias gradient): thread -> column (tid % T); TWO threads share a column (16 kk
 // rows each) for either tile edge, so the summation order -- and with it a trial's bias gradient, bit for bit -- does
 // not depend on which tile edge the size of its pack selected.  Threads >= 2T sit this out.
@@ -125,7 +178,9 @@ __device__ __forceinline__ void f32_wait_ahead(int ahead) {
 }
 
 // One T x T output tile.  ksplits > 1 (wgrad only): tile.ti carries the split index in bits 8..14.
-template <int MODE, int NSTAGE, int T, int KU = 1>
+// PROD: 0 = every product an f32 fused multiply-add (v_mfma_f32_16x16x4_f32); 1 = operands rounded to bf16 for the matrix
+// instruction (f32_mma_stage_bf16).
+template <int MODE, int NSTAGE, int T, int KU = 1, int PROD = 0>
 __device__ __forceinline__ void f32_gemm_tile(const MtGemmGroup* __restrict__ groups, const MtTile tile, int step,
                                               int flags, int arow0, int i_override, int ksplits, size_t split_stride,
                                               uint8_t* lds) {
@@ -184,7 +239,8 @@ __device__ __forceinline__ void f32_gemm_tile(const MtGemmGroup* __restrict__ gr
       if (it + 1 < n_it) f32_wait_vm<DMA_PER_TILE>();
       else f32_wait_vm<0>();
       __builtin_amdgcn_s_barrier();
-      f32_mma_stage<T, A_KMAJ, B_KMAJ>(acc, ldsA, ldsA + IMG, wr, wc, lane);
+      if constexpr (PROD == 1) f32_mma_stage_bf16<T, A_KMAJ, B_KMAJ>(acc, ldsA, ldsA + IMG, wr, wc, lane);
+      else f32_mma_stage<T, A_KMAJ, B_KMAJ>(acc, ldsA, ldsA + IMG, wr, wc, lane);
       if (want_db) db_acc += f32_colsum_stage<T>(ldsA, tid);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();

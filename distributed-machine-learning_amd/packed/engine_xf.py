@@ -48,6 +48,7 @@ MAX_LAYERS = 16
 HEAD_DIMS = (128, 64, 32, 16)          # fc1 .. fc4 outputs; fc5 maps the last to the prediction
 PE_SITE = 4000                         # dropout site of the positional encoding (layer sites are 8 l + k)
 FUSED_MAX_HEAD = 64                    # widest head (query / key or value) the fused attention kernels take
+GEMM_BF16_PRODUCTS = 0x100      # MT_GEMM_FLAG_BF16_PRODUCTS (csrc/mt_common.h)
 MAX_CHAINS = 4                         # concurrent training programs, one HIP stream each
 WGRAD_TARGET_TILES = 64                # weight gradients with fewer tiles than this split their contraction up to it
 
@@ -173,8 +174,8 @@ def supports(trainable: PackedTrainable, config: Optional[Dict] = None) -> Optio
         return "sequence data [N, S, F] is required"
     if X.shape[1] > 128:
         return "sequences longer than 128 tokens do not fit the attention kernels"
-    if trainable.dtype != "f32":
-        return "the program engine computes in f32"
+    if trainable.dtype not in ("f32", "bf16"):
+        return "the program engine computes in f32, or in f32 with bf16 matrix products ('bf16')"
     if config is not None:
         try:
             sp = xf_spec(trainable, config, int(X.shape[0]))
@@ -384,6 +385,9 @@ class XfPackEngine(PackEngine):
         self.t = trainable
         self.device = dev = torch.device(device)
         self.seed = int(seed or 0)
+        # dtype "bf16": parameters, activations, accumulation and every non-matrix kernel stay f32; the grouped GEMMs round
+        # their operands to bf16 for the matrix instruction (the arithmetic of bf16 autocast, with f32 outputs)
+        self.product_flag = GEMM_BF16_PRODUCTS if trainable.dtype == "bf16" else 0
         kw = trainable.model_kwargs
         self.max_d = int(kw.get("max_d_model", 512))
         self.max_layers = int(kw.get("max_layers", MAX_LAYERS))
@@ -683,7 +687,7 @@ class XfPackEngine(PackEngine):
             tiles = spread_tiles(shapes)
             nm = name()
             op(K_GEMM, len(tiles), self._upload(nm + "g", groups), self._upload(nm + "t", tiles), a=mode, b=edge, c=a_shared,
-               d=rows_kind, flags=flags, p2=stride)
+               d=rows_kind, flags=flags | self.product_flag, p2=stride)
             if sums:
                 tab = np.zeros(len(sums), dtype=SUM_DTYPE)
                 for j, (k, C0, off, n, ks, steps) in enumerate(sums):
@@ -1022,7 +1026,8 @@ class XfPackEngine(PackEngine):
             edge = 32
             tiles = _uniform_tiles(len(g), (r + edge - 1) // edge, (c + edge - 1) // edge)
             nm = name()
-            op(K_GEMM, len(tiles), self._upload(nm + "g", g), self._upload(nm + "t", tiles), a=mode, b=edge, c=0, d=2)
+            op(K_GEMM, len(tiles), self._upload(nm + "g", g), self._upload(nm + "t", tiles), a=mode, b=edge, c=0, d=2,
+               flags=self.product_flag)
 
         rows = np.zeros(T, dtype=ROW_DTYPE)
         for slot, s in wide_slots:

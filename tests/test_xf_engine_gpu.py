@@ -232,3 +232,36 @@ def test_a_space_outside_the_program_engine_runs_on_the_per_slot_engine():
                     local_dir=None, verbose=0, seed=1, metric="validation_mape", mode="min", device=torch.device("cuda"))
     assert an.stats["engine"] == "graph" and "engine_fallback" in an.stats
     assert all(np.isfinite(t.last_result["validation_mape"]) for t in an.trials)
+
+
+def test_bf16_products_track_the_f32_pack_and_keep_packing_invariance():
+    """``dtype="bf16"``: same parameters, activations and accumulation in f32, operands of the grouped GEMMs rounded to bf16
+    for the matrix instruction.  Losses follow the f32 pack within bf16 rounding, are not identical to it (the switch is in
+    force), and a trial's numbers still do not depend on its slot or neighbours."""
+    import dataclasses
+    tr32 = _trainable()
+    tr16 = dataclasses.replace(tr32, dtype="bf16")
+    packs = {}
+    for name, tr in (("f32", tr32), ("bf16", tr16)):
+        pack = _xf(tr)
+        for slot, (i, c) in zip((5, 0, 3, 2, 7, 1), enumerate(CONFIGS)):
+            pack.load(slot, 30 + i, c)
+        for _ in range(2):
+            pack.train_epoch()
+        packs[name] = (pack, pack.evaluate())
+    differs = 0
+    for slot in (5, 0, 3, 2, 7, 1):
+        a, b = packs["f32"][1][slot], packs["bf16"][1][slot]
+        for key in ("train_loss", "validation_loss", "validation_mape"):
+            assert np.isfinite(b[key])
+            assert abs(a[key] - b[key]) <= 0.08 * abs(a[key]) + 2e-3, (slot, key, a[key], b[key])
+        differs += a["validation_loss"] != b["validation_loss"]
+    assert differs >= 4
+    alone = _xf(tr16)
+    alone.load(4, 30 + 2, CONFIGS[2])
+    for _ in range(2):
+        alone.train_epoch()
+    assert alone.evaluate()[4] == packs["bf16"][1][3]
+    wa, wp = alone.export(4)["model"], packs["bf16"][0].export(3)["model"]
+    for k in wa:
+        assert torch.equal(wa[k], wp[k]), k
