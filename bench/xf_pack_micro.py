@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """One pack of the full search space on the program engine: host time to enqueue an epoch against the epoch's GPU time.
 
-    python bench/xf_pack_micro.py [--slots 16] [--max-layers 16] [--epochs 2] [--seed 0]
+    python bench/xf_pack_micro.py [--slots 16] [--max-layers 16] [--epochs 2] [--seed 0] [--dtype bf16]
 """
 import argparse
 import os
@@ -27,12 +27,13 @@ def main():
     ap.add_argument("--max-layers", type=int, default=16)
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: bf16 products in the grouped GEMMs")
     args = ap.parse_args()
     tl, vl = frames_to_loaders(synthetic_glucose_frame(96 * 2000, seed=7))
     space = dict(FULL_SPACE)
     space["num_encoder_layers"] = tune.choice([n for n in (2, 4, 6, 8, 12, 16) if n <= args.max_layers])
     tr = PackedTrainable(model="transformer", train=tuple(tl.dataset.tensors), val=tuple(vl.dataset.tensors), max_epochs=5,
-                         dtype="f32", capacity=args.slots, name="xf_micro",
+                         dtype=args.dtype, capacity=args.slots, name="xf_micro",
                          model_kwargs={"max_d_model": 512, "max_layers": args.max_layers, "max_dim_feedforward": 2048,
                                        "max_batch": 256})
     eng = XfPackEngine(tr, "cuda", args.slots, 0)

@@ -648,7 +648,9 @@ class XfPackEngine(PackEngine):
             if not recs:
                 return
             count = lambda e: sum(((r + e - 1) // e) * ((c + e - 1) // e) for _, _, r, c, _ in recs)      # noqa: E731
-            edge = 128 if count(128) >= OPTIONS.f32_small_tiles else 64
+            # bf16 products leave the tile bound by LDS reads and DMA instead of the matrix pipe: 128-tiles halve both per flop
+            big = OPTIONS.xf_bf16_big_tiles if self.product_flag else OPTIONS.f32_small_tiles
+            edge = 128 if count(128) >= big else 64
             if edge == 64 and count(64) < OPTIONS.f32_tiny_tiles:
                 edge = 32
             if mode == 2:
