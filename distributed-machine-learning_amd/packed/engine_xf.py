@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import ctypes as C
 import dataclasses
+import functools
 import math
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
@@ -331,6 +332,20 @@ def _uniform_tiles(n_groups: int, ti: int, tj: int) -> np.ndarray:
 
 
 def spread_tiles(shapes: List[Tuple[int, ...]]) -> np.ndarray:
+    """``_spread_tiles`` through a cache: the launches of a program repeat a few shape lists layer after layer, and most of
+    them survive a change of the pack (building the lists was 1.1 s of the 8.7 s full-workload search).  The result is
+    shared: read only."""
+    return _spread_tiles_cached(tuple(tuple(int(v) for v in x) for x in shapes))
+
+
+@functools.lru_cache(maxsize=8192)
+def _spread_tiles_cached(shapes: Tuple[Tuple[int, ...], ...]) -> np.ndarray:
+    out = _spread_tiles(list(shapes))
+    out.setflags(write=False)
+    return out
+
+
+def _spread_tiles(shapes: List[Tuple[int, ...]]) -> np.ndarray:
     """Tile list of a launch with few, very unequal groups (a pack of a dozen Transformer trials whose token counts and
     widths differ by orders of magnitude): ``shapes`` = (group, row tiles, column tiles[, contraction splits: one entry
     per split, index in the high byte of ``ti``]).  Workgroup ids go round-robin
@@ -370,9 +385,60 @@ def spread_tiles(shapes: List[Tuple[int, ...]]) -> np.ndarray:
     return out.reshape(-1)
 
 
+class _ArenaFull(Exception):
+    pass
+
+
+class _TableArena:
+    """The descriptor tables of one set of programs as ONE device buffer filled by ONE copy from a pinned host image.  A
+    16-layer pack has some 2 500 tables (group records, tile lists, per-slot records); uploaded one by one they were 0.2 s
+    of host time per change of the pack, with the GPU idle."""
+
+    def __init__(self, device: torch.device, capacity: int):
+        self.capacity = int(capacity)
+        self.host = torch.empty(self.capacity, dtype=torch.uint8).pin_memory()
+        self.image = self.host.numpy()
+        self.dev = torch.empty(self.capacity, dtype=torch.uint8, device=device)
+        self.used = 0
+        self.index: Dict[str, Tuple[int, int]] = {}
+        self.copied: Optional[torch.cuda.Event] = None
+
+    def reset(self) -> None:
+        if self.copied is not None:
+            self.copied.synchronize()        # the last copy out of the host image has been made
+        self.used, self.index = 0, {}
+
+    def put(self, name: str, arr: np.ndarray) -> int:
+        raw = arr.view(np.uint8).reshape(-1)
+        n = int(raw.size)
+        off = (self.used + 63) // 64 * 64
+        if off + n > self.capacity:
+            raise _ArenaFull()
+        self.image[off:off + n] = raw
+        self.index[name] = (off, n)
+        self.used = off + n
+        return self.dev.data_ptr() + off
+
+    def flush(self) -> None:
+        if self.used:
+            self.dev[:self.used].copy_(self.host[:self.used], non_blocking=True)
+            self.copied = torch.cuda.Event()
+            self.copied.record()
+
+    def update(self, name: str, arr: np.ndarray) -> int:
+        """Replace one table after the flush (the per-epoch tables): a small copy of its own, from a fresh host tensor."""
+        off, n = self.index[name]
+        raw = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy())
+        if raw.numel() != n:
+            raise ValueError(f"table {name!r} changed size")
+        self.dev[off:off + n].copy_(raw)
+        return self.dev.data_ptr() + off
+
+
 class XfPackEngine(PackEngine):
     name = "xf"
     move_cost_s = 0.01
+    prepare_is_cheap = True      # prepare() draws weights on the host: the executor may prepare for every slot that may free up
 
     def __init__(self, trainable: PackedTrainable, device: Any = "cuda", capacity: Optional[int] = None, seed: int = 0):
         why = supports(trainable)
@@ -431,6 +497,10 @@ class XfPackEngine(PackEngine):
         self.head_scratch = torch.zeros(int(self.lib.mt_head_scratch_floats(T, rows_max, HEAD_DIMS[-1])), device=dev)
         self.slots: Dict[int, _XSlot] = {}
         self._tables: Dict[str, Any] = {}
+        self._arenas: List[Optional[_TableArena]] = [None, None]      # the programs in force and the ones before them
+        self._arena: Optional[_TableArena] = None
+        self._arena_open = False
+        self._arena_turn = 0
         self._stage: Optional[torch.Tensor] = None
         self._dirty = True
         self._chains: List[Dict[str, Any]] = []
@@ -442,6 +512,10 @@ class XfPackEngine(PackEngine):
         self._table = torch.zeros(T + 1, 6, device=dev, dtype=torch.float64)
         self._stamps = torch.zeros(2, device=dev, dtype=torch.int64)
         self.prepared_total = 0
+        self._prepared: Dict[int, Tuple[Dict, torch.Tensor]] = {}      # trial index -> (config, parameter image on the host)
+        self._meta_host: Optional[torch.Tensor] = None
+        self._meta_copied: List[Optional[torch.cuda.Event]] = [None, None]
+        self._meta_turn = 0
 
     # ------------------------------------------------------------------ slot management
     def occupied(self) -> List[int]:
@@ -513,6 +587,23 @@ class XfPackEngine(PackEngine):
         s.epoch, s.step = 0, 0
         return s
 
+    def prepare(self, trial_index, config) -> bool:
+        """Draw a coming trial's initial weights and lay them out as its parameter image on the host (the executor calls
+        this once an epoch and its validation are enqueued: the GPU is still busy); ``load`` then only copies the image.
+        Returns False when the cache is full."""
+        key = int(trial_index)
+        if key in self._prepared:
+            return True
+        if len(self._prepared) >= self.capacity:
+            return False
+        spec = self._spec(config)
+        lay = XfLayout(self.F, self.fpad, spec)
+        image = torch.zeros(lay.total, dtype=torch.float32)
+        self._pack(lay, self._initial_state(config, trial_index), image)
+        self._prepared[key] = (dict(config), image)
+        self.prepared_total += 1
+        return True
+
     def load(self, slot, trial_index, config, state=None):
         if slot in self.slots:
             raise RuntimeError(f"slot {slot} is occupied")
@@ -520,6 +611,13 @@ class XfPackEngine(PackEngine):
         n = s.layout.total
         for slab in (self.M, self.V, self.G):
             self._region(slab, slot)[:n].zero_()
+        ready = self._prepared.pop(int(trial_index), None)
+        if ready is not None and state is None and ready[0] == dict(config):
+            self._region(self.P, slot)[:n].copy_(ready[1][:n])
+            self.loss_acc[slot] = 0
+            self.slots[slot] = s
+            self._dirty = True
+            return
         if state is not None and "model" in state:
             self._write_params(slot, s.layout, state["model"], self.P)
             opt = state.get("optimizer") or {}
@@ -571,6 +669,11 @@ class XfPackEngine(PackEngine):
 
     # ------------------------------------------------------------------ descriptor tables
     def _upload(self, name: str, arr: np.ndarray) -> int:
+        if self._arena is not None:
+            if self._arena_open:
+                return self._arena.put(name, arr)
+            if name in self._arena.index:
+                return self._arena.update(name, arr)
         host = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy())
         t = self._tables.get(name)
         if isinstance(t, torch.Tensor) and t.numel() == host.numel():
@@ -1076,10 +1179,25 @@ class XfPackEngine(PackEngine):
         while len(groups) > MAX_CHAINS:
             groups[-2] = groups[-2] + groups[-1]
             groups.pop()
-        self._chains = [self._compile(False, g, f"t{c}_") for c, g in enumerate(groups)]
+        self._arena_turn ^= 1
+        capacity = self._arenas[self._arena_turn].capacity if self._arenas[self._arena_turn] is not None else (8 << 20)
+        while True:
+            arena = self._arenas[self._arena_turn]
+            if arena is None or arena.capacity < capacity:
+                arena = self._arenas[self._arena_turn] = _TableArena(self.device, capacity)
+            arena.reset()
+            self._arena, self._arena_open = arena, True
+            try:
+                self._chains = [self._compile(False, g, f"t{c}_") for c, g in enumerate(groups)]
+                self._eval = self._compile(True)
+                break
+            except _ArenaFull:
+                capacity *= 2
+            finally:
+                self._arena_open = False
+        arena.flush()
         while len(self._streams) < len(self._chains) - 1:
             self._streams.append(torch.cuda.Stream(self.device))
-        self._eval = self._compile(True)
         self._dirty = False
 
     def _epoch_tables(self) -> int:
@@ -1165,7 +1283,22 @@ class XfPackEngine(PackEngine):
         if self.slots:
             self._enqueue_eval()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        L.check(self.lib.mt_metric_table_launch(self._upload("table_meta", meta), self.loss_acc.data_ptr(),
+        # through a pinned image and a posted copy: a blocking upload would hold the host until the whole round has run,
+        # and the host has the next trials to prepare meanwhile (the image is rewritten a round later, after the table
+        # has been read back)
+        raw = meta.view(np.uint8).reshape(-1)
+        if self._meta_host is None or self._meta_host.shape[1] != raw.size:
+            self._meta_host = torch.empty(2, raw.size, dtype=torch.uint8).pin_memory()
+            self._meta_copied = [None, None]
+            self._tables["table_meta"] = torch.empty(raw.size, dtype=torch.uint8, device=self.device)
+        k = self._meta_turn = self._meta_turn ^ 1
+        if self._meta_copied[k] is not None:
+            self._meta_copied[k].synchronize()      # rounds may be in flight (asynchronous exchange): two images, each reused
+        self._meta_host[k].numpy()[:] = raw         # only once its last copy has been made
+        self._tables["table_meta"].copy_(self._meta_host[k], non_blocking=True)
+        self._meta_copied[k] = torch.cuda.Event()
+        self._meta_copied[k].record()
+        L.check(self.lib.mt_metric_table_launch(self._tables["table_meta"].data_ptr(), self.loss_acc.data_ptr(),
                                                 self.metrics.data_ptr(), T, max(self.n_val, 1), len(self.slots),
                                                 self._stamps.data_ptr(), self._table.data_ptr(), stream),
                 "mt_metric_table_launch")

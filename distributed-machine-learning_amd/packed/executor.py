@@ -543,7 +543,12 @@ class PackedExecutor(Executor):
         it.  Only trials the runner can name in advance without changing the search (already pending, or drawn from a
         searcher that does not look at results)."""
         sure = sum(1 for tr in self._live.values() if tr.training_iteration + 1 >= self.t.max_epochs)
-        want = min(self.capacity, max(sure, self._retired_last))
+        # ... or, for an engine whose preparation is host arithmetic only (no capture, nothing on the device), as many as
+        # the scheduler may stop when this epoch's results arrive: what is prepared too early waits in the engine's cache
+        may_stop = 0
+        if getattr(self.engine, "prepare_is_cheap", False):
+            may_stop = sum(1 for tr in self._live.values() if self.runner.decides_at(tr.training_iteration + 1))
+        want = min(self.capacity, max(sure, self._retired_last, may_stop))
         if want <= 0:
             return
         done = 0
