@@ -2,7 +2,11 @@
 """Microseconds per optimiser step of a small exact-f32 MLP pack: the 16 survivors of the headline search (their widths
 and batch sizes as the seed-0 search of bench.py produces them) trained by tile launches and by the row-block step.
 
-    python bench/small_pack_micro.py [--rows 250000] [--forms 0,1] [--epochs 2]
+    python bench/small_pack_micro.py [--rows 250000] [--forms 0,1s1,1s2,1s4] [--epochs 2]
+
+A form is the ``rowblock`` option ("0": tile launches, "1": row blocks), optionally followed by ``s<n>``: the most
+workgroups that may share one row block (``rowblock_split``), ``c<cost>``: the exchange cost the split rule assumes,
+``b<n>``: the most workgroups a split work list may hold.
 """
 from __future__ import annotations
 
@@ -57,8 +61,16 @@ def main():
         from mitune.ops import lib as L
         prof = torch.zeros(4096 * 16, device=dev, dtype=torch.int64)
         L.load().mt_rowblock_set_prof(C.c_void_p(prof.data_ptr()))
+    import re
     for form in args.forms.split(","):
-        OPTIONS.rowblock = form
+        m = re.fullmatch(r"([01a-z]+?)(?:s(\d+))?(?:c(\d+))?(?:b(\d+))?", form)
+        OPTIONS.rowblock = m.group(1)
+        if m.group(2):
+            OPTIONS.rowblock_split = int(m.group(2))
+        if m.group(3):
+            OPTIONS.rowblock_split_cost = int(m.group(3))
+        if m.group(4):
+            OPTIONS.rowblock_wg_budget = int(m.group(4))
         tr = PackedTrainable(train=train, val=val, max_epochs=args.epochs, engine="hip", dtype="f32", capacity=args.slots,
                              val_chunk=4096, model_kwargs={"max_width": 512, "max_layers": 3, "max_batch": 1024})
         eng = engine_hip.HipPackEngine(tr, device=dev, capacity=args.slots, seed=0)
@@ -77,8 +89,9 @@ def main():
         out[form] = {"s_per_epoch": dt / args.epochs, "us_per_step": dt / (args.epochs * steps) * 1e6, "steps_per_epoch": steps,
                      "chains": [len(ch.ids) for ch in eng._chains],
                      "rb_blocks": [int(ch.plan.rb_nblocks) for ch in eng._chains],
+                     "rb_split": [eng._rowblock_split(ch.ids, int(ch.plan.rb_mt)) for ch in eng._chains if ch.plan.rb_nblocks],
                      "val_mse_slot0": ev[0]["validation_mse"], "val_mse_slot3": ev[3]["validation_mse"] if 3 in ev else None}
-        if prof is not None and form != "0":
+        if prof is not None and OPTIONS.rowblock != "0":
             import numpy as np
             blocks = eng._tables[eng._chains[0].tag + "rb_blocks"].cpu().numpy().view(np.int32).reshape(-1, 2)
             st = prof.cpu().numpy().reshape(-1, 16)[:len(blocks)]
@@ -86,6 +99,7 @@ def main():
             for b, (slot, row0) in enumerate(blocks):
                 if slot < 0 or st[b, 0] == 0:
                     continue
+                row0 &= 0xFFFFF
                 v = st[b][st[b] > 0]
                 rows.append((int(slot), int(row0), [int(x - v[0]) for x in v]))
             by_slot = {}

@@ -73,6 +73,7 @@ struct RbPhase {
   rb_gcf bias;           // forward only
   rb_gf out;             // memory copy of the output rows, [B][ldo] (null: not needed)
   int ldw, ldo, N, K, ns, nn, tv, layer;
+  int tbase;             // first 16-column tile of this workgroup's share of the layer (0 unless the block is split)
   int depth;             // K-steps (of 16) the wave's ring holds for this layer's tile count
   uint32_t lane_off;     // byte offset of this lane's 16-byte piece inside a fragment's source block
 };
@@ -80,7 +81,8 @@ struct RbPhase {
 // Every layer width and the input row length are multiples of 32 (the caller checks): a K-step is always whole and a
 // layer has an even number of 16-column tiles.  CAP: fragments of the wave's ring.
 template <int NW, int TPW, int CAP>
-__device__ __forceinline__ void rb_make_phase(RbPhase& ph, const MtGemmGroup& g, int nn, int layer, int wave, int lane) {
+__device__ __forceinline__ void rb_make_phase(RbPhase& ph, const MtGemmGroup& g, int nn, int layer, int wave, int lane,
+                                              int part, int nparts) {
   ph.W = (rb_gcc)rb_uniform64((uint64_t)g.B);
   ph.bias = nn ? nullptr : (rb_gcf)rb_uniform64((uint64_t)g.aux);
   ph.out = (rb_gf)rb_uniform64((uint64_t)g.C);
@@ -91,7 +93,8 @@ __device__ __forceinline__ void rb_make_phase(RbPhase& ph, const MtGemmGroup& g,
   ph.ns = ph.K >> 4;
   ph.nn = nn;
   ph.layer = layer;
-  const int ntp = ph.N >> 4;
+  const int ntp = (ph.N >> 4) / nparts;              // tiles of this workgroup: [tbase, tbase + ntp)
+  ph.tbase = part * ntp;
   int tv = (ntp - wave + NW - 1) / NW;
   ph.tv = tv < 0 ? 0 : (tv > TPW ? TPW : tv);
   ph.depth = ph.tv > 0 ? CAP / ph.tv : 0;
@@ -144,7 +147,7 @@ template <int NW>
 __device__ __forceinline__ void rb_issue_stage(const RbPhase& ph, uint8_t* ring, int stage, int s, int wave) {
   uint8_t* dst = ring + stage * ph.tv * RB_FRAG;
   for (int t = 0; t < ph.tv; ++t) {
-    const int c0 = (wave + NW * t) * 16;
+    const int c0 = (ph.tbase + wave + NW * t) * 16;
     const size_t elem = ph.nn ? (size_t)(s * 16) * ph.ldw + c0 : (size_t)c0 * ph.ldw + s * 16;      // wave-uniform
     rb_gcc src = ph.W + elem * 4 + (uint64_t)ph.lane_off;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -293,7 +296,7 @@ __device__ __forceinline__ void rb_head_fetch(RbHeadRegs& hr, const MtHeadSlot& 
 
 template <int MT>
 __device__ __forceinline__ void rb_head(const RbHeadRegs& hr, const MtHeadSlot& hs, uint8_t* act, float (*red)[4][RB_MAXW],
-                                        float (*red_s)[4][2], int row0, int wave, int lane) {
+                                        float (*red_s)[4][2], int row0, int wave, int lane, bool to_mem) {
   if (wave >= 4 * MT) return;
   const int m = wave >> 2, hw = wave & 3;
   const int crow0 = row0 + 16 * m;
@@ -337,9 +340,11 @@ __device__ __forceinline__ void rb_head(const RbHeadRegs& hr, const MtHeadSlot& 
       }
       *reinterpret_cast<f32x4*>(p0) = f32x4{o[0], o[1], o[2], o[3]};
       *reinterpret_cast<f32x4*>(p1) = f32x4{o[4], o[5], o[6], o[7]};
-      rb_gf dst = (rb_gf)hs.dH + (size_t)(crow0 + r) * hs.ldh + k0;
-      *(rb_g4)dst = f32x4{o[0], o[1], o[2], o[3]};
-      *(rb_g4)(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      if (to_mem) {
+        rb_gf dst = (rb_gf)hs.dH + (size_t)(crow0 + r) * hs.ldh + k0;
+        *(rb_g4)dst = f32x4{o[0], o[1], o[2], o[3]};
+        *(rb_g4)(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      }
     }
   }
 #pragma unroll
@@ -376,18 +381,93 @@ __device__ __forceinline__ int rb_opaque(int v) {
 
 // Outputs of the wave's tiles -> the LDS image (in place of the layer's input), between two barriers.
 template <int MT>
-__device__ __forceinline__ void rb_store_image(const f32x4 (&acc)[RbCfg<MT>::TPW][MT], uint8_t* act, int tv, int wave, int lane) {
+__device__ __forceinline__ void rb_store_image(const f32x4 (&acc)[RbCfg<MT>::TPW][MT], uint8_t* act, int tv, int tbase, int wave,
+                                               int lane, bool last_barrier = true) {
   rb_lds_barrier();          // every wave has read the layer's input for the last time
   const int i = rb_opaque(lane & 15), g = lane >> 4;
 #pragma unroll
   for (int t = 0; t < RbCfg<MT>::TPW; ++t) {
     if (t < tv) {
-      const int col = (wave + RbCfg<MT>::NW * t) * 16 + 4 * g;
+      const int col = (tbase + wave + RbCfg<MT>::NW * t) * 16 + 4 * g;
 #pragma unroll
       for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(act + rb_act_off(m * 16 + i, col)) = acc[t][m];
     }
   }
-  rb_lds_barrier();          // the output image is complete
+  if (last_barrier) rb_lds_barrier();          // the output image is complete
+}
+
+// ---- split blocks: nparts workgroups (2 or 4) share one row block, each computing 1 / nparts of every layer's output
+// columns (a quarter or half of the weights to stream and of the matrix instructions per workgroup).  After a layer each
+// part needs the others' columns: they are in memory already (the weight-gradient launch reads H and dZ from there), so
+// the exchange is a flag per workgroup.  A part publishes boundary number `seq` (counting up through the epoch: the
+// engine zeroes the flags before an epoch's first step) once its stores are visible to the device, waits for its
+// partners' flags to reach `seq`, and copies their columns into its LDS image.  The partners of a block sit 8 entries
+// apart in the work list (same XCD under round-robin dispatch, consecutive in that XCD's dispatch order), and the engine
+// never lists more workgroups than fit the chip at once, so a waiting part's partner is running or next in line.  The
+// wait is bounded all the same: after RB_SPIN_LIMIT polls a part raises the error word behind the flags and goes on
+// with whatever is in memory -- the grid always drains, and the engine refuses the epoch's results.
+#define RB_SPIN_LIMIT (1 << 22)
+// Device-scope accesses (sc1): the store is written through the XCD's L2, the load is not served from a cache that another
+// XCD's stores do not reach.  Only the exchanged columns and the flags travel this way; a cache write-back / invalidate
+// fence per boundary would also throw out the weights every workgroup of the XCD is streaming (measured: 45 us per
+// boundary).  The asm loads are not tracked by the compiler's wait counters: rb_exchange waits for them itself.
+__device__ __forceinline__ void rb_store4_dev(rb_g4 p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void rb_load4_dev(f32x4& v, rb_gc4 p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+}
+
+template <int MT>
+__device__ __forceinline__ void rb_exchange(const MtRbArgs& a, int part, int nparts, int seq, rb_gcf out, int ldo, int N, int row0,
+                                            int B, uint8_t* act, int tid, int wave, int lane) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's output stores are acknowledged, its image rows written
+  __builtin_amdgcn_s_barrier();
+  if (wave == 0) {
+    if (lane == 0) __hip_atomic_store(a.flags + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < nparts && lane != part) {
+      const int32_t* f = a.flags + ((int)blockIdx.x + (lane - part) * 8);
+      int spins = 0;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > RB_SPIN_LIMIT) {
+          __hip_atomic_store(a.flags + a.n_flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_s_barrier();
+  const int wq = N / nparts;                 // columns per part
+  const int cpr = (N - wq) >> 2;             // 16-byte chunks of the other parts' columns per row
+  const int total = 16 * MT * cpr;           // at most 16 MT x 96 chunks: RB_XCH per thread
+  constexpr int RB_XCH = (16 * MT * (RB_MAXW * 3 / 16) + RbCfg<MT>::THREADS - 1) / RbCfg<MT>::THREADS;
+  f32x4 v[RB_XCH];
+  int off[RB_XCH];
+#pragma unroll
+  for (int u = 0; u < RB_XCH; ++u) {
+    const int idx = tid + u * RbCfg<MT>::THREADS;
+    off[u] = -1;
+    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (idx < total) {
+      const int r = idx / cpr;
+      int k = (idx - r * cpr) * 4;
+      if (k >= part * wq) k += wq;           // step over this part's own columns
+      if (row0 + r < B) {
+        off[u] = rb_act_off(r, k);
+        rb_load4_dev(v[u], (rb_gc4)(out + (size_t)(row0 + r) * ldo + k));
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < RB_XCH; ++u) asm volatile("" : "+v"(v[u]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < RB_XCH; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+  for (int u = 0; u < RB_XCH; ++u)
+    if (off[u] >= 0) *reinterpret_cast<f32x4*>(act + off[u]) = v[u];
+  rb_lds_barrier();
 }
 
 // LDS of one workgroup: the activation image, the ReLU masks of every layer (one byte per tile and lane), the head's
@@ -405,9 +485,13 @@ __global__ __launch_bounds__(RbCfg<MT>::THREADS) void mt_mlp_rowblock_kernel(MtR
   static_assert(HL_ROWS == 16, "one head record per 16-row MFMA row tile");
 
   const int step = mt_step(step_imm, step_base);
+  int seq = step * 32;                          // exchange boundaries of a split block count up from here
   const MtRbBlock blk = a.blocks[blockIdx.x];
   if (blk.slot < 0) return;
-  const int slot = blk.slot, row0 = blk.row0;
+  // row0 carries the split in its upper bits: part index (bits 20-23) and number of parts (bits 24-27; 0 reads as 1)
+  const int slot = blk.slot, row0 = blk.row0 & 0xFFFFF;
+  const int part = __builtin_amdgcn_readfirstlane((blk.row0 >> 20) & 15);
+  const int nparts = __builtin_amdgcn_readfirstlane(((blk.row0 >> 24) & 15) > 1 ? ((blk.row0 >> 24) & 15) : 1);
   const MtHeadSlot hs = a.head[slot];
   if (step >= hs.active_steps || row0 >= hs.B) return;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -428,7 +512,7 @@ __global__ __launch_bounds__(RbCfg<MT>::THREADS) void mt_mlp_rowblock_kernel(MtR
   RbPhase cur;
   {
     const MtGemmGroup g0 = a.fwd[0][slot];
-    rb_make_phase<NW, TPW, CAP>(cur, g0, 0, 0, wave, lane);
+    rb_make_phase<NW, TPW, CAP>(cur, g0, 0, 0, wave, lane, part, nparts);
     rb_prologue<NW>(cur, ring, wave);
     // the block's input rows -> LDS image (zero beyond the batch, as the tile kernel's staging does)
     rb_gcf X = (rb_gcf)rb_uniform64((uint64_t)g0.A);
@@ -450,8 +534,8 @@ __global__ __launch_bounds__(RbCfg<MT>::THREADS) void mt_mlp_rowblock_kernel(MtR
   // ---- forward layers: H_l = relu(H_{l-1} W_l^T + b_l)
   for (int l = 0; l < L; ++l) {
     RbPhase nxt = {};
-    if (l + 1 < L) rb_make_phase<NW, TPW, CAP>(nxt, a.fwd[l + 1][slot], 0, l + 1, wave, lane);
-    else if (L > 1) rb_make_phase<NW, TPW, CAP>(nxt, a.dgrad[L - 1][slot], 1, L - 1, wave, lane);
+    if (l + 1 < L) rb_make_phase<NW, TPW, CAP>(nxt, a.fwd[l + 1][slot], 0, l + 1, wave, lane, part, nparts);
+    else if (L > 1) rb_make_phase<NW, TPW, CAP>(nxt, a.dgrad[L - 1][slot], 1, L - 1, wave, lane, part, nparts);
     const int i = rb_opaque(lane & 15), g = lane >> 4;
     // bias of the wave's tiles (the array is padded with zeros to a multiple of 8 columns), waited for before the next
     // layer's fragments are requested
@@ -459,7 +543,7 @@ __global__ __launch_bounds__(RbCfg<MT>::THREADS) void mt_mlp_rowblock_kernel(MtR
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       bb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int col = (wave + NW * t) * 16 + 4 * g;
+      const int col = (cur.tbase + wave + NW * t) * 16 + 4 * g;
       if (cur.bias != nullptr && t < cur.tv) bb[t] = *(rb_gc4)(cur.bias + col);
     }
     rb_run_kloop<MT, false, CAP>(acc, cur, act, ring, wave, lane);
@@ -468,11 +552,12 @@ __global__ __launch_bounds__(RbCfg<MT>::THREADS) void mt_mlp_rowblock_kernel(MtR
     for (int t = 0; t < TPW; ++t) asm volatile("" : "+v"(bb[t]));
     rb_prologue<NW>(nxt, ring, wave);
 
-    const bool to_mem = cur.out != nullptr && l + 1 < L;     // H of the last layer is consumed by the head below, from LDS
+    // H of the last layer is consumed by the head below, from LDS -- unless the block is split: then it travels
+    const bool to_mem = cur.out != nullptr && (l + 1 < L || nparts > 1);
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       if (t < cur.tv) {
-        const int tile = wave + NW * t;
+        const int tile = cur.tbase + wave + NW * t;
         const int col = tile * 16 + 4 * g;
         uint32_t bits = 0u;
 #pragma unroll
@@ -485,26 +570,31 @@ __global__ __launch_bounds__(RbCfg<MT>::THREADS) void mt_mlp_rowblock_kernel(MtR
           }
           acc[t][m] = v;
           const int row = row0 + m * 16 + i;
-          if (to_mem && row < hs.B) *(rb_g4)(cur.out + (size_t)row * cur.ldo + col) = v;
+          if (to_mem && row < hs.B) {
+            if (nparts > 1) rb_store4_dev((rb_g4)(cur.out + (size_t)row * cur.ldo + col), v);
+            else *(rb_g4)(cur.out + (size_t)row * cur.ldo + col) = v;
+          }
         }
         mask[(l * (RB_MAXW / 16) + tile) * 64 + lane] = (uint8_t)bits;
       }
     }
-    rb_store_image<MT>(acc, act, cur.tv, wave, lane);
+    rb_store_image<MT>(acc, act, cur.tv, cur.tbase, wave, lane, nparts == 1);
+    if (nparts > 1) rb_exchange<MT>(a, part, nparts, ++seq, cur.out, cur.ldo, cur.N, row0, hs.B, act, tid, wave, lane);
     stamp();
     cur = nxt;
   }
 
   // ---- head, loss, dLoss/dH of the last layer (left in the image)
-  rb_head<MT>(hr, hs, act, red, red_s, row0, wave, lane);
+  // (every part of a split block runs the head on the whole rows: each needs dLoss/dH of all columns; part 0 writes)
+  rb_head<MT>(hr, hs, act, red, red_s, row0, wave, lane, part == 0);
   rb_lds_barrier();
-  rb_head_record<MT>(hs, a, slot, red, red_s, row0, wave, lane);
+  if (part == 0) rb_head_record<MT>(hs, a, slot, red, red_s, row0, wave, lane);
   stamp();
 
   // ---- input gradients: dZ_{l-1} = (dZ_l W_l) * (H_{l-1} > 0), l = L-1 .. 1
   for (int l = L - 1; l >= 1; --l) {
     RbPhase nxt = {};
-    if (l > 1) rb_make_phase<NW, TPW, CAP>(nxt, a.dgrad[l - 1][slot], 1, l - 1, wave, lane);
+    if (l > 1) rb_make_phase<NW, TPW, CAP>(nxt, a.dgrad[l - 1][slot], 1, l - 1, wave, lane, part, nparts);
     rb_run_kloop<MT, true, CAP>(acc, cur, act, ring, wave, lane);
     stamp();
     rb_prologue<NW>(nxt, ring, wave);
@@ -512,7 +602,7 @@ __global__ __launch_bounds__(RbCfg<MT>::THREADS) void mt_mlp_rowblock_kernel(MtR
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       if (t < cur.tv) {
-        const int tile = wave + NW * t;
+        const int tile = cur.tbase + wave + NW * t;
         const int col = tile * 16 + 4 * g;
         const uint32_t bits = mask[((l - 1) * (RB_MAXW / 16) + tile) * 64 + lane];
 #pragma unroll
@@ -522,11 +612,17 @@ __global__ __launch_bounds__(RbCfg<MT>::THREADS) void mt_mlp_rowblock_kernel(MtR
           for (int j = 0; j < 4; ++j) v[j] = ((bits >> (m * 4 + j)) & 1u) ? v[j] : 0.f;
           acc[t][m] = v;
           const int row = row0 + m * 16 + i;
-          if (cur.out != nullptr && row < hs.B) *(rb_g4)(cur.out + (size_t)row * cur.ldo + col) = v;
+          if (cur.out != nullptr && row < hs.B) {
+            if (nparts > 1) rb_store4_dev((rb_g4)(cur.out + (size_t)row * cur.ldo + col), v);
+            else *(rb_g4)(cur.out + (size_t)row * cur.ldo + col) = v;
+          }
         }
       }
     }
-    if (l > 1) rb_store_image<MT>(acc, act, cur.tv, wave, lane);      // the last input gradient is read by nobody in here
+    if (l > 1) {                                                       // the last input gradient is read by nobody in here
+      rb_store_image<MT>(acc, act, cur.tv, cur.tbase, wave, lane, nparts == 1);
+      if (nparts > 1) rb_exchange<MT>(a, part, nparts, ++seq, cur.out, cur.ldo, cur.N, row0, hs.B, act, tid, wave, lane);
+    }
     stamp();
     cur = nxt;
   }
@@ -545,7 +641,8 @@ extern "C" int mt_rowblock_max_width() { return RB_MAXW; }
 extern "C" int mt_mlp_rowblock_launch(const MtRbArgs* args, int n_blocks, int mt, int step, hipStream_t stream) {
   if (n_blocks <= 0) return 0;
   if (args == nullptr || args->n_hidden < 1 || args->n_hidden > MT_MAX_LAYERS || args->blocks == nullptr ||
-      args->head == nullptr || args->scratch == nullptr || args->rec < 10 || args->max_chunks < 1)
+      args->head == nullptr || args->scratch == nullptr || args->rec < 10 || args->max_chunks < 1 ||
+      (args->flags != nullptr && args->n_flags < n_blocks))
     return -2;
   MtRbArgs a = *args;
   a.prof = rb_prof_buffer;

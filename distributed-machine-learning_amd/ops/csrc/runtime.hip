@@ -99,6 +99,15 @@ struct MtMlpPlan {
   const MtGemmGroup* wg_all_groups;
   const MtTile* wg_all_tiles;
   int32_t wg_all_ntiles, wg_all_edge;
+  int32_t* rb_flags;      // exchange flags of split row blocks: rb_nflags + 1 words (null: no block is split)
+  // Later phases of an epoch: once the trials with the largest batches have run out of steps, the chain continues on a
+  // work list without them (and with the freed CUs given to further splits).  List k serves steps >= rb_ph_from[k]
+  // (ascending; rb_ph_nblocks[k] == 0 ends the table).  Steps whose number is only known on the device (captured
+  // blocks) stay on the first list, which holds every trial.
+  const MtRbBlock* rb_ph_blocks[3];
+  int32_t rb_ph_nblocks[3];
+  int32_t rb_ph_from[3];
+  int32_t rb_nflags, rb_pad;
 };
 
 thread_local const int* mt_step_base_tls = nullptr;
@@ -154,13 +163,22 @@ static int mlp_enqueue_steps(const MtMlpPlan* p, int step0, int nsteps, hipStrea
     MtRbArgs ra = {};
     for (int l = 0; l < L; ++l) { ra.fwd[l] = p->fwd_groups[l]; ra.dgrad[l] = p->dgrad_groups[l]; }
     ra.head = p->head;
-    ra.blocks = p->rb_blocks;
+    ra.flags = p->rb_flags;
+    ra.n_flags = p->rb_nflags;
     ra.scratch = p->head_scratch;
     ra.n_hidden = L;
     ra.max_chunks = hr.max_chunks;
     ra.rec = hr.rec;
     for (int step = step0; step < step0 + nsteps; ++step) {
-      MT_TRY(mt_mlp_rowblock_launch(&ra, p->rb_nblocks, p->rb_mt, step, stream));
+      ra.blocks = p->rb_blocks;
+      int nblocks = p->rb_nblocks;
+      if (mt_step_base_tls == nullptr)
+        for (int k = 0; k < 3 && p->rb_ph_nblocks[k] > 0 && step >= p->rb_ph_from[k]; ++k) {
+          ra.blocks = p->rb_ph_blocks[k];
+          nblocks = p->rb_ph_nblocks[k];
+        }
+      if (ra.flags != nullptr && nblocks > ra.n_flags) return -18;
+      MT_TRY(mt_mlp_rowblock_launch(&ra, nblocks, p->rb_mt, step, stream));
       MT_TRY(mt_gemm_f32_bwd_head_launch(p->wg_all_groups, p->wg_all_tiles, p->wg_all_ntiles, nullptr, nullptr, 0, step,
                                          p->ksplits, p->gsplit_stride, f32_edge(p->wg_all_edge), hr, stream));
       MT_TRY(mt_optim_gather_launch(p->P, p->G, p->M, p->V, p->Pb, p->slot_stride, p->opt, p->active_ids, p->n_active,

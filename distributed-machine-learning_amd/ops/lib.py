@@ -69,7 +69,9 @@ class MlpPlan(C.Structure):
                 ("fwd_big", c_int32 * MT_MAX_LAYERS), ("bwd_big", c_int32 * MT_MAX_LAYERS),
                 ("rb_blocks", c_void_p), ("rb_nblocks", c_int32), ("rb_mt", c_int32),
                 ("wg_all_groups", c_void_p), ("wg_all_tiles", c_void_p), ("wg_all_ntiles", c_int32),
-                ("wg_all_edge", c_int32)]
+                ("wg_all_edge", c_int32), ("rb_flags", c_void_p),
+                ("rb_ph_blocks", c_void_p * 3), ("rb_ph_nblocks", c_int32 * 3), ("rb_ph_from", c_int32 * 3),
+                ("rb_nflags", c_int32), ("rb_pad", c_int32)]
 
 
 class DpPlan(C.Structure):

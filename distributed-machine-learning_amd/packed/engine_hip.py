@@ -36,6 +36,7 @@ from ..train.optim import OPT_CODES
 
 TILE = 128
 N_XCD = 8
+N_CU = 256
 MAX_KSPLITS = 4        # weight-gradient slabs kept per slot (split-K over the batch for small packs)
 MAX_STREAMS = 4        # concurrent step chains, one HIP stream each
 BIG_TILE = 256         # tile edge of the throughput-form GEMM kernels
@@ -232,6 +233,7 @@ class HipPackEngine(PackEngine):
         self.slots: Dict[int, _HSlot] = {}
         self._stage: Optional[torch.Tensor] = None
         self._tables: Dict[str, Any] = {}
+        self._rb_flags: Dict[str, torch.Tensor] = {}      # chain tag -> exchange flags of its split row blocks
         self._dirty = True
         # Optional concurrent chains: trials are independent, so a pack can be split into up to MAX_STREAMS chains on
         # separate HIP streams.  One host thread cannot feed several chains kernel by kernel (a launch costs ~3.5 us
@@ -598,32 +600,112 @@ class HipPackEngine(PackEngine):
             return 2
         return 1
 
-    def _rowblock_blocks(self, ids: List[int], mt: int, tag: str) -> Tuple[int, int]:
-        """(device pointer, count) of the row-block work list: one (slot, first row) entry per workgroup.  All blocks of a
-        trial go to one XCD (workgroup b runs on XCD b % 8; they stream the same weights from that XCD's L2), trials are
-        dealt to the XCDs heaviest first, each to the XCD with the least work so far, and an XCD's list starts with its
-        heaviest blocks, so that the long chains start first and the short ones fill in behind them."""
+    def _rowblock_split(self, ids: List[int], mt: int) -> Dict[int, int]:
+        """Workgroups per 16-row block for every slot of a chain (1, 2 or 4).  A block's chain of layers runs on one CU, and
+        a step is as long as the longest chain; splitting a block over n workgroups cuts its weight stream and matrix
+        instructions by n at the price of one exchange through memory per layer boundary.  Greedy: the slot with the
+        longest chain is split further while that shortens it and the work list still fits the chip in one go (one
+        workgroup per CU: the parts of a block wait for each other, so all of them must be running)."""
+        parts = {slot: 1 for slot in ids}
+        if mt != 1 or OPTIONS.rowblock_split <= 1:
+            return parts
+        rows = ROWBLOCK_ROWS
+
+        def nblk(slot: int) -> int:
+            return (min(self.slots[slot].spec.batch_size, self.n_train) + rows - 1) // rows
+
+        def macs(slot: int) -> int:
+            lay = self.slots[slot].layout
+            return sum(h * k for h, k in zip(lay.hidden, lay.in_dims)) + sum(h * k for h, k in zip(lay.hidden[1:], lay.in_dims[1:]))
+
+        def cost(slot: int, n: int) -> float:
+            nl = len(self.slots[slot].layout.hidden)
+            bounds = nl + max(nl - 2, 0)          # every forward layer's output and all but the last two input gradients travel
+            return macs(slot) / n + (bounds * OPTIONS.rowblock_split_cost if n > 1 else 0)
+
+        def can(slot: int, n: int) -> bool:
+            return n <= OPTIONS.rowblock_split and all(h % (16 * n) == 0 for h in self.slots[slot].layout.hidden)
+
+        total = sum(nblk(slot) for slot in ids)
+        while True:
+            slot = max(ids, key=lambda k: (cost(k, parts[k]), -k))
+            n = parts[slot] * 2
+            if not can(slot, n) or cost(slot, n) >= cost(slot, parts[slot]):
+                break
+            if total + nblk(slot) * (n - parts[slot]) > OPTIONS.rowblock_wg_budget:
+                break
+            total += nblk(slot) * (n - parts[slot])
+            parts[slot] = n
+        return parts
+
+    def _rowblock_blocks(self, ids: List[int], mt: int, tag: str):
+        """The chain's row-block work lists: ((pointer, count) of the list that holds every trial, flags pointer, flag
+        count, [(first step, pointer, count) of up to three later lists]).  Trials with larger batches run out of steps
+        earlier in the epoch; from each such step on the chain works through a list without them, laid out -- and split
+        -- afresh for the trials that are left."""
+        def steps_of(slot: int) -> int:
+            return self.n_train // min(self.slots[slot].spec.batch_size, self.n_train)
+
+        ends = sorted({steps_of(slot) for slot in ids})[:-1][:3]       # the steps at which somebody drops out
+        lists = [self._rowblock_list(ids, mt, f"{tag}rb_blocks")]
+        later = []
+        for k, first in enumerate(ends):
+            left = [slot for slot in ids if steps_of(slot) > first]
+            ptr, n, any_split = self._rowblock_list(left, mt, f"{tag}rb_blocks_ph{k}")
+            lists.append((ptr, n, any_split))
+            later.append((first, ptr, n))
+        n_flags = max(n for _, n, _ in lists)
+        flags = 0
+        self._rb_flags.pop(tag, None)
+        if any(sp for _, _, sp in lists):
+            t = self._tables.get(f"{tag}rb_flags")
+            if not (isinstance(t, torch.Tensor) and t.numel() == n_flags + 1):
+                t = torch.zeros(n_flags + 1, dtype=torch.int32, device=self.device)
+                self._tables[f"{tag}rb_flags"] = t
+            self._rb_flags[tag] = t
+            flags = t.data_ptr()
+        return lists[0][:2], flags, n_flags, later
+
+    def _rowblock_list(self, ids: List[int], mt: int, name: str) -> Tuple[int, int, bool]:
+        """(device pointer, count, any block split) of one work list: one (slot, first row, part) entry per workgroup.  All blocks of a trial go to one XCD (workgroup b runs on XCD b % 8; they stream the same weights from
+        that XCD's L2), trials are dealt to the XCDs heaviest first, each to the XCD with the least work so far, and an
+        XCD's list starts with its heaviest blocks, so that the long chains start first and the short ones fill in behind
+        them.  The parts of a split block follow each other in their XCD's list (8 entries apart in the whole list)."""
         rows = ROWBLOCK_ROWS * mt
-        per_xcd: List[List[Tuple[float, int, int]]] = [[] for _ in range(N_XCD)]
+        split = self._rowblock_split(ids, mt)
+        # an XCD has 32 CUs and a row-block workgroup fills one (LDS): a trial whose blocks do not fit what is left of an
+        # XCD's first round spills onto the next emptiest XCD rather than queueing behind its own blocks
+        room_per_xcd = N_CU // N_XCD
+        per_xcd: List[List[Tuple[float, int, int, int]]] = [[] for _ in range(N_XCD)]
         load = [0.0] * N_XCD
         costs = []
         for slot in ids:
             lay = self.slots[slot].layout
             macs = sum(h * k for h, k in zip(lay.hidden, lay.in_dims)) + sum(h * k for h, k in zip(lay.hidden[1:], lay.in_dims[1:]))
-            costs.append((float(macs), slot))
+            costs.append((float(macs) / split[slot], slot))
         for macs, slot in sorted(costs, key=lambda c: (-c[0], c[1])):
-            x = min(range(N_XCD), key=lambda k: (load[k], k))
             b = min(self.slots[slot].spec.batch_size, self.n_train)
-            nblk = (b + rows - 1) // rows
-            per_xcd[x].extend((macs, slot, r * rows) for r in range(nblk))
-            load[x] += macs * nblk
+            n = split[slot]
+            groups = list(range((b + rows - 1) // rows))
+            while groups:
+                open_ = [k for k in range(N_XCD) if room_per_xcd - len(per_xcd[k]) >= n]
+                if open_:
+                    x = min(open_, key=lambda k: (load[k], k))
+                    take = groups[:(room_per_xcd - len(per_xcd[x])) // n]
+                else:                                    # every XCD's first round is full: the rest queues on the shortest list
+                    x = min(range(N_XCD), key=lambda k: (len(per_xcd[k]), load[k], k))
+                    take = groups[:max(1, room_per_xcd // n)]
+                groups = groups[len(take):]
+                per_xcd[x].extend((macs, slot, r * rows, part) for r in take for part in range(n))
+                load[x] += macs * len(take) * n
         depth = max(len(v) for v in per_xcd)
         arr = np.zeros(depth * N_XCD, dtype=L.RB_BLOCK_DTYPE)
         arr["slot"] = -1
         for x in range(N_XCD):
-            for k, (_, slot, row0) in enumerate(sorted(per_xcd[x], key=lambda e: (-e[0], e[1], e[2]))):
-                arr[k * N_XCD + x] = (slot, row0)
-        return self._upload(f"{tag}rb_blocks", arr), len(arr)
+            for k, (_, slot, row0, part) in enumerate(sorted(per_xcd[x], key=lambda e: (-e[0], e[1], e[2], e[3]))):
+                n = split[slot]
+                arr[k * N_XCD + x] = (slot, row0 | (part << 20) | ((n if n > 1 else 0) << 24))
+        return self._upload(name, arr), len(arr), any(n > 1 for n in split.values())
 
     def _build_plan(self, eval_mode: bool, slot_ids: Optional[List[int]] = None, tag: Optional[str] = None,
                     scratch: Optional[torch.Tensor] = None) -> L.MlpPlan:
@@ -654,7 +736,9 @@ class HipPackEngine(PackEngine):
                 plan.wgrad_groups[l], plan.wgrad_tiles[l], plan.wgrad_ntiles[l] = gt[f"wgrad{l}"]
         if gt.get("rb_mt"):
             plan.rb_mt = gt["rb_mt"]
-            plan.rb_blocks, plan.rb_nblocks = gt["rb_blocks"]
+            (plan.rb_blocks, plan.rb_nblocks), plan.rb_flags, plan.rb_nflags, later = gt["rb_blocks"]
+            for k, (first, ptr, n) in enumerate(later):
+                plan.rb_ph_from[k], plan.rb_ph_blocks[k], plan.rb_ph_nblocks[k] = first, ptr, n
             plan.wg_all_groups, plan.wg_all_tiles, plan.wg_all_ntiles, plan.wg_all_edge = gt["wg_all"]
         head = np.zeros(T, dtype=L.HEAD_DTYPE)
         for slot, s in members:
@@ -744,8 +828,18 @@ class HipPackEngine(PackEngine):
             groups[i:i + 1] = [groups[i][0::2], groups[i][1::2]]
         return [sorted(g) for g in groups]
 
+    def _check_rb_errors(self) -> None:
+        """The word behind a chain's exchange flags is raised by a part of a split row block that gave up waiting for its
+        partner; read where the host has synchronised anyway (before the chains are rebuilt, and when the engine closes)."""
+        for tag, flags in self._rb_flags.items():
+            if int(flags[-1].item()) != 0:
+                raise L.KernelLibraryError(f"row-block exchange timed out in chain {tag!r}: a part of a split block never saw "
+                                           "its partner's flag, the results of the last epochs are not to be trusted")
+
     def _build_chains(self) -> None:
         torch.cuda.synchronize(self.device)      # nothing may still be replaying a graph that is about to go
+        self._check_rb_errors()
+        self._rb_flags = {}
         self._drop_graphs()
         parts = self._partition(self._n_chains())
         n = len(parts)
@@ -792,6 +886,8 @@ class HipPackEngine(PackEngine):
         for ch in self._chains:
             ch.steps = self._epoch_tables(ch.plan, ch.ids, ch.tag)
         self.loss_acc.zero_()
+        for flags in self._rb_flags.values():
+            flags[:-1].zero_()        # split row blocks count their exchanges up from zero through an epoch
         main = torch.cuda.current_stream(self.device)
         if len(self._chains) == 1:
             ch = self._chains[0]
@@ -889,4 +985,5 @@ class HipPackEngine(PackEngine):
     def close(self) -> None:
         if self._chains:
             torch.cuda.synchronize(self.device)
+            self._check_rb_errors()
             self._drop_graphs()

@@ -29,10 +29,12 @@ def _data(n=8000, f=64, seed=0):
     return (X[:k], y[:k]), (X[k:], y[k:])
 
 
-def _run(form, monkeypatch, configs, slots, epochs=2, capacity=8, seed=5):
+def _run(form, monkeypatch, configs, slots, epochs=2, capacity=8, seed=5, split=1, split_cost=150000):
     from mitune.options import OPTIONS
     from mitune.packed import PackedTrainable, engine_hip
     monkeypatch.setattr(OPTIONS, "rowblock", form)
+    monkeypatch.setattr(OPTIONS, "rowblock_split", split)
+    monkeypatch.setattr(OPTIONS, "rowblock_split_cost", split_cost)
     train, val = _data(seed=3)
     tr = PackedTrainable(train=train, val=val, max_epochs=epochs, val_chunk=512, dtype="f32",
                          model_kwargs={"max_width": 512, "max_layers": 4, "max_batch": 512})
@@ -44,6 +46,8 @@ def _run(form, monkeypatch, configs, slots, epochs=2, capacity=8, seed=5):
         eng.train_epoch()
         hist.append(eng.evaluate())
     used = [int(ch.plan.rb_nblocks) for ch in eng._chains]
+    if split > 1:
+        used = [eng._rowblock_split(ch.ids, int(ch.plan.rb_mt)) for ch in eng._chains]
     states = {slot: eng.export(slot) for slot in slots}
     eng.close()
     return hist, states, used
@@ -83,3 +87,38 @@ def test_small_packs_take_the_row_block_step_and_unsupported_shapes_the_tiles(mo
     odd = dict(CONFIGS[0], hidden_sizes=[64, 40])           # 40 columns: not a multiple of 32
     _, _, used = _run("auto", monkeypatch, [(1, CONFIGS[0]), (2, odd)], [0, 1], epochs=1)
     assert all(n == 0 for n in used)
+
+
+def test_blocks_split_over_several_workgroups_give_the_same_bits(monkeypatch):
+    """Two or four workgroups per 16-row block, each computing a share of every layer's columns and fetching the others'
+    through memory behind a flag: the trained weights, optimiser state and metrics are those of unsplit blocks (and so of
+    the tile launches).  An exchange cost of zero makes the rule split whatever divides."""
+    cfgs = list(enumerate(CONFIGS, start=3))
+    slots = [4, 0, 6, 1, 3]
+    h_one, s_one, _ = _run("1", monkeypatch, cfgs, slots)
+    h_sp, s_sp, split = _run("1", monkeypatch, cfgs, slots, split=2, split_cost=0)
+    parts = {slot: n for ch in split for slot, n in ch.items()}
+    assert max(parts.values()) == 2 and sum(n == 2 for n in parts.values()) >= 2, parts
+    for slot in slots:
+        _same(s_one[slot], s_sp[slot], f"split2.slot{slot}")
+    assert h_one == h_sp
+    wide = [{"hidden_sizes": [512, 256, 128], "batch_size": 256, "learning_rate": 1e-3, "optimizer": "adamw"},
+            {"hidden_sizes": [64, 64], "batch_size": 100, "learning_rate": 3e-3, "optimizer": "adam", "loss_function": "huber"},
+            {"hidden_sizes": [256, 512, 512, 64], "batch_size": 512, "learning_rate": 1e-3, "optimizer": "sgd", "momentum": 0.9}]
+    cfgs, slots = list(enumerate(wide, start=11)), [2, 5, 0]
+    h_one, s_one, _ = _run("1", monkeypatch, cfgs, slots)
+    h_sp, s_sp, split = _run("1", monkeypatch, cfgs, slots, split=4, split_cost=0)
+    parts = {slot: n for ch in split for slot, n in ch.items()}
+    assert max(parts.values()) == 4 and parts[0] == 4, parts
+    for slot in slots:
+        _same(s_one[slot], s_sp[slot], f"split4.slot{slot}")
+    assert h_one == h_sp
+
+
+def test_split_rule_keeps_the_work_list_within_the_chip(monkeypatch):
+    from mitune.options import OPTIONS
+    monkeypatch.setattr(OPTIONS, "rowblock_wg_budget", 40)
+    cfgs = [(i, dict(CONFIGS[0], hidden_sizes=[512, 512], batch_size=256)) for i in range(2)]
+    _, _, split = _run("1", monkeypatch, cfgs, [0, 1], epochs=1, split=4, split_cost=0)
+    # 2 x 16 blocks: one trial may double (48 > 40 is refused, so neither does) -- the list never outgrows the budget
+    assert sum(16 * n for ch in split for n in ch.values()) <= 40
