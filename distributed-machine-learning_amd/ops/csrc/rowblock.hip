@@ -31,7 +31,8 @@
 
 // Geometry per row-tile count MT.  16 rows: sixteen waves of at most two tiles each -- four waves per SIMD cover each
 // other's DMA issue and LDS round trips better than two (critical workgroup of the 16-survivor pack 184 k -> 163 k
-// clocks); 32 rows: eight waves of at most four tiles (the MFMA work per fragment doubles, and so do the registers).
+// clocks); 32 rows: eight waves of at most four tiles (the MFMA work per fragment doubles, and so do the registers) --
+// measured no faster on any pack; the launcher builds the 16-row form only.
 template <int MT> struct RbCfg {
   static constexpr int NW = MT == 1 ? 16 : 8;                  // waves per workgroup
   static constexpr int THREADS = NW * 64;
@@ -635,8 +636,9 @@ extern "C" void mt_rowblock_set_prof(unsigned long long* buf) { rb_prof_buffer =
 extern "C" int mt_rb_args_sizeof() { return (int)sizeof(MtRbArgs); }
 extern "C" int mt_rowblock_max_width() { return RB_MAXW; }
 
-// blocks: n_blocks entries (slot, first row), one workgroup each; rows per workgroup = 16 * mt (mt = 1 or 2), and a
-// slot's entries must cover its batch in steps of that many rows.  Every layer of every listed slot must be at most
+// blocks: n_blocks entries (slot, first row), one workgroup each; rows per workgroup = 16 * mt (mt = 1: the 32-row form,
+// eight waves of four tiles, measured no faster on any pack and is no longer built), and a slot's entries must cover its
+// batch in steps of that many rows.  Every layer of every listed slot must be at most
 // mt_rowblock_max_width() wide (input rows included); the caller checks (the tables live in device memory).
 extern "C" int mt_mlp_rowblock_launch(const MtRbArgs* args, int n_blocks, int mt, int step, hipStream_t stream) {
   if (n_blocks <= 0) return 0;
@@ -648,8 +650,6 @@ extern "C" int mt_mlp_rowblock_launch(const MtRbArgs* args, int n_blocks, int mt
   a.prof = rb_prof_buffer;
   if (mt == 1)
     hipLaunchKernelGGL(mt_mlp_rowblock_kernel<1>, dim3(n_blocks), dim3(RbCfg<1>::THREADS), 0, stream, a, step, mt_step_base_tls);
-  else if (mt == 2)
-    hipLaunchKernelGGL(mt_mlp_rowblock_kernel<2>, dim3(n_blocks), dim3(RbCfg<2>::THREADS), 0, stream, a, step, mt_step_base_tls);
   else
     return -2;
   return (int)hipGetLastError();

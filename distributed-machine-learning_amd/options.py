@@ -34,11 +34,9 @@ class EngineOptions:
     streams: int = 0                  # force this many chains for every pack (0: the rules above)
     rowblock: str = "auto"            # exact-f32 row-block step: "auto" (chains of <= rowblock_max_blocks blocks), "1", "0"
     rowblock_max_blocks: int = 400
-    rowblock_mt: int = 1              # 16-row tiles per row-block workgroup (2: at most 4 layers)
     rowblock_split: int = 4           # most workgroups that may share one 16-row block, each taking 1/n of every layer's columns (1: never split)
     rowblock_split_cost: int = 50000  # what one exchange between the parts of a split block costs, in multiply-adds of a 16-row chain
     rowblock_wg_budget: int = 256     # a chain is only split while its work list stays within this many workgroups (one per CU)
-    rowblock_big: bool = False        # "auto": chains past rowblock_max_blocks take the row-block step with 32-row blocks
     chain_debug: bool = False         # print every chain's composition when a plan is built
     # ---- packs of sequence-model trials on grouped launches (packed/engine_seq.py)
     seq_engine: bool = True           # False keeps sample-Transformer packs on one captured step per trial

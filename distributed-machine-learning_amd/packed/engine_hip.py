@@ -81,7 +81,7 @@ DTYPES = ("bf16", "f32")
 # per chain: "auto" takes it for chains of at most ROWBLOCK_MAX_BLOCKS 16-row blocks (the late rounds of a search, where a
 # step is bound by launch latencies), "1" whenever the shapes allow (every width and the feature count a multiple of 32,
 # at most 512), "0" never.
-# (OPTIONS.rowblock, OPTIONS.rowblock_max_blocks; OPTIONS.rowblock_mt: row tiles of 16 per workgroup, 2 for at most 4 layers)
+# (OPTIONS.rowblock, OPTIONS.rowblock_max_blocks)
 ROWBLOCK_ROWS = 16
 
 def ceil8(x: int) -> int:
@@ -592,12 +592,7 @@ class HipPackEngine(PackEngine):
                 return 0
             blocks += (min(s.spec.batch_size, self.n_train) + ROWBLOCK_ROWS - 1) // ROWBLOCK_ROWS
         if OPTIONS.rowblock != "1" and blocks > OPTIONS.rowblock_max_blocks:
-            # big chains: 32-row blocks (half the weight bytes streamed per row) where the kernel has them, if asked for
-            if OPTIONS.rowblock_big and all(len(self.slots[k].layout.hidden) <= 4 for k in ids):
-                return 2
             return 0
-        if OPTIONS.rowblock_mt == 2 and all(len(self.slots[k].layout.hidden) <= 4 for k in ids):
-            return 2
         return 1
 
     def _rowblock_split(self, ids: List[int], mt: int) -> Dict[int, int]:
