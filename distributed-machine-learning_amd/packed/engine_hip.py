@@ -27,6 +27,7 @@ import torch
 
 from .engine import PackEngine
 from .permutation import half_bits, round_keys
+from . import rowblock_plan
 from .trainable import PackedTrainable
 from ..models.mlp import MLPTrialSpec, init_mlp_state
 from ..ops import lib as L
@@ -595,43 +596,18 @@ class HipPackEngine(PackEngine):
             return 0
         return 1
 
+    def _rb_trials(self, ids: List[int]) -> List["rowblock_plan.RbTrial"]:
+        out = []
+        for slot in ids:
+            s = self.slots[slot]
+            nblk = (min(s.spec.batch_size, self.n_train) + ROWBLOCK_ROWS - 1) // ROWBLOCK_ROWS
+            out.append(rowblock_plan.RbTrial(slot, nblk, tuple(s.layout.hidden), tuple(s.layout.in_dims)))
+        return out
+
     def _rowblock_split(self, ids: List[int], mt: int) -> Dict[int, int]:
-        """Workgroups per 16-row block for every slot of a chain (1, 2 or 4).  A block's chain of layers runs on one CU, and
-        a step is as long as the longest chain; splitting a block over n workgroups cuts its weight stream and matrix
-        instructions by n at the price of one exchange through memory per layer boundary.  Greedy: the slot with the
-        longest chain is split further while that shortens it and the work list still fits the chip in one go (one
-        workgroup per CU: the parts of a block wait for each other, so all of them must be running)."""
-        parts = {slot: 1 for slot in ids}
-        if mt != 1 or OPTIONS.rowblock_split <= 1:
-            return parts
-        rows = ROWBLOCK_ROWS
-
-        def nblk(slot: int) -> int:
-            return (min(self.slots[slot].spec.batch_size, self.n_train) + rows - 1) // rows
-
-        def macs(slot: int) -> int:
-            lay = self.slots[slot].layout
-            return sum(h * k for h, k in zip(lay.hidden, lay.in_dims)) + sum(h * k for h, k in zip(lay.hidden[1:], lay.in_dims[1:]))
-
-        def cost(slot: int, n: int) -> float:
-            nl = len(self.slots[slot].layout.hidden)
-            bounds = nl + max(nl - 2, 0)          # every forward layer's output and all but the last two input gradients travel
-            return macs(slot) / n + (bounds * OPTIONS.rowblock_split_cost if n > 1 else 0)
-
-        def can(slot: int, n: int) -> bool:
-            return n <= OPTIONS.rowblock_split and all(h % (16 * n) == 0 for h in self.slots[slot].layout.hidden)
-
-        total = sum(nblk(slot) for slot in ids)
-        while True:
-            slot = max(ids, key=lambda k: (cost(k, parts[k]), -k))
-            n = parts[slot] * 2
-            if not can(slot, n) or cost(slot, n) >= cost(slot, parts[slot]):
-                break
-            if total + nblk(slot) * (n - parts[slot]) > OPTIONS.rowblock_wg_budget:
-                break
-            total += nblk(slot) * (n - parts[slot])
-            parts[slot] = n
-        return parts
+        """Workgroups per 16-row block for every slot of a chain (rowblock_plan.split_parts with this engine's options)."""
+        return rowblock_plan.split_parts(self._rb_trials(ids), OPTIONS.rowblock_split if mt == 1 else 1,
+                                         OPTIONS.rowblock_split_cost, OPTIONS.rowblock_wg_budget)
 
     def _rowblock_blocks(self, ids: List[int], mt: int, tag: str):
         """The chain's row-block work lists: ((pointer, count) of the list that holds every trial, flags pointer, flag
@@ -662,44 +638,9 @@ class HipPackEngine(PackEngine):
         return lists[0][:2], flags, n_flags, later
 
     def _rowblock_list(self, ids: List[int], mt: int, name: str) -> Tuple[int, int, bool]:
-        """(device pointer, count, any block split) of one work list: one (slot, first row, part) entry per workgroup.  All blocks of a trial go to one XCD (workgroup b runs on XCD b % 8; they stream the same weights from
-        that XCD's L2), trials are dealt to the XCDs heaviest first, each to the XCD with the least work so far, and an
-        XCD's list starts with its heaviest blocks, so that the long chains start first and the short ones fill in behind
-        them.  The parts of a split block follow each other in their XCD's list (8 entries apart in the whole list)."""
-        rows = ROWBLOCK_ROWS * mt
+        """(device pointer, count, any block split) of one work list (rowblock_plan.work_list), uploaded under ``name``."""
         split = self._rowblock_split(ids, mt)
-        # an XCD has 32 CUs and a row-block workgroup fills one (LDS): a trial whose blocks do not fit what is left of an
-        # XCD's first round spills onto the next emptiest XCD rather than queueing behind its own blocks
-        room_per_xcd = N_CU // N_XCD
-        per_xcd: List[List[Tuple[float, int, int, int]]] = [[] for _ in range(N_XCD)]
-        load = [0.0] * N_XCD
-        costs = []
-        for slot in ids:
-            lay = self.slots[slot].layout
-            macs = sum(h * k for h, k in zip(lay.hidden, lay.in_dims)) + sum(h * k for h, k in zip(lay.hidden[1:], lay.in_dims[1:]))
-            costs.append((float(macs) / split[slot], slot))
-        for macs, slot in sorted(costs, key=lambda c: (-c[0], c[1])):
-            b = min(self.slots[slot].spec.batch_size, self.n_train)
-            n = split[slot]
-            groups = list(range((b + rows - 1) // rows))
-            while groups:
-                open_ = [k for k in range(N_XCD) if room_per_xcd - len(per_xcd[k]) >= n]
-                if open_:
-                    x = min(open_, key=lambda k: (load[k], k))
-                    take = groups[:(room_per_xcd - len(per_xcd[x])) // n]
-                else:                                    # every XCD's first round is full: the rest queues on the shortest list
-                    x = min(range(N_XCD), key=lambda k: (len(per_xcd[k]), load[k], k))
-                    take = groups[:max(1, room_per_xcd // n)]
-                groups = groups[len(take):]
-                per_xcd[x].extend((macs, slot, r * rows, part) for r in take for part in range(n))
-                load[x] += macs * len(take) * n
-        depth = max(len(v) for v in per_xcd)
-        arr = np.zeros(depth * N_XCD, dtype=L.RB_BLOCK_DTYPE)
-        arr["slot"] = -1
-        for x in range(N_XCD):
-            for k, (_, slot, row0, part) in enumerate(sorted(per_xcd[x], key=lambda e: (-e[0], e[1], e[2], e[3]))):
-                n = split[slot]
-                arr[k * N_XCD + x] = (slot, row0 | (part << 20) | ((n if n > 1 else 0) << 24))
+        arr = rowblock_plan.encode(rowblock_plan.work_list(self._rb_trials(ids), split, ROWBLOCK_ROWS), L.RB_BLOCK_DTYPE)
         return self._upload(name, arr), len(arr), any(n > 1 for n in split.values())
 
     def _build_plan(self, eval_mode: bool, slot_ids: Optional[List[int]] = None, tag: Optional[str] = None,
