@@ -28,7 +28,7 @@ class EngineOptions:
     big_cost: float = 3.5             # ... and a 256-tile is priced at this many 128-tiles when padding is compared
     ksplits_small: int = 4            # weight-gradient splits over the batch for packs of at most 128 tiles
     f32_small_tiles: int = 2048       # exact-f32 packs: launches with fewer 128-tiles than this use 64x64 tiles
-    f32_tiny_tiles: int = 512         # ... and launches with fewer 64-tiles than this use 32x32 tiles
+    f32_tiny_tiles: int = 1024        # ... and launches with fewer 64-tiles than this use 32x32 tiles
     f32_chain_rule: str = "128:4,32:2"   # "min_slots:chains,...": independent chains of launches on separate HIP streams
     chains_by_batch: bool = True      # one chain per batch size (a chain's step count is that of its smallest batch)
     streams: int = 0                  # force this many chains for every pack (0: the rules above)
