@@ -1,12 +1,15 @@
 set -e
-mkdir -p gpurun_out/ex
-timeout -k 10 100 python bench.py --no-bf16 > gpurun_out/ex/lock.json 2> gpurun_out/ex/lock.err
-MITUNE_BENCH_EXCHANGE_1GPU=1 timeout -k 10 100 python bench.py --no-bf16 > gpurun_out/ex/rungs.json 2> gpurun_out/ex/rungs.err || tail -5 gpurun_out/ex/rungs.err
-MITUNE_BENCH_EXCHANGE_1GPU=1 timeout -k 10 100 python bench.py --no-bf16 --steps 20 --warmup 5 > gpurun_out/ex/rungs20.json 2> gpurun_out/ex/rungs20.err || tail -5 gpurun_out/ex/rungs20.err
-timeout -k 10 100 python bench.py --no-bf16 --steps 20 --warmup 5 > gpurun_out/ex/lock20.json 2> gpurun_out/ex/lock20.err
-python - <<'PY'
+mkdir -p gpurun_out/prio
+LIB=distributed-machine-learning_amd/ops/libmitune_hip.so
+for m in 0 1 2; do
+  cp bench/ab/lib_mode$m.so $LIB
+  for s in 16 4; do
+    timeout -k 10 100 python bench/small_pack_micro.py --forms 1s1,1s4 --slots $s --check > gpurun_out/prio/m${m}_${s}.json 2> gpurun_out/prio/m${m}_${s}.err
+    python -c "
 import json
-for n in ('lock','rungs','lock20','rungs20'):
-    d=json.load(open(f'gpurun_out/ex/{n}.json'))
-    print(n, round(d['value']), round(d['elapsed_s'],3), d['best_validation_mse'], d['slot_epochs'], d['train_s'], d['eval_s'])
-PY
+d=json.load(open('gpurun_out/prio/m${m}_${s}.json'))['forms']
+print('prio mode $m slots $s', round(d['1s1']['us_per_step'],1), round(d['1s4']['us_per_step'],1), d.get('n_mismatches'))
+"
+  done
+done
+cp bench/ab/lib_mode0.so $LIB
