@@ -1,15 +1,11 @@
 set -e
-mkdir -p gpurun_out/prio
-LIB=distributed-machine-learning_amd/ops/libmitune_hip.so
-for m in 0 1 2; do
-  cp bench/ab/lib_mode$m.so $LIB
-  for s in 16 4; do
-    timeout -k 10 100 python bench/small_pack_micro.py --forms 1s1,1s4 --slots $s --check > gpurun_out/prio/m${m}_${s}.json 2> gpurun_out/prio/m${m}_${s}.err
-    python -c "
+mkdir -p gpurun_out/reg
+timeout -k 10 100 python bench/small_pack_micro.py --forms 1s1,1s1g --slots 4 --stamps > gpurun_out/reg/st4.json 2> gpurun_out/reg/st4.err
+python - <<'PY'
 import json
-d=json.load(open('gpurun_out/prio/m${m}_${s}.json'))['forms']
-print('prio mode $m slots $s', round(d['1s1']['us_per_step'],1), round(d['1s4']['us_per_step'],1), d.get('n_mismatches'))
-"
-  done
-done
-cp bench/ab/lib_mode0.so $LIB
+d=json.load(open('gpurun_out/reg/st4.json'))['forms']
+for f,v in d.items():
+    print(f, round(v['us_per_step'],1))
+    for s,st in v['stamps_ticks_median_by_slot'].items():
+        print('  slot',s,v['widths_by_slot'][s], st)
+PY
