@@ -101,24 +101,13 @@ def main():
     import mitune
     from mitune.packed import PackedTrainable
     from mitune.packed.executor import PackedExecutor
-    from mitune.parallel.comm import LocalComm, TorchDistComm
+    from mitune.parallel.comm import open_comm
     from mitune.schedulers import ASHAScheduler
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        # RCCL over xGMI; MITUNE_COMM_BACKEND=gloo rehearses the multi-process path on a box with fewer GPUs than ranks
-        backend = os.environ.get("MITUNE_COMM_BACKEND", "nccl")
-        if backend == "nccl":
-            comm = TorchDistComm(backend="nccl")
-            device = comm.device
-        else:
-            comm = TorchDistComm(backend=backend)
-            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
-            torch.cuda.set_device(device)
-    else:
-        device = torch.device("cuda", 0)
-        torch.cuda.set_device(device)
-        comm = LocalComm(device)
+    # one process per GPU under the launcher: RCCL over xGMI (MITUNE_COMM_BACKEND=gloo rehearses the multi-process path on a
+    # box with fewer GPUs than ranks; gloo is also what the job falls back to if RCCL cannot form the group)
+    comm, device = open_comm()
+    torch.cuda.set_device(device)
     if args.gpus != comm.world_size and comm.rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE is {comm.world_size}; using {comm.world_size}",
               file=sys.stderr)

@@ -431,6 +431,51 @@ class ThreadComm(Comm):
         return self._exchange(obj if self.rank == src else None)[src]
 
 
+def open_comm(prefer: Optional[str] = None, timeout_s: float = 600.0):
+    """The rank's communicator and compute device for a job started by a launcher (``WORLD_SIZE`` > 1), or a local
+    no-op communicator.  RCCL (backend ``"nccl"``) is tried first; when it cannot form the group -- a node whose driver
+    refuses the IPC handles RCCL needs, fewer GPUs than ranks on a rehearsal box -- the job goes on over gloo on the
+    next port instead of ending there: what the ranks exchange per round is a table of a few kilobytes, so the
+    backend changes what a data-parallel trial costs, not what a packed search measures.  ``prefer`` (or
+    ``MITUNE_COMM_BACKEND``) names a backend to use without trying the other.  Every rank takes the same decision:
+    group creation with a ``device_id`` is collective and eager, so a failure shows on all of them."""
+    import sys
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local % n_dev) if n_dev else torch.device("cpu")
+    if world <= 1:
+        return LocalComm(device), device
+    backend = prefer or os.environ.get("MITUNE_COMM_BACKEND")
+    if backend is None:
+        # more ranks on this node than GPUs (a rehearsal box): RCCL refuses two ranks on one device, and every rank of the
+        # node can tell from the launcher's environment alone, so all of them go to gloo without trying
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
+        backend = "nccl" if n_dev and local_world <= n_dev else "gloo"
+    if backend == "nccl":
+        try:
+            comm = TorchDistComm(backend="nccl", timeout_s=timeout_s)
+            probe = torch.ones(1, device=comm.device)
+            comm.all_reduce(probe)                       # the first collective proves the communicator
+            if int(probe.item()) != world:
+                raise RuntimeError(f"all-reduce over {world} ranks returned {probe.item()}")
+            return comm, comm.device
+        except Exception as e:      # noqa: BLE001 - RCCL reports through several exception types
+            print(f"[mitune] rank {os.environ.get('RANK', '?')}: RCCL group not formed ({type(e).__name__}: "
+                  f"{str(e).splitlines()[0] if str(e) else ''}); continuing over gloo", file=sys.stderr, flush=True)
+            import torch.distributed as dist
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:       # noqa: BLE001
+                pass
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            backend = "gloo"
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    return TorchDistComm(backend=backend, timeout_s=timeout_s), device
+
+
 def default_comm() -> Comm:
     """RCCL/gloo group when launched under torchrun (WORLD_SIZE > 1), else a local no-op comm."""
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:

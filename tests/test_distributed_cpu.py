@@ -731,3 +731,32 @@ def test_file_rendezvous_gives_every_survivor_the_same_member_list(tmp_path, wor
         assert "after the survivors" in errs[late]
     else:
         assert not errs
+
+
+def test_open_comm_is_local_without_a_launcher_and_picks_gloo_for_more_ranks_than_gpus(monkeypatch):
+    """``open_comm`` decides from the launcher's environment alone, the same way on every rank: no launcher -> a local
+    no-op communicator; more ranks on the node than GPUs (here: none) -> gloo without trying RCCL."""
+    import torch.distributed as dist
+    from mitune.parallel import comm as C
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MITUNE_COMM_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+    c, device = C.open_comm()
+    assert isinstance(c, C.LocalComm) and c.world_size == 1 and device.type in ("cpu", "cuda")
+    chosen = {}
+
+    class Fake(C.Comm):
+        def __init__(self, backend=None, **kw):
+            chosen["backend"] = backend
+            self.rank, self.world_size, self.backend = 0, 2, backend
+
+    monkeypatch.setattr(C, "TorchDistComm", Fake)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    monkeypatch.setattr(C.torch.cuda, "is_available", lambda: False)
+    c, device = C.open_comm()
+    assert chosen["backend"] == "gloo" and device.type == "cpu"
+    monkeypatch.setenv("MITUNE_COMM_BACKEND", "gloo")
+    chosen.clear()
+    C.open_comm()
+    assert chosen["backend"] == "gloo"
+    assert not dist.is_initialized()
