@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--verbose", type=int, default=0)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="compute dtype of the timed search")
+    ap.add_argument("--val-chunk", type=int, default=4096, help="validation rows per launch")
     ap.add_argument("--no-bf16", action="store_true", help="skip the second, untimed-for-the-headline bf16 search")
     ap.add_argument("--exchange", choices=["lockstep", "rungs", "async"], default="rungs",
                     help="multi-rank metric exchange: 'lockstep' gathers and decides on every round; 'rungs' (default) keeps "
@@ -122,7 +123,7 @@ def main():
         # ones dealt would be forced onto whichever rank still has room.  The number of trials per GPU does not change.
         slots = trials_per_gpu + (max(8, trials_per_gpu // 32) if n_gpus > 1 else 0)
         tr = PackedTrainable(train=train, val=val, max_epochs=rounds, engine="hip", dtype=dtype,
-                             capacity=slots, val_chunk=4096, model_kwargs=kw, name="bench_mlp",
+                             capacity=slots, val_chunk=args.val_chunk, model_kwargs=kw, name="bench_mlp",
                              exchange=args.exchange if n_gpus > 1 else "lockstep")
         ex = PackedExecutor(tr, comm=comm, device=device, capacity=slots, seed=seed)
         sched = ASHAScheduler(metric="validation_loss", mode="min", max_t=rounds, grace_period=1, reduction_factor=4)
