@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -606,8 +607,11 @@ class HipPackEngine(PackEngine):
 
     def _rowblock_split(self, ids: List[int], mt: int) -> Dict[int, int]:
         """Workgroups per 16-row block for every slot of a chain (rowblock_plan.split_parts with this engine's options)."""
+        # ranks that share a GPU (more ranks on the node than devices: a rehearsal box) share its CUs too
+        n_dev = max(1, torch.cuda.device_count())
+        share = max(1, -(-int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1) // n_dev))
         return rowblock_plan.split_parts(self._rb_trials(ids), OPTIONS.rowblock_split if mt == 1 else 1,
-                                         OPTIONS.rowblock_split_cost, OPTIONS.rowblock_wg_budget)
+                                         OPTIONS.rowblock_split_cost, OPTIONS.rowblock_wg_budget // share)
 
     def _rowblock_blocks(self, ids: List[int], mt: int, tag: str):
         """The chain's row-block work lists: ((pointer, count) of the list that holds every trial, flags pointer, flag
