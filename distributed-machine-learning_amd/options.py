@@ -41,6 +41,7 @@ class EngineOptions:
     # ---- packs of sequence-model trials on grouped launches (packed/engine_seq.py)
     seq_engine: bool = True           # False keeps sample-Transformer packs on one captured step per trial
     xf_engine: bool = True            # False keeps packs of the configurable Transformer on one captured step per trial
+    xf_tiny_tiles: int = 512          # program engine: launches with fewer 64-tiles than this use 32x32 tiles
     xf_bf16_big_tiles: int = 256      # program engine, bf16 products: launches with at least this many 128-tiles take them
     seq_prep_threads: int = 2         # host threads drawing the next trials' initial weights
     seq_ksplits: int = 2              # weight-gradient slabs over the token rows

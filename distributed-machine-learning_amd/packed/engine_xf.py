@@ -754,7 +754,7 @@ class XfPackEngine(PackEngine):
             # bf16 products leave the tile bound by LDS reads and DMA instead of the matrix pipe: 128-tiles halve both per flop
             big = OPTIONS.xf_bf16_big_tiles if self.product_flag else OPTIONS.f32_small_tiles
             edge = 128 if count(128) >= big else 64
-            if edge == 64 and count(64) < OPTIONS.f32_tiny_tiles:
+            if edge == 64 and count(64) < OPTIONS.xf_tiny_tiles:
                 edge = 32
             if mode == 2:
                 edge = min(edge, 64)        # weight gradients: few tiles, each as long as the token count
@@ -767,7 +767,11 @@ class XfPackEngine(PackEngine):
                 if mode == 2:
                     C0, db, KK = rec[2], rec[4], rec[8]
                     n = r * c + (r if db else 0)
-                    ks = max(1, min(16, (WGRAD_TARGET_TILES + ti * tj - 1) // (ti * tj), (KK // 32) // 4))
+                    # the split count follows the layer's OWN shape (its 64-tile count), not the edge this launch happens
+                    # to use: the edge depends on who else is in the pack, and the split count decides the order in which
+                    # a gradient is summed -- a trial's numbers may not depend on its neighbours
+                    t64 = ((r + 63) // 64) * ((c + 63) // 64)
+                    ks = max(1, min(16, (WGRAD_TARGET_TILES + t64 - 1) // t64, (KK // 32) // 4))
                     if ks > 1 and n % 4 == 0 and (not db or db == C0 + r * c * 4):
                         sums.append((k, C0, slab, n, ks, rec[13]))
                         slab += n

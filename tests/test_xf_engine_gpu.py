@@ -159,6 +159,27 @@ def test_a_mixed_pack_matches_the_trials_trained_alone_bitwise():
         assert np.isfinite(m["train_loss"]) and np.isfinite(m["validation_mape"])
 
 
+def test_a_pack_trains_to_the_same_bits_on_32_tiles_and_on_64_tiles(monkeypatch):
+    """The tile edge of a grouped GEMM launch follows the launch's size, i.e. who else is resident; a trial's weights and
+    metrics must not (same contraction order on every edge, weight-gradient splits chosen from the layer's own shape)."""
+    from mitune.options import OPTIONS
+    cfgs = [dict(c, dropout=0.1) for c in CONFIGS]
+    out = []
+    for tiny in (0, 10 ** 9):                  # never 32-tiles / 32-tiles for every launch below the 128-tile threshold
+        monkeypatch.setattr(OPTIONS, "xf_tiny_tiles", tiny)
+        pack = _xf(_trainable())
+        for slot, (i, c) in zip((5, 0, 3, 2, 7, 1), enumerate(cfgs)):
+            pack.load(slot, 30 + i, c)
+        for _ in range(2):
+            pack.train_epoch()
+        out.append((pack.evaluate(), {slot: pack.export(slot)["model"] for slot in (5, 0, 3, 2, 7, 1)}))
+    (m64, w64), (m32, w32) = out
+    assert m64 == m32
+    for slot in w64:
+        for k in w64[slot]:
+            assert torch.equal(w64[slot][k], w32[slot][k]), (slot, k)
+
+
 def test_dropout_and_stochastic_depth_change_training_and_not_evaluation():
     tr = _trainable()
     eng = _xf(tr)
