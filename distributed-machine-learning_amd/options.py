@@ -26,7 +26,8 @@ class EngineOptions:
     # ---- packs of MLP trials on grouped launches (packed/engine_hip.py)
     big_min_tiles: int = 256          # bf16 packs: a launch takes 256x256 tiles when it has at least this many (0: never)
     big_cost: float = 3.5             # ... and a 256-tile is priced at this many 128-tiles when padding is compared
-    ksplits_small: int = 4            # weight-gradient splits over the batch for packs of at most 128 tiles
+    ksplits_small: int = 1            # weight-gradient splits over the batch for packs of at most 32 / 64 tiles (4 / 2 at most); 1 = never:
+                                      # the split count follows the PACK's size, so anything else lets a trial's rounding depend on its neighbours
     f32_small_tiles: int = 2048       # exact-f32 packs: launches with fewer 128-tiles than this use 64x64 tiles
     f32_tiny_tiles: int = 1024        # ... and launches with fewer 64-tiles than this use 32x32 tiles
     f32_chain_rule: str = "128:4,32:2"   # "min_slots:chains,...": independent chains of launches on separate HIP streams

@@ -91,6 +91,22 @@ def test_packing_invariance_is_bitwise(dtype):
         assert torch.equal(v, packed[2]["model"][k]), k
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_a_small_trial_alone_equals_the_same_trial_among_wide_neighbours(dtype):
+    """A pack of one narrow trial is a handful of weight-gradient tiles, a pack with six wide neighbours a hundred: launch
+    forms, tile edges and (by default) split counts may follow that, the trial's weights may not."""
+    from mitune.packed import PackedTrainable
+    from mitune.packed.engine_hip import HipPackEngine
+    train, val = _data(seed=2)
+    tr = PackedTrainable(train=train, val=val, max_epochs=2, val_chunk=512, dtype=dtype,
+                         model_kwargs={"max_width": 256, "max_layers": 3, "max_batch": 512})
+    _, alone = _run(HipPackEngine, tr, [(7, CONFIGS[1])], [0], 2, device="cuda", capacity=8, seed=5)
+    crowd = [(7, CONFIGS[1])] + [(20 + i, dict(CONFIGS[3], learning_rate=1e-3 * (i + 1))) for i in range(6)]
+    _, packed = _run(HipPackEngine, tr, crowd, [3, 0, 1, 2, 4, 5, 6], 2, device="cuda", capacity=8, seed=5)
+    for k, v in alone[0]["model"].items():
+        assert torch.equal(v, packed[3]["model"][k]), k
+
+
 def test_f32_results_do_not_depend_on_the_tile_edge(monkeypatch):
     """The exact-f32 engine picks 128-, 64- or 32-tiles from the size of the pack; a trial's weights must not notice."""
     from mitune.options import OPTIONS
@@ -304,11 +320,14 @@ def test_concurrent_chains_match_single_stream():
         assert a["train_loss"] == pytest.approx(b["train_loss"], rel=2e-3), slot
 
 
-def test_layer0_splits_its_weight_gradient_further_than_wide_layers():
-    """12 trials of [512, 512]: the 512x512 layer has enough tiles for one pass, layer 0 (20 features) does not, so the
-    two use different split counts and the optimiser must add the right number of slabs per region."""
+def test_layer0_splits_its_weight_gradient_further_than_wide_layers(monkeypatch):
+    """12 trials of [512, 512] with weight-gradient splits allowed (``ksplits_small``; off by default): the 512x512 layer
+    has enough tiles for one pass, layer 0 (20 features) does not, so the two use different split counts and the
+    optimiser must add the right number of slabs per region."""
+    from mitune.options import OPTIONS
     from mitune.packed import PackedTrainable, TorchPackEngine
     from mitune.packed.engine_hip import HipPackEngine
+    monkeypatch.setattr(OPTIONS, "ksplits_small", 4)
     train, val = _data(n=4000, seed=6)
     tr = PackedTrainable(train=train, val=val, max_epochs=1, val_chunk=512,
                          model_kwargs={"max_width": 512, "max_layers": 2, "max_batch": 512})
