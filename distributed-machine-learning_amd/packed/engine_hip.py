@@ -38,7 +38,6 @@ from ..train.optim import OPT_CODES
 
 TILE = 128
 N_XCD = 8
-N_CU = 256
 MAX_KSPLITS = 4        # weight-gradient slabs kept per slot (split-K over the batch for small packs)
 MAX_STREAMS = 4        # concurrent step chains, one HIP stream each
 BIG_TILE = 256         # tile edge of the throughput-form GEMM kernels
