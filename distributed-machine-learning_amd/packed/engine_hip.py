@@ -19,7 +19,6 @@ weights, same keyed-permutation batches, same step count per epoch, same metrics
 from __future__ import annotations
 
 import ctypes as C
-import math
 import os
 from typing import Any, Dict, List, Optional, Tuple
 

@@ -20,7 +20,7 @@ import os
 import tempfile
 import threading
 import time
-from typing import Any, List, Optional, Sequence
+from typing import Any, List, Optional
 
 import torch
 
